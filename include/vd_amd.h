@@ -1,0 +1,142 @@
+/* vd_amd.h -- C ABI of the MI355X-native video-diffusion denoise engine (libvdamd.so).
+ *
+ * The reference (cliangyu/video-diffusion) is pure Python and has no FFI; its seam for this hot path
+ * is a set of Python call signatures.  Each entry point below names the reference
+ * interface it replaces (paths relative to /root/reference).  All `const float*`/`float*` tensor
+ * arguments are DEVICE pointers owned by the caller unless the name says `host`; `stream` is a
+ * hipStream_t passed as void*.  Every function returns 0 on success or a negative code
+ * (-1 bad argument / unsupported configuration, -2 HIP runtime error); text via vd_last_error().
+ * No entry point synchronises the stream except vd_load_weight (a blocking H2D copy).
+ */
+#ifndef VD_AMD_H
+#define VD_AMD_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Keys of video_model_and_diffusion_defaults() that shape the network
+ * (improved_diffusion/script_util.py:15-57, create_video_model :229-300). */
+typedef struct vd_config {
+    int image_size;              /* 32 / 64 / 128 / 256 -> channel_mult table, script_util.py:255-264 */
+    int num_channels;
+    int num_res_blocks;
+    int num_heads;
+    int T;                       /* model's max_frames: only used by the frame-embedding period (unet.py:921) */
+    int n_attention_ds;          /* attention_resolutions converted to downsample rates, script_util.py:266-268 */
+    int attention_ds[8];
+    int use_scale_shift_norm;
+    int use_spatial_encoding;
+    int use_frame_encoding;
+    int enforce_position_invariance;
+    int use_rpe_net;
+    int allow_interactions_between_padding;
+    float rp_alpha, rp_beta, rp_gamma;   /* bucket parameters of the table RPE (unet.py:330-340) */
+    int time_embed_mult;         /* 4: time_embed_dim = 4*num_channels (unet.py:605) */
+} vd_config;
+
+typedef struct vd_engine vd_engine;
+
+const char* vd_last_error(void);
+const char* vd_version(void);
+
+/* CondMargVideoModel(...) constructor via create_video_model (script_util.py:229-300; unet.py:929-947).
+ * Host-only: builds the topology and the parameter table; touches no GPU. */
+int vd_create(const vd_config* cfg, vd_engine** out);
+void vd_destroy(vd_engine* e);
+
+/* model.state_dict() keys/shapes, in the reference's order (checkpoint format, train_util.py:570-574). */
+int vd_param_count(vd_engine* e);
+int vd_param_info(vd_engine* e, int index, char* name, int name_cap, int* ndim, long long shape[4]);
+
+/* model.load_state_dict(sd) (scripts/video_sample.py:565).  Weights live in ONE packed device buffer
+ * (engine layout: conv OIHW -> [tap][O][I], spatial_encoding -> [HW][C]) so that a single RCCL
+ * broadcast replaces dist_util.sync_params' per-tensor broadcasts (dist_util.py:139-143).
+ * The buffer is caller-owned (e.g. a torch tensor) and must outlive the engine. */
+long long vd_weights_bytes(vd_engine* e);
+int vd_set_weight_storage(vd_engine* e, void* dev_buffer, long long bytes);
+int vd_load_weight(vd_engine* e, const char* name, const float* host_data, long long numel);
+int vd_weights_missing(vd_engine* e);          /* number of parameters not loaded yet */
+int vd_mark_weights_loaded(vd_engine* e);      /* after receiving the packed buffer by broadcast */
+
+/* Channels / resolution of the tensor the positional encodings are added to (unet.py:669-675,914-926). */
+int vd_pos_channels(vd_engine* e);
+int vd_pos_resolution(vd_engine* e);
+
+/* Frequency tables of timestep_embedding / frame_embedding (nn.py:89-122), built by the host with
+ * the reference's own float32 expression so the angles agree bit for bit. */
+int vd_set_freqs(vd_engine* e, const float* host_time_freqs, int n_time, const float* host_frame_freqs, int n_frame);
+
+/* SpacedDiffusion tables (respace.py:68-82, gaussian_diffusion.py:123-172,299-317).
+ * host_tab: VD_NTAB rows of num_timesteps float32 (float64 tables cast like _extract_into_tensor,
+ * gaussian_diffusion.py:1019-1031), row order VD_TAB_*.  timestep_map + rescale = _WrappedModel
+ * (respace.py:111-119): t_model = map[t] * rescale (rescale = 1000/original_steps, or 1 with rescale off). */
+enum { VD_TAB_SQRT_RECIP = 0, VD_TAB_SQRT_RECIPM1, VD_TAB_COEF1, VD_TAB_COEF2, VD_TAB_LOGVAR, VD_TAB_ACP,
+       VD_TAB_ACP_PREV, VD_TAB_SQRT_ACP, VD_TAB_SQRT_1M_ACP, VD_NTAB };
+int vd_set_schedule(vd_engine* e, int num_timesteps, const float* host_tab, const int* host_timestep_map,
+                    float rescale);
+
+/* Bytes of engine-owned workspace a (B, T) window needs; allocated lazily by the first call. */
+int vd_workspace_bytes(vd_engine* e, int B, int T, long long* bytes);
+
+/* observed_frames: 0 'x_0', 1 'x_t', 2 'x_t_minus_1' (unet.py:958-974,991-1013). */
+
+/* Boundary A: model(x, timesteps, **model_kwargs) -> eps   (unet.py:949-1026 after respace.py:111-119).
+ * x, obs_src, eps: [B][T][3][H][W] fp32;  obs/lat/km masks: [B*T] fp32;  frame_indices: [B*T] int64;
+ * t_model: [B] fp32 value handed to the network. */
+int vd_unet_forward(vd_engine* e, int B, int T, const float* x, const float* obs_src, const float* obs_mask,
+                    const float* latent_mask, const float* kinda_marg_mask, const long long* frame_indices,
+                    const float* t_model, int observed_frames, float* eps, void* stream);
+
+/* diffusion.p_sample(model, x, t, clip_denoised, model_kwargs) -> {'sample','pred_xstart'}
+ * (gaussian_diffusion.py:403-448 through SpacedDiffusion.p_mean_variance, respace.py:84-86).
+ * t: [B] int64 respaced indices (device).  noise: explicit N(0,1) draws or NULL -> in-kernel
+ * Philox4x32-10(seed, offset).  x is not modified; sample/pred_xstart/eps are outputs (the last two may be NULL). */
+int vd_p_sample(vd_engine* e, int B, int T, const float* x, const float* obs_src, const float* obs_mask,
+                const float* latent_mask, const float* kinda_marg_mask, const long long* frame_indices,
+                const long long* t, int observed_frames, int clip_denoised, const float* noise,
+                unsigned long long seed, unsigned long long offset, float* sample, float* pred_xstart, float* eps,
+                void* stream);
+
+/* diffusion.ddim_sample(..., eta) (gaussian_diffusion.py:597-634). */
+int vd_ddim_sample(vd_engine* e, int B, int T, const float* x, const float* obs_src, const float* obs_mask,
+                   const float* latent_mask, const float* kinda_marg_mask, const long long* frame_indices,
+                   const long long* t, int observed_frames, int clip_denoised, float eta, const float* noise,
+                   unsigned long long seed, unsigned long long offset, float* sample, float* pred_xstart, float* eps,
+                   void* stream);
+
+/* The posterior arithmetic alone, given eps (same formulas; mode 0 p_sample, 1 ddim). */
+int vd_posterior_update(vd_engine* e, int mode, int B, long long per_sample, const float* x, const float* eps,
+                        const long long* t, int clip_denoised, float eta, const float* noise,
+                        unsigned long long seed, unsigned long long offset, float* sample, float* pred_xstart,
+                        void* stream);
+
+/* diffusion.q_sample(x_start, t, noise) (gaussian_diffusion.py:190-206). */
+int vd_q_sample(vd_engine* e, int B, long long per_sample, const float* x_start, const long long* t,
+                const float* noise, float* out, void* stream);
+
+/* th.randn(*shape) replacement on the engine's own counter-based generator. */
+int vd_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream);
+
+/* ---- single-operator entry points (parity tests call the kernels through these) -------------- */
+/* NHWC conv / linear on fp32 MFMA.  src1/C0: virtual channel concat; affA/affB: folded GroupNorm(+FiLM);
+ * act: SiLU on the operand; res: residual in the epilogue; fbias: per-frame bias [nfr][fbias_ld]. */
+int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, int ups, int stride,
+               int pad, int ksz, const float* w_packed, const float* bias, const float* affA, const float* affB,
+               int act, const float* res, const float* fbias, int fbias_ld, float* out, int Cout, void* stream);
+/* GroupNorm32 statistics folded to y = x*A + B per (frame, channel); film ([nfr][2C] scale|shift) optional. */
+int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, int HW, const float* gamma,
+                  const float* beta, const float* film, int film_ld, float* affA, float* affB, void* stream);
+int vd_op_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y,
+                       void* stream);
+int vd_op_gn_temporal(const float* x, const float* gamma, const float* beta, int B, int T, int HW, int C, float* y,
+                      void* stream);
+int vd_op_attn_spatial(const float* qkv, int nfr, int L, int C, int heads, float* out, void* stream);
+int vd_op_attn_temporal(const float* qkv, const float* Rk, const float* Rq, const float* Rv, const float* mask, int B,
+                        int T, int HW, int C, int heads, int allow_pad, float* out, void* stream);
+int vd_op_out_conv(const float* x, const float* affA, const float* affB, const float* w_packed, const float* bias,
+                   int nfr, int H, int W, int C, int Cout, float* out_nchw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,88 @@
+"""ORACLE (test infrastructure, NOT product code) -- ancestral / DDIM sampling steps.
+
+torch-CPU fp32 restatement of the reference's per-step posterior arithmetic
+and its sampling loops.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s cpu_baseline leg may import it.
+
+Pinned by tests/golden/psample_*.npz (imported reference, explicit noise).
+
+Follows (reference file:line, relative to /root/reference/improved_diffusion):
+  - _extract_into_tensor (f64 gather THEN cast to f32)  gaussian_diffusion.py:1019-1031
+  - p_mean_variance (EPSILON, FIXED_*)                  gaussian_diffusion.py:229-372
+  - _predict_xstart_from_eps / _predict_eps_from_xstart gaussian_diffusion.py:374-396
+  - q_posterior_mean_variance                           gaussian_diffusion.py:208-227
+  - p_sample                                            gaussian_diffusion.py:403-448
+  - ddim_sample                                         gaussian_diffusion.py:597-634
+  - q_sample                                            gaussian_diffusion.py:190-206
+  - p_sample_loop_progressive (side draws)              gaussian_diffusion.py:528-595
+  - ddim_sample_loop_progressive                        gaussian_diffusion.py:702-748
+  - _WrappedModel.__call__                              respace.py:111-119
+"""
+import numpy as np
+import torch
+
+
+def _coef(table, t, like):
+    v = torch.from_numpy(np.asarray(table))[t].float()
+    return v.view(-1, *([1] * (like.dim() - 1)))
+
+
+class SamplerRef:
+    def __init__(self, sched, net):
+        self.s, self.net = sched, net
+        self.num_timesteps = sched.num_timesteps
+
+    def eps(self, x, t, kw):
+        tm = torch.tensor(self.s.timestep_map, dtype=t.dtype)[t]
+        if self.s.rescale_timesteps:
+            tm = tm.float() * (1000.0 / self.s.original_num_steps)
+        return self.net(x, tm, **kw)
+
+    def mean_variance(self, x, t, kw, clip=True, eps=None):
+        s = self.s
+        if eps is None:
+            eps = self.eps(x, t, kw)
+        x0 = _coef(s.sqrt_recip_alphas_cumprod, t, x) * x - _coef(s.sqrt_recipm1_alphas_cumprod, t, x) * eps
+        if clip:
+            x0 = x0.clamp(-1, 1)
+        mean = _coef(s.posterior_mean_coef1, t, x) * x0 + _coef(s.posterior_mean_coef2, t, x) * x
+        shape = x.shape
+        return dict(mean=mean, pred_xstart=x0, eps=eps,
+                    variance=_coef(s.model_variance, t, x).expand(shape),
+                    log_variance=_coef(s.model_log_variance, t, x).expand(shape))
+
+    def p_sample(self, x, t, kw, noise, clip=True, eps=None):
+        o = self.mean_variance(x, t, kw, clip, eps)
+        nz = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+        o["sample"] = o["mean"] + nz * torch.exp(0.5 * o["log_variance"]) * noise
+        return o
+
+    def ddim_sample(self, x, t, kw, noise, eta=0.0, clip=True, eps=None):
+        s = self.s
+        o = self.mean_variance(x, t, kw, clip, eps)
+        e = (_coef(s.sqrt_recip_alphas_cumprod, t, x) * x - o["pred_xstart"]) \
+            / _coef(s.sqrt_recipm1_alphas_cumprod, t, x)
+        ab, abp = _coef(s.alphas_cumprod, t, x), _coef(s.alphas_cumprod_prev, t, x)
+        sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+        mean = o["pred_xstart"] * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * e
+        nz = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+        o["sample"] = mean + nz * sigma * noise
+        return o
+
+    def q_sample(self, x0, t, noise):
+        s = self.s
+        return _coef(s.sqrt_alphas_cumprod, t, x0) * x0 + _coef(s.sqrt_one_minus_alphas_cumprod, t, x0) * noise
+
+    def window_loop(self, x_init, kw, noises, sampler="p", eta=0.0):
+        """scripts/video_sample.py:149-168 -- the loop the drop-in target runs:
+        start from x_init (= x0.clone()), one step per respaced index, high to low.
+        `noises[i]` is the draw consumed at loop iteration i."""
+        x = x_init.clone()
+        B = x.shape[0]
+        for i, step in enumerate(range(self.num_timesteps)[::-1]):
+            t = torch.tensor([step] * B)
+            if sampler == "p":
+                x = self.p_sample(x, t, kw, noises[i])["sample"]
+            else:
+                x = self.ddim_sample(x, t, kw, noises[i], eta=eta)["sample"]
+        return x

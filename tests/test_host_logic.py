@@ -1,0 +1,156 @@
+"""CPU: the product's host logic (integer schedulers, respacing, float64 tables, parameter table)
+against the reference's golden vectors, and the C-ABI library's exported surface.
+No GPU compute call is made here."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import video_diffusion_amd as vda
+from helpers import ROOT, load_json
+from video_diffusion_amd import _lib
+from video_diffusion_amd.inference_util import inference_strategies
+from video_diffusion_amd.respace import space_timesteps
+from video_diffusion_amd.script_util import create_gaussian_diffusion, video_model_and_diffusion_defaults
+
+
+def test_space_timesteps_bit_exact():
+    for c in load_json("space_timesteps.json"):
+        if "error" in c:
+            with pytest.raises(ValueError, match=re.escape(c["error"])):
+                space_timesteps(c["n"], c["spec"])
+        else:
+            assert sorted(space_timesteps(c["n"], c["spec"])) == c["steps"], c["spec"]
+
+
+@pytest.mark.parametrize("tag", ["linear1000_ddim250", "linear1000_full", "linear1000_ddim50",
+                                 "cosine1000_ddim100", "linear1000_ddim5_small"])
+def test_schedule_tables_bit_exact(tag):
+    rec = load_json(f"schedule_{tag}.json")
+    d = create_gaussian_diffusion(rescale_timesteps=True, rescale_learned_sigmas=True, **rec["kw"])
+    assert list(d.timestep_map) == rec["timestep_map"]
+    assert d.num_timesteps == rec["num_timesteps"]
+    for name in ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                 "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                 "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+                 "posterior_mean_coef2"]:
+        want = np.array([float.fromhex(h) for h in rec[name]])
+        assert np.array_equal(getattr(d, name), want), name
+    tab = d._device_tables()
+    assert tab.shape == (9, d.num_timesteps) and tab.dtype == np.float32
+
+
+def test_schedulers_match_reference_sequences():
+    rec = load_json("schedulers.json")
+    seen = 0
+    for c in rec["cases"]:
+        if c["mode"] not in inference_strategies:
+            continue
+        vl, no, mf, ss = c["args"]
+        it = iter(inference_strategies[c["mode"]](video_length=vl, num_obs=no, max_frames=mf, step_size=ss,
+                                                  optimal_schedule_path=None))
+        if "error" in c:
+            with pytest.raises(AssertionError):
+                list(it)
+            continue
+        got = [[[int(i) for i in o], [int(i) for i in l]] for o, l in it]
+        assert got == c["seq"], (c["mode"], c["args"])
+        seen += 1
+    assert seen >= 10
+
+
+def test_scheduler_known_answers_survey_appendix_d():
+    def run(mode, *a):
+        return list(inference_strategies[mode](video_length=a[0], num_obs=a[1], max_frames=a[2], step_size=a[3]))
+    s = run("autoreg", 16, 4, 10, 1)
+    assert len(s) == 12 and s[0] == ([0, 1, 2, 3], [4]) and s[-1] == (list(range(6, 15)), [15])
+    assert run("independent", 16, 4, 16, 12) == [([0, 1, 2, 3], list(range(4, 16)))]
+    s = run("autoreg", 300, 36, 20, 7)
+    assert len(s) == 38 and s[-1] == (list(range(282, 295)), list(range(295, 300)))
+    s = run("exp-past", 16, 4, 16, 4)
+    assert [list(map(int, o)) for o, _ in s] == [[3, 2, 1, 0], [7, 6, 4, 5, 3, 2, 1, 0],
+                                                  [11, 10, 8, 9, 7, 6, 5, 4, 3, 2, 1, 0]]
+    s = run("autoreg", 16, 0, 10, 1)
+    assert s[0] == ([], list(range(10))) and s[1] == (list(range(1, 10)), [10])
+
+
+def test_scheduler_rejects_unfinished_conditioning():
+    class Bad(vda.inference_util.InferenceStrategyBase):
+        def next_indices(self):
+            return [9], [4]
+    with pytest.raises(AssertionError, match="not generated yet"):
+        next(iter(Bad(16, 4, 10, 1)))
+
+
+# ---------------------------------------------------------------------------------------- C ABI surface
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "vd_amd.h")).read()
+    declared = set(re.findall(r"\b(vd_[a-z_0-9]+)\s*\(", header))
+    L = _lib.lib()
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/vd_amd.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == declared
+    assert b"gfx950" in L.vd_version()
+
+
+def _cfg(tag):
+    d = video_model_and_diffusion_defaults()
+    if tag.startswith("tiny"):
+        d.update(T=4, image_size=32, num_channels=32, num_res_blocks=1, rp_alpha=4, rp_beta=4, rp_gamma=4)
+        if tag == "tiny_table":
+            d.update(use_rpe_net=False)
+    else:
+        d.update(T=16, image_size=int(tag[len("default"):]), rp_alpha=16, rp_beta=16, rp_gamma=16)
+    return d
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny_table", "default64", "default128"])
+def test_param_table_matches_reference_state_dict(tag):
+    want = [(k, tuple(s)) for k, s in load_json("param_specs.json")[tag]]
+    got = vda.param_specs(_cfg(tag))
+    assert got == want        # names, shapes AND order of the reference's state_dict
+    if tag == "default64":
+        assert sum(int(np.prod(s)) for _, s in got) == 116052099
+
+
+def test_factory_error_behaviour():
+    d = _cfg("tiny")
+    with pytest.raises(ValueError, match="unsupported image size"):
+        vda.create_video_model_and_diffusion(**{**d, "image_size": 48})
+    with pytest.raises(AssertionError):                       # bucket params missing (unet.py:423-427)
+        vda.create_video_model_and_diffusion(**{**d, "rp_alpha": None, "rp_beta": None, "rp_gamma": None})
+    with pytest.raises(ValueError, match="cannot create exactly"):
+        vda.create_video_model_and_diffusion(**{**d, "timestep_respacing": "ddim300"})
+    model, diff = vda.create_video_model_and_diffusion(**{**d, "timestep_respacing": "ddim250"})
+    assert diff.num_timesteps == 250
+    with pytest.raises(RuntimeError, match="Missing key"):
+        model.load_state_dict({})
+    sd = {k: vda.weights_init.synth_param(k, s) for k, s in model.param_specs()}
+    sd["time_embed.0.bias"] = sd["time_embed.0.bias"][:-1]
+    with pytest.raises(RuntimeError, match="size mismatch for time_embed.0.bias"):
+        model.load_state_dict(sd)
+    import torch
+    x = torch.zeros(1, 4, 3, 32, 32)
+    with pytest.raises(RuntimeError, match="no CPU path"):    # the product path never falls back to the CPU
+        model(x, torch.zeros(1), x0=x, obs_mask=x[:, :, :1, :1, :1], latent_mask=x[:, :, :1, :1, :1],
+              kinda_marg_mask=x[:, :, :1, :1, :1], observed_frames="x_0")
+
+
+def test_engine_reports_errors_not_crashes():
+    L = _lib.lib()
+    cfg = _lib.VdConfig()
+    cfg.image_size, cfg.num_channels, cfg.num_res_blocks, cfg.num_heads = 48, 32, 1, 4
+    h = ctypes.c_void_p()
+    assert L.vd_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"unsupported image size" in L.vd_last_error()
+    nbytes = ctypes.c_longlong()
+    model, _ = vda.create_video_model_and_diffusion(**_cfg("tiny"))
+    assert L.vd_workspace_bytes(model._handle, 2, 4, ctypes.byref(nbytes)) == 0 and nbytes.value > 0
+    # compute entry points refuse to run without weights (no silent fallback)
+    assert L.vd_unet_forward(model._handle, 2, 4, None, None, None, None, None, None, None, 0, None, None) == -1
+    assert b"weights not set" in L.vd_last_error()

@@ -1,0 +1,140 @@
+"""CPU: pin the oracle (oracle/*.py) against golden vectors minted from the imported reference.
+
+tools/gen_golden.py wrote tests/golden/ by running /root/reference on CPU; these
+tests never read the reference.  An oracle that fails here may not be used as a checker.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import case_inputs, close, load_json, load_npz, n_cases, synth_sd
+from oracle.sampler_ref import SamplerRef
+from oracle.schedule_ref import ScheduleRef, space_steps
+from oracle.unet_ref import UNetRef, sinus_embedding
+
+
+def test_space_timesteps_exact():
+    for c in load_json("space_timesteps.json"):
+        if "error" in c:
+            with pytest.raises(ValueError):
+                space_steps(c["n"], c["spec"])
+        else:
+            assert sorted(space_steps(c["n"], c["spec"])) == c["steps"], c["spec"]
+
+
+@pytest.mark.parametrize("tag", ["linear1000_ddim250", "linear1000_full", "linear1000_ddim50",
+                                 "cosine1000_ddim100", "linear1000_ddim5_small"])
+def test_schedule_tables_bit_exact(tag):
+    rec = load_json(f"schedule_{tag}.json")
+    s = ScheduleRef(**rec["kw"])
+    assert s.timestep_map == rec["timestep_map"]
+    assert s.num_timesteps == rec["num_timesteps"]
+    for name in ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                 "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                 "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+                 "posterior_mean_coef2"]:
+        want = np.array([float.fromhex(h) for h in rec[name]])
+        assert np.array_equal(getattr(s, name), want), name      # float64, bit for bit
+
+
+def test_known_answers_survey_appendix_c():
+    s = ScheduleRef(timestep_respacing="ddim250")
+    assert s.timestep_map[:3] == [0, 4, 8] and s.timestep_map[-1] == 996
+    np.testing.assert_allclose(s.betas[:3], [1e-4, 5.99065564e-4, 9.17602993e-4], rtol=1e-8)
+    np.testing.assert_allclose(s.alphas_cumprod[-1], 4.287736906800033e-05, rtol=1e-12)
+
+
+def _oracle_for(rec):
+    cfg = json.loads(str(rec["cfg_json"]))
+    specs = load_json("param_specs.json")
+    return cfg
+
+
+def _build(cfg, spec_tag=None):
+    from oracle.unet_ref import topology  # noqa: F401
+    import video_diffusion_amd as vda
+    specs = vda.param_specs(cfg)
+    return UNetRef(cfg, synth_sd(specs))
+
+
+@pytest.mark.parametrize("name", ["unet_tiny.npz", "unet_tiny_table.npz", "unet_tiny_frameenc.npz",
+                                  "unet_tiny_noss.npz"])
+def test_unet_eps_matches_reference(name):
+    rec = load_npz(name)
+    cfg = json.loads(str(rec["cfg_json"]))
+    net = _build(cfg)
+    sampler = SamplerRef(ScheduleRef(cfg["diffusion_steps"], cfg["noise_schedule"], cfg["timestep_respacing"],
+                                     cfg["sigma_small"], cfg["rescale_timesteps"]), net)
+    for ci in range(n_cases(rec)):
+        c = case_inputs(rec, ci)
+        kw = dict(x0=c["x0"], obs_mask=c["obs_mask"], latent_mask=c["latent_mask"],
+                  kinda_marg_mask=c["kinda_marg_mask"], frame_indices=c["frame_indices"],
+                  observed_frames=c["observed_frames"], x_t_minus_1=c["x0"])
+        eps = sampler.eps(c["x"], c["t"], kw)
+        close(eps, c["eps"], atol=2e-5, rtol=2e-5)
+
+
+def test_block_activations_match_reference():
+    rec = load_npz("blocks_tiny.npz")
+    urec = load_npz("unet_tiny.npz")
+    cfg = json.loads(str(urec["cfg_json"]))
+    net = _build(cfg)
+    c = case_inputs(urec, 0)
+    sched = ScheduleRef(timestep_respacing=cfg["timestep_respacing"])
+    tm = torch.tensor([float(sched.model_timestep(int(rec["t"])))] * c["x"].shape[0])
+    # timestep embedding (nn.py:89-107 + unet.py:605-610): latent frames see tm, observed frames see 0
+    B, T = c["x"].shape[:2]
+    om = c["obs_mask"].view(B, T)
+    tfr = (tm.view(B, 1) * (1 - om)).reshape(-1)
+    emb = net.lin(torch.nn.functional.silu(net.lin(sinus_embedding(tfr, cfg["num_channels"]), "time_embed.0")),
+                  "time_embed.2")
+    close(emb, rec["emb"], atol=2e-5, rtol=2e-5)
+    net.taps = {"attn_t": [], "out_blocks": []}
+    net(c["x"], tm, x0=c["x0"], obs_mask=c["obs_mask"], latent_mask=c["latent_mask"],
+        kinda_marg_mask=c["kinda_marg_mask"], frame_indices=c["frame_indices"])
+    close(net.taps["attn_t"][0][:, ::7, ::4, :], rec["in3_tattn"], atol=2e-5, rtol=2e-5)
+    close(net.taps["out_blocks"][0][:, ::4, ::3, ::3], rec["out0"], atol=5e-5, rtol=5e-5)
+    close(net.taps["out_blocks"][-1][:, ::4, ::3, ::3], rec["out_last"], atol=5e-5, rtol=5e-5)
+
+
+def test_psample_and_ddim_match_reference():
+    rec = load_npz("psample_tiny.npz")
+    cfg = json.loads(str(load_npz("unet_tiny.npz")["cfg_json"]))
+    net = _build(cfg)
+    s = SamplerRef(ScheduleRef(timestep_respacing=cfg["timestep_respacing"]), net)
+    T = {k: torch.from_numpy(rec[k]) for k in ["x", "x0", "noise", "obs_mask", "latent_mask", "kinda_marg_mask",
+                                                "frame_indices"]}
+    kw = dict(x0=T["x0"], obs_mask=T["obs_mask"], latent_mask=T["latent_mask"],
+              kinda_marg_mask=T["kinda_marg_mask"], frame_indices=T["frame_indices"])
+    B = T["x"].shape[0]
+    for t_val in [249, 248, 1, 0]:
+        t = torch.tensor([t_val] * B)
+        o = s.p_sample(T["x"], t, kw, T["noise"])
+        # x0_hat = sqrt(1/acp)*x - sqrt(1/acp-1)*eps amplifies an eps difference by up to 153x at t=249
+        # (gaussian_diffusion.py:374-382): the bound on pred_xstart is the eps bound times that gain.
+        gain = 1.0 + float(s.s.sqrt_recipm1_alphas_cumprod[t_val])
+        close(o["pred_xstart"], rec[f"t{t_val}_pred_xstart"], atol=1e-5 * gain, rtol=5e-5)
+        close(o["mean"], rec[f"t{t_val}_mean"], atol=5e-5, rtol=5e-5)
+        close(o["sample"], rec[f"t{t_val}_psample"], atol=5e-5, rtol=5e-5)
+        assert np.array_equal(o["log_variance"][:, 0, 0, 0, 0].numpy(), rec[f"t{t_val}_log_variance"])
+        assert np.array_equal(o["variance"][:, 0, 0, 0, 0].numpy(), rec[f"t{t_val}_variance"])
+        for eta in (0, 1):
+            d = s.ddim_sample(T["x"], t, kw, T["noise"], eta=float(eta), eps=o["eps"])
+            close(d["sample"], rec[f"t{t_val}_ddim_eta{eta}"], atol=1e-4, rtol=1e-4)
+    q = s.q_sample(T["x0"], torch.tensor([3] * B), T["noise"])
+    assert np.array_equal(q.numpy(), rec["q_sample_t3"])
+
+
+def test_window_loop_matches_reference():
+    rec = load_npz("window_tiny.npz")
+    cfg = json.loads(str(rec["cfg_json"]))
+    net = _build(cfg)
+    s = SamplerRef(ScheduleRef(timestep_respacing=cfg["timestep_respacing"]), net)
+    T = {k: torch.from_numpy(rec[k]) for k in ["x0", "obs_mask", "latent_mask", "kinda_marg_mask", "frame_indices"]}
+    kw = dict(x0=T["x0"], obs_mask=T["obs_mask"], latent_mask=T["latent_mask"],
+              kinda_marg_mask=T["kinda_marg_mask"], frame_indices=T["frame_indices"])
+    noises = [torch.from_numpy(n) for n in rec["noises"]]
+    out = s.window_loop(T["x0"], kw, noises)
+    close(out, rec["final"], atol=2e-4, rtol=2e-4)

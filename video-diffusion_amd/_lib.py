@@ -1,0 +1,128 @@
+"""Build and bind libvdamd.so (the C ABI declared in include/vd_amd.h).
+
+The product path has no CPU fallback: if the HIP library cannot be built or
+loaded, every compute entry point raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(_HERE, "libvdamd.so")
+SOURCES = ["igemm.hip", "norm.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "vd_amd.h")
+
+
+def _stale():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(_CSRC, "vd_common.h"), HEADER]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> in-tree libvdamd.so (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           *[os.path.join(_CSRC, s) for s in SOURCES], "-o", SO_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(SO_PATH + ".tmp", SO_PATH)
+    return SO_PATH
+
+
+class VdConfig(ctypes.Structure):
+    _fields_ = [("image_size", ctypes.c_int), ("num_channels", ctypes.c_int), ("num_res_blocks", ctypes.c_int),
+                ("num_heads", ctypes.c_int), ("T", ctypes.c_int), ("n_attention_ds", ctypes.c_int),
+                ("attention_ds", ctypes.c_int * 8), ("use_scale_shift_norm", ctypes.c_int),
+                ("use_spatial_encoding", ctypes.c_int), ("use_frame_encoding", ctypes.c_int),
+                ("enforce_position_invariance", ctypes.c_int), ("use_rpe_net", ctypes.c_int),
+                ("allow_interactions_between_padding", ctypes.c_int), ("rp_alpha", ctypes.c_float),
+                ("rp_beta", ctypes.c_float), ("rp_gamma", ctypes.c_float), ("time_embed_mult", ctypes.c_int)]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_longlong
+_U = ctypes.c_ulonglong
+_F = ctypes.c_float
+
+# name -> (restype, argtypes); every symbol declared in include/vd_amd.h
+SIGNATURES = {
+    "vd_last_error": (ctypes.c_char_p, []),
+    "vd_version": (ctypes.c_char_p, []),
+    "vd_create": (_I, [ctypes.POINTER(VdConfig), ctypes.POINTER(_P)]),
+    "vd_destroy": (None, [_P]),
+    "vd_param_count": (_I, [_P]),
+    "vd_param_info": (_I, [_P, _I, ctypes.c_char_p, _I, ctypes.POINTER(_I), ctypes.POINTER(_L)]),
+    "vd_weights_bytes": (_L, [_P]),
+    "vd_set_weight_storage": (_I, [_P, _P, _L]),
+    "vd_load_weight": (_I, [_P, ctypes.c_char_p, _P, _L]),
+    "vd_weights_missing": (_I, [_P]),
+    "vd_mark_weights_loaded": (_I, [_P]),
+    "vd_pos_channels": (_I, [_P]),
+    "vd_pos_resolution": (_I, [_P]),
+    "vd_set_freqs": (_I, [_P, _P, _I, _P, _I]),
+    "vd_set_schedule": (_I, [_P, _I, _P, _P, _F]),
+    "vd_workspace_bytes": (_I, [_P, _I, _I, ctypes.POINTER(_L)]),
+    "vd_unet_forward": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "vd_p_sample": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _U, _P, _P, _P, _P]),
+    "vd_ddim_sample": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _U, _U, _P, _P, _P, _P]),
+    "vd_posterior_update": (_I, [_P, _I, _I, _L, _P, _P, _P, _I, _F, _P, _U, _U, _P, _P, _P]),
+    "vd_q_sample": (_I, [_P, _I, _L, _P, _P, _P, _P, _P]),
+    "vd_randn": (_I, [_P, _L, _U, _U, _P]),
+    "vd_op_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P]),
+    "vd_op_gn_fold": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
+    "vd_op_affine_apply": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "vd_op_gn_temporal": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "vd_op_attn_spatial": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "vd_op_attn_temporal": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "vd_op_out_conv": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library with argtypes set; builds it on first use if the .so is missing/stale."""
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class VdError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().vd_last_error().decode(errors="replace")
+        raise VdError(f"libvdamd error {rc}: {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / numpy array, or NULL."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.ctypes.data)
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,808 @@
+// Step engine: UNet topology, packed weights, the per-step launch sequence and the C ABI.
+//
+// One process per GPU owns one engine.  A denoise step is a fixed sequence of ~600 kernel launches
+// on the caller's stream; activations live in one bump-allocated arena sized per (B, T) window (288 GB
+// of HBM: no buffer reuse games, the same addresses every step, so the sequence is graph-capturable).
+// Weights live in ONE packed device buffer in kernel-ready layouts (see Param::kind).
+//
+// Reference call path being replaced (paths relative to /root/reference/improved_diffusion):
+//   _WrappedModel.__call__ respace.py:111-119 -> CondMargVideoModel.forward unet.py:949-1026 ->
+//   UNetVideoModel.forward :898-912 -> UNetModel.forward :768-839 ; p_sample gaussian_diffusion.py:403-448.
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vd_amd.h"
+#include "vd_common.h"
+
+namespace vd {
+
+thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hipStream_t s);
+
+enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV };
+
+struct Param {
+    std::string name;
+    int nd = 0;
+    long long shape[4] = {1, 1, 1, 1};
+    size_t numel = 0;        // as stored in the checkpoint
+    size_t packed = 0;       // floats in the packed buffer
+    size_t off = 0;          // float offset in the packed buffer
+    int kind = PK_RAW;
+    bool loaded = false;
+};
+
+struct ResP {
+    int cin, cout;
+    int gn1w, gn1b, c1w, c1b, embw, embb, gn2w, gn2b, c2w, c2b, skw = -1, skb = -1;
+    int film_off = 0;        // column offset in the batched emb projection
+};
+struct RpeP { int dw = -1, db = -1, tw = -1, tb = -1, ow = -1, ob = -1, table = -1; int te_off = 0; };
+struct AttP { int normw, normb, qkvw, qkvb, projw, projb; };
+struct AttnP { int C; AttP sp, tp; RpeP rq, rk, rv; };
+struct ConvP { int w, b, c; };
+struct Layer { int type; int idx; };      // 0 stem, 1 res, 2 attn, 3 down, 4 up
+struct Tens { float* p; int C, H; };
+
+static const int CH_MULT_256[] = {1, 1, 2, 2, 4, 4};
+static const int CH_MULT_128[] = {1, 1, 2, 3, 4};
+static const int CH_MULT_64[] = {1, 2, 3, 4};
+static const int CH_MULT_32[] = {1, 2, 2, 2};
+constexpr int STEM_CPAD = 32;
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    bool dry = false;
+    template <class Tp> Tp* get(size_t n) {
+        size_t bytes = (n * sizeof(Tp) + 255) & ~(size_t)255;
+        char* p = dry ? reinterpret_cast<char*>(0x1000) : base + used;
+        used += bytes;
+        return reinterpret_cast<Tp*>(p);
+    }
+};
+
+struct FwdIn {
+    int B, T;
+    const float *x, *obs_src, *obs, *lat, *km, *t_model;
+    const int64_t* fidx;
+    int obs_mode;
+    float* eps;
+};
+
+}  // namespace vd
+
+using namespace vd;
+
+struct vd_engine {
+    vd_config cfg;
+    int E = 0;                       // time_embed_dim
+    std::vector<Param> params;
+    std::unordered_map<std::string, int> pidx;
+    std::vector<ResP> res;
+    std::vector<AttnP> attn;
+    std::vector<ConvP> convs;        // stem / down / up
+    std::vector<std::vector<Layer>> input_blocks, output_blocks;
+    std::vector<Layer> middle;
+    int n_before_attn = 0, pos_res = 0, pos_ch = 0, final_ch = 0;
+    int p_posenc = -1, p_te0w, p_te0b, p_te2w, p_te2b, p_outgw, p_outgb, p_outw, p_outb;
+    size_t film_w_off = 0, film_b_off = 0, te_w_off = 0, te_b_off = 0;
+    int film_total = 0, te_total = 0;
+    size_t packed_total = 0;
+    float* wbuf = nullptr;           // caller-owned packed weights
+    // small device tables
+    float* d_freq_time = nullptr; int n_freq_time = 0;
+    float* d_freq_frame = nullptr; int n_freq_frame = 0;
+    float* d_tab = nullptr; int num_timesteps = 0;
+    float* d_tmap = nullptr; float rescale = 1.f;
+    // workspace
+    char* ws = nullptr; size_t ws_cap = 0;
+
+    ~vd_engine() {
+        if (d_freq_time) (void)hipFree(d_freq_time);
+        if (d_freq_frame) (void)hipFree(d_freq_frame);
+        if (d_tab) (void)hipFree(d_tab);
+        if (d_tmap) (void)hipFree(d_tmap);
+        if (ws) (void)hipFree(ws);
+    }
+
+    const float* W(int p) const { return wbuf + params[p].off; }
+
+    int add(const std::string& name, std::initializer_list<long long> shape, int kind = PK_RAW) {
+        Param p;
+        p.name = name;
+        p.nd = (int)shape.size();
+        int i = 0;
+        p.numel = 1;
+        for (long long s : shape) { p.shape[i++] = s; p.numel *= (size_t)s; }
+        p.kind = kind;
+        p.packed = p.numel;
+        if (kind == PK_STEM) p.packed = (size_t)9 * p.shape[0] * STEM_CPAD;
+        params.push_back(p);
+        pidx[name] = (int)params.size() - 1;
+        return (int)params.size() - 1;
+    }
+
+    int build();
+    int forward(const FwdIn& in, hipStream_t st, Arena& ar);
+    int ensure_ws(int B, int T);
+    int res_block(const ResP& r, Tens x0, const Tens* x1, int N, const float* film_all, const float* emb_unused,
+                  hipStream_t st, Arena& ar, Tens* out);
+    int attn_block(const AttnP& a, Tens x, int B, int T, const float* te_all, const int64_t* fidx, const float* amask,
+                   hipStream_t st, Arena& ar, Tens* out);
+    int gn_fold(const float* s0, const float* s1, int C0, int C, int N, int HW, int gw, int gb, const float* film,
+                int film_ld, hipStream_t st, Arena& ar, float** A, float** B);
+    int linear(const float* a, int M, int K, int pw, int pb, int Nout, const float* wptr, const float* bptr, int act,
+               const float* res, float* out, hipStream_t st);
+};
+
+// ------------------------------------------------------------------------------------------ topology
+int vd_engine::build() {
+    const int mc = cfg.num_channels, nrb = cfg.num_res_blocks;
+    const int* mult; int nlev;
+    switch (cfg.image_size) {
+        case 256: mult = CH_MULT_256; nlev = 6; break;
+        case 128: mult = CH_MULT_128; nlev = 5; break;
+        case 64: mult = CH_MULT_64; nlev = 4; break;
+        case 32: mult = CH_MULT_32; nlev = 4; break;
+        default: set_error("unsupported image size: " + std::to_string(cfg.image_size)); return -1;
+    }
+    VD_REQUIRE(mc % 32 == 0, "num_channels must be a multiple of 32 (GroupNorm32)");
+    VD_REQUIRE(cfg.num_heads > 0 && cfg.n_attention_ds >= 0 && cfg.n_attention_ds <= 8, "heads / attention_ds");
+    E = mc * (cfg.time_embed_mult > 0 ? cfg.time_embed_mult : 4);
+    auto in_att = [&](int ds) { for (int i = 0; i < cfg.n_attention_ds; ++i) if (cfg.attention_ds[i] == ds) return true; return false; };
+
+    // The reference registers spatial_encoding first (a Parameter of the root module), but its shape is
+    // known only after the input blocks are laid out; reserve the slot now.
+    if (cfg.use_spatial_encoding) p_posenc = add("spatial_encoding", {1, 1, 1, 1}, PK_POSENC);
+    p_te0w = add("time_embed.0.weight", {E, mc}); p_te0b = add("time_embed.0.bias", {E});
+    p_te2w = add("time_embed.2.weight", {E, E}); p_te2b = add("time_embed.2.bias", {E});
+
+    auto add_res = [&](const std::string& pre, int cin, int cout) {
+        ResP r; r.cin = cin; r.cout = cout;
+        r.gn1w = add(pre + ".in_layers.0.weight", {cin}); r.gn1b = add(pre + ".in_layers.0.bias", {cin});
+        r.c1w = add(pre + ".in_layers.2.weight", {cout, cin, 3, 3}, PK_CONV3); r.c1b = add(pre + ".in_layers.2.bias", {cout});
+        const int eo = cfg.use_scale_shift_norm ? 2 * cout : cout;
+        r.embw = add(pre + ".emb_layers.1.weight", {eo, E}); r.embb = add(pre + ".emb_layers.1.bias", {eo});
+        r.gn2w = add(pre + ".out_layers.0.weight", {cout}); r.gn2b = add(pre + ".out_layers.0.bias", {cout});
+        r.c2w = add(pre + ".out_layers.3.weight", {cout, cout, 3, 3}, PK_CONV3); r.c2b = add(pre + ".out_layers.3.bias", {cout});
+        if (cin != cout) {
+            r.skw = add(pre + ".skip_connection.weight", {cout, cin, 1, 1}); r.skb = add(pre + ".skip_connection.bias", {cout});
+        }
+        res.push_back(r);
+        return (int)res.size() - 1;
+    };
+    auto add_att = [&](const std::string& pre, int C) {
+        AttP a;
+        a.qkvw = add(pre + ".qkv.weight", {3 * C, C}); a.qkvb = add(pre + ".qkv.bias", {3 * C});
+        a.projw = add(pre + ".proj_out.weight", {C, C}); a.projb = add(pre + ".proj_out.bias", {C});
+        a.normw = add(pre + ".norm.weight", {C}); a.normb = add(pre + ".norm.bias", {C});
+        return a;
+    };
+    auto add_rpe = [&](const std::string& pre, int C) {
+        RpeP r;
+        if (cfg.use_rpe_net) {
+            r.dw = add(pre + ".rpe_net.embed_distances.weight", {C, 3}); r.db = add(pre + ".rpe_net.embed_distances.bias", {C});
+            r.tw = add(pre + ".rpe_net.embed_diffusion_time.weight", {C, E}); r.tb = add(pre + ".rpe_net.embed_diffusion_time.bias", {C});
+            r.ow = add(pre + ".rpe_net.out.weight", {C, C}); r.ob = add(pre + ".rpe_net.out.bias", {C});
+        } else {
+            r.table = add(pre + ".lookup_table_weight", {2 * (long long)cfg.rp_beta + 1, cfg.num_heads, C / cfg.num_heads});
+        }
+        return r;
+    };
+    auto add_attn = [&](const std::string& pre, int C) {
+        VD_REQUIRE(C % cfg.num_heads == 0 && (C / cfg.num_heads) % 8 == 0, "head dim must be a multiple of 8");
+        AttnP a; a.C = C;
+        a.sp = add_att(pre + ".spatial_attention", C);
+        a.tp = add_att(pre + ".temporal_attention", C);
+        a.rq = add_rpe(pre + ".temporal_attention.rpe_q", C);
+        a.rk = add_rpe(pre + ".temporal_attention.rpe_k", C);
+        a.rv = add_rpe(pre + ".temporal_attention.rpe_v", C);
+        attn.push_back(a);
+        return (int)attn.size() - 1;
+    };
+    auto add_conv = [&](const std::string& pre, int cin, int cout, int kind) {
+        ConvP c; c.c = cout;
+        c.w = add(pre + ".weight", {cout, cin, 3, 3}, kind); c.b = add(pre + ".bias", {cout});
+        convs.push_back(c);
+        return (int)convs.size() - 1;
+    };
+
+    std::vector<int> chans;
+    input_blocks.push_back({Layer{0, add_conv("input_blocks.0.0", 5, mc, PK_STEM)}});
+    chans.push_back(mc);
+    int ch = mc, ds = 1, first_ds = -1, first_ch = -1;
+    n_before_attn = -1;
+    for (int lvl = 0; lvl < nlev; ++lvl) {
+        for (int k = 0; k < nrb; ++k) {
+            if (in_att(ds) && n_before_attn < 0) { n_before_attn = (int)input_blocks.size(); first_ds = ds; first_ch = ch; }
+            const std::string pre = "input_blocks." + std::to_string(input_blocks.size());
+            std::vector<Layer> blk;
+            int ri = add_res(pre + ".0", ch, mult[lvl] * mc);
+            blk.push_back(Layer{1, ri});
+            ch = mult[lvl] * mc;
+            if (in_att(ds)) { int ai = add_attn(pre + ".1", ch); if (ai < 0) return ai; blk.push_back(Layer{2, ai}); }
+            input_blocks.push_back(blk);
+            chans.push_back(ch);
+        }
+        if (lvl != nlev - 1) {
+            const std::string pre = "input_blocks." + std::to_string(input_blocks.size());
+            input_blocks.push_back({Layer{3, add_conv(pre + ".0.op", ch, ch, PK_CONV3)}});
+            chans.push_back(ch);
+            ds *= 2;
+        }
+    }
+    if (n_before_attn < 0) { n_before_attn = (int)input_blocks.size(); first_ds = ds; first_ch = ch; }
+    pos_res = cfg.image_size / first_ds; pos_ch = first_ch;
+    if (p_posenc >= 0) {
+        Param& p = params[p_posenc];
+        p.nd = 4; p.shape[0] = 1; p.shape[1] = pos_ch; p.shape[2] = pos_res; p.shape[3] = pos_res;
+        p.numel = p.packed = (size_t)pos_ch * pos_res * pos_res;
+    }
+    {
+        int r0 = add_res("middle_block.0", ch, ch);
+        int a0 = add_attn("middle_block.1", ch); if (a0 < 0) return a0;
+        int r1 = add_res("middle_block.2", ch, ch);
+        middle = {Layer{1, r0}, Layer{2, a0}, Layer{1, r1}};
+    }
+    for (int lvl = nlev - 1; lvl >= 0; --lvl) {
+        for (int i = 0; i <= nrb; ++i) {
+            const std::string pre = "output_blocks." + std::to_string(output_blocks.size());
+            std::vector<Layer> blk;
+            const int skip = chans.back(); chans.pop_back();
+            blk.push_back(Layer{1, add_res(pre + ".0", ch + skip, mc * mult[lvl])});
+            ch = mc * mult[lvl];
+            int li = 1;
+            if (in_att(ds)) { int ai = add_attn(pre + "." + std::to_string(li++), ch); if (ai < 0) return ai; blk.push_back(Layer{2, ai}); }
+            if (lvl && i == nrb) {
+                blk.push_back(Layer{4, add_conv(pre + "." + std::to_string(li++) + ".conv", ch, ch, PK_CONV3)});
+                ds /= 2;
+            }
+            output_blocks.push_back(blk);
+        }
+    }
+    final_ch = ch;
+    p_outgw = add("out.0.weight", {ch}); p_outgb = add("out.0.bias", {ch});
+    p_outw = add("out.2.weight", {3, mc, 3, 3}, PK_OUTCONV); p_outb = add("out.2.bias", {3});
+    VD_REQUIRE(final_ch == mc, "channel_mult[0] must be 1");
+
+    // ---- packed layout: [FiLM weights | FiLM biases | rpe-time weights | rpe-time biases | everything else]
+    size_t off = 0;
+    auto place = [&](int p) { params[p].off = off; off += (params[p].packed + 3) & ~(size_t)3; };
+    film_w_off = off; film_total = 0;
+    for (auto& r : res) { r.film_off = film_total; place(r.embw); film_total += (int)params[r.embw].shape[0]; }
+    film_b_off = off;
+    for (auto& r : res) place(r.embb);
+    te_total = 0;
+    if (cfg.use_rpe_net) {
+        te_w_off = off;
+        for (auto& a : attn) for (RpeP* r : {&a.rq, &a.rk, &a.rv}) { r->te_off = te_total; place(r->tw); te_total += a.C; }
+        te_b_off = off;
+        for (auto& a : attn) for (RpeP* r : {&a.rq, &a.rk, &a.rv}) place(r->tb);
+    }
+    std::vector<char> placed(params.size(), 0);
+    for (auto& r : res) { placed[r.embw] = placed[r.embb] = 1; }
+    if (cfg.use_rpe_net) for (auto& a : attn) for (RpeP* r : {&a.rq, &a.rk, &a.rv}) { placed[r->tw] = placed[r->tb] = 1; }
+    for (size_t i = 0; i < params.size(); ++i) if (!placed[i]) place((int)i);
+    packed_total = off;
+    // FiLM rows must be contiguous for the single batched GEMM: every 2*cout / cout is a multiple of 4.
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ helpers
+int vd_engine::linear(const float* a, int M, int K, int, int, int Nout, const float* wptr, const float* bptr, int act,
+                      const float* resid, float* out, hipStream_t st) {
+    IgemmArgs g{};
+    g.src0 = a; g.src1 = nullptr; g.C0 = K; g.Cin = K;
+    g.nfr = M; g.Hs = 1; g.Ws = 1; g.ups = 0; g.stride = 1; g.pad = 0; g.ksz = 1; g.Ho = 1; g.Wo = 1;
+    g.w = wptr; g.bias = bptr; g.affA = nullptr; g.affB = nullptr; g.act = act;
+    g.res = resid; g.res_ld = Nout; g.fbias = nullptr; g.fbias_ld = 0;
+    g.out = out; g.ldo = Nout; g.Cout = Nout; g.M = M;
+    return launch_igemm(g, st);
+}
+
+int vd_engine::gn_fold(const float* s0, const float* s1, int C0, int C, int N, int HW, int gw, int gb,
+                       const float* film, int film_ld, hipStream_t st, Arena& ar, float** A, float** Bp) {
+    const int split = gn_stats_split(N, HW, C);
+    double* part = ar.get<double>((size_t)N * split * C * 2);
+    float* mr = ar.get<float>((size_t)N * 64);
+    *A = ar.get<float>((size_t)N * C);
+    *Bp = ar.get<float>((size_t)N * C);
+    if (ar.dry) return 0;
+    int rc = launch_gn_stats(s0, s1, C0, C, N, HW, part, split, mr, st);
+    if (rc) return rc;
+    return launch_gn_affine(mr, W(gw), W(gb), film, film_ld, N, C, *A, *Bp, st);
+}
+
+static IgemmArgs conv_args(Tens x0, const Tens* x1, int N, int ksz, int stride, int ups) {
+    IgemmArgs g{};
+    g.src0 = x0.p; g.C0 = x0.C; g.Cin = x0.C;
+    if (x1) { g.src1 = x1->p; g.Cin += x1->C; }
+    g.nfr = N; g.Hs = x0.H; g.Ws = x0.H; g.ups = ups; g.stride = stride; g.pad = ksz == 3 ? 1 : 0; g.ksz = ksz;
+    const int Hl = x0.H << ups;
+    g.Ho = g.Wo = (Hl + 2 * g.pad - ksz) / stride + 1;
+    g.M = N * g.Ho * g.Wo;
+    return g;
+}
+
+int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const float* film_all, const float*,
+                         hipStream_t st, Arena& ar, Tens* out) {
+    const int H = x0.H, HW = H * H;
+    const int cin = x0.C + (x1 ? x1->C : 0);
+    VD_REQUIRE(cin == r.cin, "ResBlock input channels");
+    const float* s1 = x1 ? x1->p : nullptr;
+    float *A1, *B1, *A2, *B2;
+    int rc = gn_fold(x0.p, s1, x0.C, cin, N, HW, r.gn1w, r.gn1b, nullptr, 0, st, ar, &A1, &B1);
+    if (rc) return rc;
+    float* h = ar.get<float>((size_t)N * HW * r.cout);
+    const float* film = film_all + r.film_off;
+    if (!ar.dry) {
+        IgemmArgs g = conv_args(x0, x1, N, 3, 1, 0);
+        g.w = W(r.c1w); g.bias = W(r.c1b); g.affA = A1; g.affB = B1; g.act = 1;
+        g.out = h; g.ldo = r.cout; g.Cout = r.cout;
+        if (!cfg.use_scale_shift_norm) { g.fbias = film; g.fbias_ld = film_total; }    // h + emb_out (unet.py:196)
+        if ((rc = launch_igemm(g, st))) return rc;
+    }
+    rc = gn_fold(h, nullptr, r.cout, r.cout, N, HW, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr,
+                 film_total, st, ar, &A2, &B2);
+    if (rc) return rc;
+    const float* skip = x0.p;
+    if (r.skw >= 0) {
+        float* sk = ar.get<float>((size_t)N * HW * r.cout);
+        if (!ar.dry) {
+            IgemmArgs g = conv_args(x0, x1, N, 1, 1, 0);
+            g.w = W(r.skw); g.bias = W(r.skb); g.out = sk; g.ldo = r.cout; g.Cout = r.cout;
+            if ((rc = launch_igemm(g, st))) return rc;
+        }
+        skip = sk;
+    } else {
+        VD_REQUIRE(x1 == nullptr, "identity skip over a concatenated input");
+    }
+    float* o = ar.get<float>((size_t)N * HW * r.cout);
+    if (!ar.dry) {
+        Tens ht{h, r.cout, H};
+        IgemmArgs g = conv_args(ht, nullptr, N, 3, 1, 0);
+        g.w = W(r.c2w); g.bias = W(r.c2b); g.affA = A2; g.affB = B2; g.act = 1;
+        g.res = skip; g.res_ld = r.cout; g.out = o; g.ldo = r.cout; g.Cout = r.cout;
+        if ((rc = launch_igemm(g, st))) return rc;
+    }
+    *out = Tens{o, r.cout, H};
+    return 0;
+}
+
+int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_all, const int64_t* fidx,
+                          const float* amask, hipStream_t st, Arena& ar, Tens* out) {
+    const int C = a.C, H = x.H, HW = H * H, N = B * T;
+    const size_t tok = (size_t)N * HW;
+    const float scale = 1.0f / sqrtf((float)(C / cfg.num_heads));
+    int rc;
+    // ---- temporal attention over the T frames of each (batch, pixel)      (unet.py:246-255)
+    float* xn = ar.get<float>(tok * C);
+    float* qkv = ar.get<float>(tok * 3 * C);
+    float* R[3] = {nullptr, nullptr, nullptr};
+    const RpeP* rp[3] = {&a.rk, &a.rq, &a.rv};
+    const size_t rrows = (size_t)B * T * T;
+    float* Ehid = cfg.use_rpe_net ? ar.get<float>(rrows * C) : nullptr;
+    for (int i = 0; i < 3; ++i) R[i] = ar.get<float>(rrows * C);
+    float* o = ar.get<float>(tok * C);
+    float* xt = ar.get<float>(tok * C);
+    if (!ar.dry) {
+        if ((rc = launch_gn_temporal(x.p, W(a.tp.normw), W(a.tp.normb), B, T, HW, C, xn, st))) return rc;
+        if ((rc = linear(xn, (int)tok, C, 0, 0, 3 * C, W(a.tp.qkvw), W(a.tp.qkvb), 0, nullptr, qkv, st))) return rc;
+        for (int i = 0; i < 3; ++i) {
+            if (cfg.use_rpe_net) {
+                if ((rc = launch_rpe_hidden(te_all + rp[i]->te_off, te_total, W(rp[i]->dw), W(rp[i]->db), fidx, B, T, C,
+                                            Ehid, st))) return rc;
+                if ((rc = linear(Ehid, (int)rrows, C, 0, 0, C, W(rp[i]->ow), W(rp[i]->ob), 0, nullptr, R[i], st))) return rc;
+            } else {
+                if ((rc = launch_rpe_table(W(rp[i]->table), fidx, B, T, C, cfg.rp_alpha, cfg.rp_beta, cfg.rp_gamma, R[i], st)))
+                    return rc;
+            }
+        }
+        AttnTemporalArgs ta{qkv, R[0], R[1], R[2], amask, o, B, T, HW, C, cfg.num_heads,
+                            cfg.allow_interactions_between_padding, scale};
+        if ((rc = launch_attn_temporal(ta, st))) return rc;
+        // proj_out + residual on the NORMALISED activations (unet.py:537-538)
+        if ((rc = linear(o, (int)tok, C, 0, 0, C, W(a.tp.projw), W(a.tp.projb), 0, xn, xt, st))) return rc;
+    }
+    // ---- spatial attention over the HW pixels of each frame               (unet.py:258-267)
+    float *A, *Bf;
+    if ((rc = gn_fold(xt, nullptr, C, C, N, HW, a.sp.normw, a.sp.normb, nullptr, 0, st, ar, &A, &Bf))) return rc;
+    float* xn2 = ar.get<float>(tok * C);
+    float* qkv2 = ar.get<float>(tok * 3 * C);
+    float* o2 = ar.get<float>(tok * C);
+    float* xs = ar.get<float>(tok * C);
+    if (!ar.dry) {
+        if ((rc = launch_affine_apply(xt, A, Bf, N, HW, C, xn2, st))) return rc;
+        if ((rc = linear(xn2, (int)tok, C, 0, 0, 3 * C, W(a.sp.qkvw), W(a.sp.qkvb), 0, nullptr, qkv2, st))) return rc;
+        AttnSpatialArgs sa{qkv2, o2, N, HW, C, cfg.num_heads, scale};
+        if ((rc = launch_attn_spatial(sa, st))) return rc;
+        if ((rc = linear(o2, (int)tok, C, 0, 0, C, W(a.sp.projw), W(a.sp.projb), 0, xn2, xs, st))) return rc;
+    }
+    *out = Tens{xs, C, H};
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
+    const int B = in.B, T = in.T, N = B * T, S = cfg.image_size, mc = cfg.num_channels;
+    int rc;
+    float* x8 = ar.get<float>((size_t)N * S * S * STEM_CPAD);
+    float* tfr = ar.get<float>(N);
+    float* amask = ar.get<float>(N);
+    float* tsin = ar.get<float>((size_t)N * mc);
+    float* e1 = ar.get<float>((size_t)N * E);
+    float* emb = ar.get<float>((size_t)N * E);
+    float* film = ar.get<float>((size_t)N * film_total);
+    float* te = te_total ? ar.get<float>((size_t)N * te_total) : nullptr;
+    float* ftv = cfg.use_frame_encoding ? ar.get<float>(N) : nullptr;
+    float* femb = cfg.use_frame_encoding ? ar.get<float>((size_t)N * pos_ch) : nullptr;
+    if (!ar.dry) {
+        VD_REQUIRE(d_freq_time && n_freq_time == mc / 2, "vd_set_freqs not called (time frequencies)");
+        AssembleArgs aa{in.x, in.obs_src, in.obs, in.lat, in.km, in.t_model, in.obs_mode, B, T, S, S, STEM_CPAD, x8, tfr, amask};
+        if ((rc = launch_assemble(aa, st))) return rc;
+        if ((rc = launch_sinus_embed(tfr, N, mc, d_freq_time, tsin, st))) return rc;
+        if ((rc = linear(tsin, N, mc, 0, 0, E, W(p_te0w), W(p_te0b), 0, nullptr, e1, st))) return rc;
+        if ((rc = linear(e1, N, E, 0, 0, E, W(p_te2w), W(p_te2b), 1, nullptr, emb, st))) return rc;
+        // every ResBlock's emb_layers (SiLU -> Linear, unet.py:143-150) in ONE GEMM; same for RPENet's
+        // embed_diffusion_time (no SiLU, unet.py:294)
+        if ((rc = linear(emb, N, E, 0, 0, film_total, wbuf + film_w_off, wbuf + film_b_off, 1, nullptr, film, st))) return rc;
+        if (te_total && (rc = linear(emb, N, E, 0, 0, te_total, wbuf + te_w_off, wbuf + te_b_off, 0, nullptr, te, st))) return rc;
+        if (cfg.use_frame_encoding) {
+            VD_REQUIRE(d_freq_frame && n_freq_frame == pos_ch / 2, "vd_set_freqs not called (frame frequencies)");
+            if ((rc = launch_frame_t(in.fidx, B, T, cfg.enforce_position_invariance, ftv, st))) return rc;
+            if ((rc = launch_sinus_embed(ftv, N, pos_ch, d_freq_frame, femb, st))) return rc;
+        }
+    }
+    std::vector<Tens> hs;
+    Tens h{x8, STEM_CPAD, S};
+    auto run = [&](const std::vector<Layer>& blk, Tens in0, const Tens* in1, Tens* outp) -> int {
+        Tens cur = in0;
+        const Tens* second = in1;
+        for (const Layer& L : blk) {
+            Tens nxt{};
+            if (L.type == 1) {
+                if ((rc = res_block(res[L.idx], cur, second, N, film, nullptr, st, ar, &nxt))) return rc;
+            } else if (L.type == 2) {
+                if ((rc = attn_block(attn[L.idx], cur, B, T, te, in.fidx, amask, st, ar, &nxt))) return rc;
+            } else {
+                const ConvP& c = convs[L.idx];
+                const int stride = L.type == 3 ? 2 : 1, ups = L.type == 4 ? 1 : 0;
+                IgemmArgs g = conv_args(cur, nullptr, N, 3, stride, ups);
+                float* o = ar.get<float>((size_t)g.M * c.c);
+                if (!ar.dry) {
+                    g.w = W(c.w); g.bias = W(c.b); g.out = o; g.ldo = c.c; g.Cout = c.c;
+                    if ((rc = launch_igemm(g, st))) return rc;
+                }
+                nxt = Tens{o, c.c, g.Ho};
+            }
+            cur = nxt;
+            second = nullptr;
+        }
+        *outp = cur;
+        return 0;
+    };
+    for (size_t i = 0; i < input_blocks.size(); ++i) {
+        if ((rc = run(input_blocks[i], h, nullptr, &h))) return rc;
+        hs.push_back(h);
+        if ((int)i + 1 == n_before_attn && (cfg.use_spatial_encoding || cfg.use_frame_encoding)) {
+            // added AFTER the skip push (unet.py:815-818): the skip keeps the un-encoded tensor
+            const size_t n = (size_t)N * h.H * h.H * h.C;
+            float* y = ar.get<float>(n);
+            if (!ar.dry) {
+                VD_REQUIRE(h.H == pos_res && h.C == pos_ch, "positional encoding shape");
+                if ((rc = launch_posenc_add(h.p, cfg.use_spatial_encoding ? W(p_posenc) : nullptr, femb, N, h.H * h.H, h.C, y, st)))
+                    return rc;
+            }
+            h = Tens{y, h.C, h.H};
+        }
+    }
+    if ((rc = run(middle, h, nullptr, &h))) return rc;
+    for (size_t i = 0; i < output_blocks.size(); ++i) {
+        Tens skip = hs.back(); hs.pop_back();
+        if ((rc = run(output_blocks[i], h, &skip, &h))) return rc;      // cat([h, hs.pop()]) read in place
+    }
+    float *A, *Bf;
+    if ((rc = gn_fold(h.p, nullptr, h.C, h.C, N, S * S, p_outgw, p_outgb, nullptr, 0, st, ar, &A, &Bf))) return rc;
+    if (!ar.dry) {
+        VD_REQUIRE(h.H == S && h.C == final_ch, "output head shape");
+        if ((rc = launch_out_conv(h.p, A, Bf, W(p_outw), W(p_outb), N, S, S, h.C, 3, in.eps, st))) return rc;
+    }
+    return 0;
+}
+
+int vd_engine::ensure_ws(int B, int T) {
+    Arena dry; dry.dry = true;
+    FwdIn fi{}; fi.B = B; fi.T = T;
+    int rc = forward(fi, nullptr, dry);
+    if (rc) return rc;
+    const size_t need = dry.used + (size_t)B * T * 3 * cfg.image_size * cfg.image_size * sizeof(float) + 4096;
+    if (need > ws_cap) {
+        if (ws) VD_HIP(hipFree(ws));
+        ws = nullptr; ws_cap = 0;
+        VD_HIP(hipMalloc(reinterpret_cast<void**>(&ws), need));
+        ws_cap = need;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char* vd_last_error(void) { return g_last_error.c_str(); }
+const char* vd_version(void) { return "vdamd 0.1 (gfx950, fp32 MFMA)"; }
+
+int vd_create(const vd_config* cfg, vd_engine** out) {
+    VD_REQUIRE(cfg && out, "null argument");
+    vd_engine* e = new vd_engine();
+    e->cfg = *cfg;
+    int rc = e->build();
+    if (rc) { delete e; return rc; }
+    *out = e;
+    return 0;
+}
+
+void vd_destroy(vd_engine* e) { delete e; }
+
+int vd_param_count(vd_engine* e) { return e ? (int)e->params.size() : -1; }
+
+int vd_param_info(vd_engine* e, int i, char* name, int cap, int* ndim, long long shape[4]) {
+    VD_REQUIRE(e && i >= 0 && i < (int)e->params.size(), "parameter index");
+    const Param& p = e->params[i];
+    if (name && cap > 0) { std::strncpy(name, p.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (ndim) *ndim = p.nd;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = k < p.nd ? p.shape[k] : 1;
+    return 0;
+}
+
+long long vd_weights_bytes(vd_engine* e) { return e ? (long long)(e->packed_total * sizeof(float)) : -1; }
+
+int vd_set_weight_storage(vd_engine* e, void* buf, long long bytes) {
+    VD_REQUIRE(e && buf, "null argument");
+    VD_REQUIRE(bytes >= (long long)(e->packed_total * sizeof(float)), "weight buffer too small");
+    e->wbuf = static_cast<float*>(buf);
+    return 0;
+}
+
+int vd_load_weight(vd_engine* e, const char* name, const float* host, long long numel) {
+    VD_REQUIRE(e && name && host, "null argument");
+    VD_REQUIRE(e->wbuf, "vd_set_weight_storage first");
+    auto it = e->pidx.find(name);
+    if (it == e->pidx.end()) { set_error(std::string("unexpected key in state_dict: ") + name); return -1; }
+    Param& p = e->params[it->second];
+    if ((long long)p.numel != numel) {
+        set_error("size mismatch for " + p.name + ": expected " + std::to_string(p.numel) + " got " + std::to_string(numel));
+        return -1;
+    }
+    std::vector<float> tmp;
+    const float* src = host;
+    if (p.kind == PK_CONV3 || p.kind == PK_OUTCONV || p.kind == PK_STEM) {
+        const int O = (int)p.shape[0], I = (int)p.shape[1];
+        const int Ip = p.kind == PK_STEM ? STEM_CPAD : I;
+        tmp.assign((size_t)9 * O * Ip, 0.f);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int t = 0; t < 9; ++t) tmp[((size_t)t * O + o) * Ip + i] = host[((size_t)o * I + i) * 9 + t];
+        src = tmp.data();
+    } else if (p.kind == PK_POSENC) {
+        const int C = (int)p.shape[1], HW = (int)(p.shape[2] * p.shape[3]);
+        tmp.resize((size_t)C * HW);
+        for (int c = 0; c < C; ++c)
+            for (int q = 0; q < HW; ++q) tmp[(size_t)q * C + c] = host[(size_t)c * HW + q];
+        src = tmp.data();
+    }
+    VD_HIP(hipMemcpy(e->wbuf + p.off, src, p.packed * sizeof(float), hipMemcpyHostToDevice));
+    p.loaded = true;
+    return 0;
+}
+
+int vd_weights_missing(vd_engine* e) {
+    if (!e) return -1;
+    int n = 0;
+    for (auto& p : e->params) n += p.loaded ? 0 : 1;
+    return n;
+}
+
+int vd_mark_weights_loaded(vd_engine* e) {
+    VD_REQUIRE(e, "null argument");
+    for (auto& p : e->params) p.loaded = true;
+    return 0;
+}
+
+int vd_pos_channels(vd_engine* e) { return e ? e->pos_ch : -1; }
+int vd_pos_resolution(vd_engine* e) { return e ? e->pos_res : -1; }
+
+int vd_set_freqs(vd_engine* e, const float* tf, int nt, const float* ff, int nf) {
+    VD_REQUIRE(e && tf && nt > 0, "time frequencies");
+    if (e->d_freq_time) VD_HIP(hipFree(e->d_freq_time));
+    VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_freq_time), nt * sizeof(float)));
+    VD_HIP(hipMemcpy(e->d_freq_time, tf, nt * sizeof(float), hipMemcpyHostToDevice));
+    e->n_freq_time = nt;
+    if (ff && nf > 0) {
+        if (e->d_freq_frame) VD_HIP(hipFree(e->d_freq_frame));
+        VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_freq_frame), nf * sizeof(float)));
+        VD_HIP(hipMemcpy(e->d_freq_frame, ff, nf * sizeof(float), hipMemcpyHostToDevice));
+        e->n_freq_frame = nf;
+    }
+    return 0;
+}
+
+int vd_set_schedule(vd_engine* e, int nts, const float* tab, const int* tmap, float rescale) {
+    VD_REQUIRE(e && tab && tmap && nts > 0, "schedule tables");
+    if (e->d_tab) VD_HIP(hipFree(e->d_tab));
+    if (e->d_tmap) VD_HIP(hipFree(e->d_tmap));
+    VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_tab), (size_t)NTAB * nts * sizeof(float)));
+    VD_HIP(hipMemcpy(e->d_tab, tab, (size_t)NTAB * nts * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> tm(nts);
+    for (int i = 0; i < nts; ++i) tm[i] = (float)tmap[i];
+    VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_tmap), nts * sizeof(float)));
+    VD_HIP(hipMemcpy(e->d_tmap, tm.data(), nts * sizeof(float), hipMemcpyHostToDevice));
+    e->num_timesteps = nts;
+    e->rescale = rescale;
+    return 0;
+}
+
+int vd_workspace_bytes(vd_engine* e, int B, int T, long long* bytes) {
+    VD_REQUIRE(e && bytes && B > 0 && T > 0, "arguments");
+    Arena dry; dry.dry = true;
+    FwdIn fi{}; fi.B = B; fi.T = T;
+    int rc = e->forward(fi, nullptr, dry);
+    if (rc) return rc;
+    *bytes = (long long)dry.used;
+    return 0;
+}
+
+static int check_ready(vd_engine* e, int B, int T) {
+    VD_REQUIRE(e, "null engine");
+    VD_REQUIRE(B > 0 && T > 0 && T <= 32, "window of 1..32 frames");
+    VD_REQUIRE(e->wbuf, "weights not set");
+    int miss = vd_weights_missing(e);
+    if (miss) {
+        for (auto& p : e->params) if (!p.loaded) { set_error("missing key in state_dict: " + p.name + " (+" + std::to_string(miss - 1) + " more)"); break; }
+        return -1;
+    }
+    return 0;
+}
+
+int vd_unet_forward(vd_engine* e, int B, int T, const float* x, const float* obs_src, const float* obs,
+                    const float* lat, const float* km, const long long* fidx, const float* t_model, int obs_mode,
+                    float* eps, void* stream) {
+    int rc = check_ready(e, B, T);
+    if (rc) return rc;
+    VD_REQUIRE(x && obs_src && obs && lat && km && fidx && t_model && eps, "null tensor");
+    VD_REQUIRE(obs_mode >= 0 && obs_mode <= 2, "observed_frames must be x_0 / x_t / x_t_minus_1");
+    if ((rc = e->ensure_ws(B, T))) return rc;
+    Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
+    FwdIn fi{B, T, x, obs_src, obs, lat, km, t_model, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
+    return e->forward(fi, static_cast<hipStream_t>(stream), ar);
+}
+
+__global__ void map_t_kernel(const int64_t* t, const float* tmap, float rescale, int B, int nts, float* out) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        long long i = t[b];
+        i = i < 0 ? 0 : (i >= nts ? nts - 1 : i);
+        out[b] = tmap[i] * rescale;
+    }
+}
+
+static int sample_impl(vd_engine* e, int mode, int B, int T, const float* x, const float* obs_src, const float* obs,
+                       const float* lat, const float* km, const long long* fidx, const long long* t, int obs_mode,
+                       int clip, float eta, const float* noise, unsigned long long seed, unsigned long long offset,
+                       float* sample, float* xstart, float* eps_out, void* stream) {
+    int rc = check_ready(e, B, T);
+    if (rc) return rc;
+    VD_REQUIRE(e->d_tab, "vd_set_schedule not called");
+    VD_REQUIRE(x && t && sample, "null tensor");
+    if ((rc = e->ensure_ws(B, T))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t per = (size_t)T * 3 * e->cfg.image_size * e->cfg.image_size;
+    // tail of the workspace: t_model [B] + eps scratch
+    float* tm = reinterpret_cast<float*>(e->ws + e->ws_cap - 4096);
+    float* eps = eps_out ? eps_out : reinterpret_cast<float*>(e->ws + e->ws_cap - 4096 - B * per * sizeof(float));
+    hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(t), e->d_tmap,
+                       e->rescale, B, e->num_timesteps, tm);
+    Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
+    FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
+    if ((rc = e->forward(fi, st, ar))) return rc;
+    PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
+                     mode, eta, seed, offset, sample, xstart};
+    return launch_posterior(pa, st);
+}
+
+int vd_p_sample(vd_engine* e, int B, int T, const float* x, const float* obs_src, const float* obs, const float* lat,
+                const float* km, const long long* fidx, const long long* t, int obs_mode, int clip, const float* noise,
+                unsigned long long seed, unsigned long long offset, float* sample, float* xstart, float* eps, void* stream) {
+    return sample_impl(e, 0, B, T, x, obs_src, obs, lat, km, fidx, t, obs_mode, clip, 0.f, noise, seed, offset, sample,
+                       xstart, eps, stream);
+}
+
+int vd_ddim_sample(vd_engine* e, int B, int T, const float* x, const float* obs_src, const float* obs, const float* lat,
+                   const float* km, const long long* fidx, const long long* t, int obs_mode, int clip, float eta,
+                   const float* noise, unsigned long long seed, unsigned long long offset, float* sample, float* xstart,
+                   float* eps, void* stream) {
+    return sample_impl(e, 1, B, T, x, obs_src, obs, lat, km, fidx, t, obs_mode, clip, eta, noise, seed, offset, sample,
+                       xstart, eps, stream);
+}
+
+int vd_posterior_update(vd_engine* e, int mode, int B, long long per, const float* x, const float* eps,
+                        const long long* t, int clip, float eta, const float* noise, unsigned long long seed,
+                        unsigned long long offset, float* sample, float* xstart, void* stream) {
+    VD_REQUIRE(e && e->d_tab, "vd_set_schedule not called");
+    VD_REQUIRE(x && eps && t && sample && (mode == 0 || mode == 1), "arguments");
+    PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
+                     mode, eta, seed, offset, sample, xstart};
+    return launch_posterior(pa, static_cast<hipStream_t>(stream));
+}
+
+int vd_q_sample(vd_engine* e, int B, long long per, const float* x0, const long long* t, const float* noise, float* out,
+                void* stream) {
+    VD_REQUIRE(e && e->d_tab, "vd_set_schedule not called");
+    VD_REQUIRE(x0 && t && noise && out, "null tensor");
+    return launch_q_sample(x0, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, out,
+                           static_cast<hipStream_t>(stream));
+}
+
+int vd_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream) {
+    VD_REQUIRE(out && n >= 0, "arguments");
+    return launch_randn(out, (long)n, seed, offset, static_cast<hipStream_t>(stream));
+}
+
+// ---- single-operator entry points ---------------------------------------------------------------
+int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, int ups, int stride,
+               int pad, int ksz, const float* w, const float* bias, const float* affA, const float* affB, int act,
+               const float* res, const float* fbias, int fbias_ld, float* out, int Cout, void* stream) {
+    IgemmArgs g{};
+    g.src0 = src0; g.src1 = src1; g.C0 = C0; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws; g.ups = ups;
+    g.stride = stride; g.pad = pad; g.ksz = ksz;
+    g.Ho = ((Hs << ups) + 2 * pad - ksz) / stride + 1;
+    g.Wo = ((Ws << ups) + 2 * pad - ksz) / stride + 1;
+    g.w = w; g.bias = bias; g.affA = affA; g.affB = affB; g.act = act; g.res = res; g.res_ld = Cout;
+    g.fbias = fbias; g.fbias_ld = fbias_ld; g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
+    return launch_igemm(g, static_cast<hipStream_t>(stream));
+}
+
+int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, int HW, const float* gamma,
+                  const float* beta, const float* film, int film_ld, float* affA, float* affB, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int split = gn_stats_split(nfr, HW, C);
+    double* part; float* mr;
+    VD_HIP(hipMalloc(reinterpret_cast<void**>(&part), (size_t)nfr * split * C * 2 * sizeof(double)));
+    VD_HIP(hipMalloc(reinterpret_cast<void**>(&mr), (size_t)nfr * 64 * sizeof(float)));
+    int rc = launch_gn_stats(src0, src1, C0, C, nfr, HW, part, split, mr, st);
+    if (!rc) rc = launch_gn_affine(mr, gamma, beta, film, film_ld, nfr, C, affA, affB, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(part); (void)hipFree(mr);
+    return rc;
+}
+
+int vd_op_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y, void* stream) {
+    return launch_affine_apply(x, affA, affB, nfr, HW, C, y, static_cast<hipStream_t>(stream));
+}
+
+int vd_op_gn_temporal(const float* x, const float* gamma, const float* beta, int B, int T, int HW, int C, float* y,
+                      void* stream) {
+    return launch_gn_temporal(x, gamma, beta, B, T, HW, C, y, static_cast<hipStream_t>(stream));
+}
+
+int vd_op_attn_spatial(const float* qkv, int nfr, int L, int C, int heads, float* out, void* stream) {
+    AttnSpatialArgs a{qkv, out, nfr, L, C, heads, 1.0f / sqrtf((float)(C / heads))};
+    return launch_attn_spatial(a, static_cast<hipStream_t>(stream));
+}
+
+int vd_op_attn_temporal(const float* qkv, const float* Rk, const float* Rq, const float* Rv, const float* mask, int B,
+                        int T, int HW, int C, int heads, int allow_pad, float* out, void* stream) {
+    AttnTemporalArgs a{qkv, Rk, Rq, Rv, mask, out, B, T, HW, C, heads, allow_pad, 1.0f / sqrtf((float)(C / heads))};
+    return launch_attn_temporal(a, static_cast<hipStream_t>(stream));
+}
+
+int vd_op_out_conv(const float* x, const float* affA, const float* affB, const float* w, const float* bias, int nfr,
+                   int H, int W, int C, int Cout, float* out, void* stream) {
+    return launch_out_conv(x, affA, affB, w, bias, nfr, H, W, C, Cout, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,313 @@
+// Small HBM-bound kernels around the UNet torso and the per-step posterior update, gfx950.
+#include "vd_common.h"
+
+namespace vd {
+
+// ------------------------------------------------------------------ network input (CondMargVideoModel.forward,
+// unet.py:951-983,991-1013): 5 channels [x*lat + obs_src*obs + x*(1-any), obs, kinda_marg], NCHW -> NHWC,
+// zero padded to Cpad so the stem convolution runs on the MFMA kernel; per-frame timesteps; attention mask.
+__global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
+    const int n = blockIdx.y;
+    const int HW = a.H * a.W;
+    const float om = a.obs_mask[n], lm = a.lat_mask[n], km = a.km_mask[n];
+    const float any = fminf(om + lm + km, 1.0f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float t = a.t_model[n / a.T];
+        const float tobs = a.obs_t_mode == 0 ? 0.f : (a.obs_t_mode == 1 ? t : t - 1.f);
+        a.t_frames[n] = tobs * om + t * (1.f - om);
+        a.amask[n] = any;
+    }
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    float* o = a.x_nhwc + ((size_t)n * HW + p) * a.Cpad;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float xv = a.x[((size_t)n * 3 + c) * HW + p];
+        const float ov = a.obs_src[((size_t)n * 3 + c) * HW + p];
+        v[c] = xv * lm + ov * om + xv * (1.f - any);
+    }
+    v[3] = om; v[4] = km; v[5] = v[6] = v[7] = 0.f;
+    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], 0.f, 0.f, 0.f};
+    for (int c = 8; c < a.Cpad; c += 4) *reinterpret_cast<f32x4*>(o + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+int launch_assemble(const AssembleArgs& a, hipStream_t s) {
+    VD_REQUIRE(a.Cpad % 8 == 0 && a.Cpad >= 8, "padded input channels");
+    hipLaunchKernelGGL(assemble_kernel, dim3((a.H * a.W + 255) / 256, a.B * a.T), dim3(256), 0, s, a);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ sinusoidal embedding (nn.py:89-107)
+// out[n] = [cos(t*f_i) | sin(t*f_i)], f from a host-built table so the angles match the reference bit for bit.
+__global__ void sinus_kernel(const float* __restrict__ t, const float* __restrict__ freqs, int half, int dim,
+                             float* __restrict__ out) {
+    const int n = blockIdx.x;
+    const float tv = t[n];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        const float arg = tv * freqs[i];
+        out[(size_t)n * dim + i] = cosf(arg);
+        out[(size_t)n * dim + half + i] = sinf(arg);
+    }
+    if ((dim & 1) && threadIdx.x == 0) out[(size_t)n * dim + dim - 1] = 0.f;
+}
+
+int launch_sinus_embed(const float* t, int n, int dim, const float* freqs, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sinus_kernel, dim3(n), dim3(64), 0, s, t, freqs, dim / 2, dim, out);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// frame embedding values (unet.py:914-926): t = fi (- mean over the window when centred)
+__global__ void frame_t_kernel(const int64_t* __restrict__ fidx, int T, int center, float* __restrict__ tv) {
+    const int b = blockIdx.x;
+    float mean = 0.f;
+    if (center) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += (float)fidx[b * T + t];
+        mean = s / (float)T;
+    }
+    for (int t = threadIdx.x; t < T; t += blockDim.x) tv[b * T + t] = (float)fidx[b * T + t] - mean;
+}
+
+int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hipStream_t s) {
+    hipLaunchKernelGGL(frame_t_kernel, dim3(B), dim3(64), 0, s, fidx, T, center, tv);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ RPENet hidden layer (unet.py:283-296)
+__global__ __launch_bounds__(256) void rpe_hidden_kernel(const float* __restrict__ te, int te_ld,
+                                                         const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                         const int64_t* __restrict__ fidx, int T, int C,
+                                                         float* __restrict__ E) {
+    const int row = blockIdx.x;                 // (b*T + t)*T + s
+    const int s_ = row % T, bt = row / T, b = bt / T;
+    const float d = (float)(fidx[bt] - fidx[b * T + s_]);
+    const float f0 = logf(1.0f + fmaxf(d, 0.f)), f1 = logf(1.0f + fmaxf(-d, 0.f)), f2 = d == 0.f ? 1.f : 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float lin = bd[c] + f0 * Wd[c * 3] + f1 * Wd[c * 3 + 1] + f2 * Wd[c * 3 + 2];
+        E[(size_t)row * C + c] = silu_f(te[(size_t)bt * te_ld + c] + lin);
+    }
+}
+
+int launch_rpe_hidden(const float* te, int te_ld, const float* Wd, const float* bd, const int64_t* fidx, int B, int T,
+                      int C, float* E, hipStream_t s) {
+    hipLaunchKernelGGL(rpe_hidden_kernel, dim3(B * T * T), dim3(256), 0, s, te, te_ld, Wd, bd, fidx, T, C, E);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// bucket-table relative positions (RPE.get_bucket_ids, unet.py:330-347; iRPE eq. 18)
+__global__ __launch_bounds__(256) void rpe_table_kernel(const float* __restrict__ table, const int64_t* __restrict__ fidx,
+                                                        int T, int C, float alpha, float beta, float gamma, float lg,
+                                                        float* __restrict__ R) {
+    const int row = blockIdx.x;
+    const int s_ = row % T, bt = row / T, b = bt / T;
+    const long long d = fidx[bt] - fidx[b * T + s_];
+    long long id = d;
+    const float ad = fabsf((float)d);
+    if (ad > alpha) {
+        const float coef = logf(ad / alpha) / lg;
+        const float v = fminf(beta, alpha + coef * (beta - alpha));
+        id = (long long)(int)v * (d > 0 ? 1 : -1);
+    }
+    const int nb = 2 * (int)beta + 1;
+    if (id < 0) id += nb;                       // negative indices wrap, as torch indexing does
+    for (int c = threadIdx.x; c < C; c += 256) R[(size_t)row * C + c] = table[(size_t)id * C + c];
+}
+
+int launch_rpe_table(const float* table, const int64_t* fidx, int B, int T, int C, float alpha, float beta,
+                     float gamma, float* R, hipStream_t s) {
+    const float lg = (float)log((double)gamma / (double)alpha);
+    hipLaunchKernelGGL(rpe_table_kernel, dim3(B * T * T), dim3(256), 0, s, table, fidx, T, C, alpha, beta, gamma, lg, R);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ h + spatial_encoding (+ frame embedding)
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x, const float* __restrict__ P,
+                                                     const float* __restrict__ femb, size_t per_frame4, int C4,
+                                                     size_t total4, float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        if (P) v += reinterpret_cast<const f32x4*>(P)[i % per_frame4];
+        if (femb) v += reinterpret_cast<const f32x4*>(femb)[(i / per_frame4) * C4 + (i % C4)];
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+int launch_posenc_add(const float* x, const float* P, const float* femb, int nfr, int HW, int C, float* y,
+                      hipStream_t s) {
+    const size_t total4 = (size_t)nfr * HW * C / 4;
+    const int grid = (int)std::min<size_t>((total4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(posenc_kernel, dim3(grid), dim3(256), 0, s, x, P, femb, (size_t)HW * C / 4, C / 4, total4, y);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ output head: GN-affine + SiLU + conv3x3 C->Cout (<=4)
+// NHWC in, NCHW out (the caller's layout).  16x16 output pixels per block, the activated halo tile
+// staged through LDS 32 channels at a time; VALU (3 output channels cannot feed a 32x32 MFMA tile).
+constexpr int OT = 16;
+__global__ __launch_bounds__(256) void out_conv_kernel(const float* __restrict__ x, const float* __restrict__ affA,
+                                                       const float* __restrict__ affB, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int H, int W, int C, int Cout,
+                                                       float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float tile[(OT + 2) * (OT + 2) * 36];
+    __shared__ __attribute__((aligned(16))) float ws[9 * 4 * 32];
+    const int n = blockIdx.z, y0 = blockIdx.y * OT, x0 = blockIdx.x * OT;
+    const int tid = threadIdx.x, ty = tid / OT, tx = tid % OT;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        __syncthreads();
+        for (int i = tid; i < (OT + 2) * (OT + 2) * 8; i += 256) {
+            const int pix = i >> 3, q = i & 7;
+            const int iy = y0 + pix / (OT + 2) - 1, ix = x0 + pix % (OT + 2) - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + iy) * W + ix) * C + c0 + q * 4);
+                const f32x4 A = *reinterpret_cast<const f32x4*>(affA + (size_t)n * C + c0 + q * 4);
+                const f32x4 B = *reinterpret_cast<const f32x4*>(affB + (size_t)n * C + c0 + q * 4);
+                v = v * A + B;
+                v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
+            }
+            *reinterpret_cast<f32x4*>(tile + pix * 36 + q * 4) = v;
+        }
+        for (int i = tid; i < 9 * 4 * 32; i += 256) {
+            const int tap = i / 128, co = (i / 32) % 4, c = i % 32;
+            ws[i] = co < Cout ? w[((size_t)tap * Cout + co) * C + c0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* tp = tile + ((ty + tap / 3) * (OT + 2) + tx + tap % 3) * 36;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tp + q * 4);
+#pragma unroll
+                for (int co = 0; co < 4; ++co) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + (tap * 4 + co) * 32 + q * 4);
+                    acc[co] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                }
+            }
+        }
+    }
+    const int oy = y0 + ty, ox = x0 + tx;
+    if (oy < H && ox < W)
+        for (int co = 0; co < Cout; ++co) out[(((size_t)n * Cout + co) * H + oy) * W + ox] = acc[co] + bias[co];
+}
+
+int launch_out_conv(const float* x, const float* affA, const float* affB, const float* w, const float* bias, int nfr,
+                    int H, int W, int C, int Cout, float* out_nchw, hipStream_t s) {
+    VD_REQUIRE(Cout <= 4 && C % 32 == 0, "output head: Cout <= 4, C multiple of 32");
+    hipLaunchKernelGGL(out_conv_kernel, dim3((W + OT - 1) / OT, (H + OT - 1) / OT, nfr), dim3(256), 0, s, x, affA, affB,
+                       w, bias, H, W, C, Cout, out_nchw);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
+__device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned long long key, unsigned (&o)[4]) {
+    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0x5eed5eedu, c3 = 0;
+    unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// element i -> standard normal; elements 4j..4j+3 share one Philox block
+__device__ __forceinline__ float normal_at(unsigned long long seed, unsigned long long offset, unsigned long long i) {
+    unsigned r[4];
+    philox4x32_10(offset + (i >> 2), seed, r);
+    const int pair = (int)(i & 2);
+    const float u1 = ((float)r[pair] + 1.0f) * 2.3283064365386963e-10f;       // (0,1]
+    const float u2 = (float)r[pair + 1] * 2.3283064365386963e-10f;
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    return (i & 1) ? rad * sn : rad * cs;
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* out, size_t n, unsigned long long seed,
+                                                    unsigned long long offset) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = normal_at(seed, offset, i);
+}
+
+int launch_randn(float* out, long n, unsigned long long seed, unsigned long long offset, hipStream_t s) {
+    const int grid = (int)std::min<long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(randn_kernel, dim3(grid), dim3(256), 0, s, out, (size_t)n, seed, offset);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ posterior update (one fused pass)
+// p_sample (gaussian_diffusion.py:319-343,374-382,208-227,438-443) and ddim_sample (:597-634).
+// Coefficients are float32 casts of the float64 tables, exactly what _extract_into_tensor yields.
+__global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
+    const size_t total = (size_t)a.B * a.per;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / a.per);
+        const int t = (int)a.t[b];
+        const float* tb = a.tab + t;
+        const int NT = a.num_timesteps;
+        const float x = a.x[i], e = a.eps[i];
+        float x0 = tb[TAB_SQRT_RECIP * NT] * x - tb[TAB_SQRT_RECIPM1 * NT] * e;
+        if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        const float z = a.noise ? a.noise[i] : normal_at(a.seed, a.offset, i);
+        const float nz = t != 0 ? 1.0f : 0.0f;
+        float smp;
+        if (a.mode == 0) {
+            const float mean = tb[TAB_COEF1 * NT] * x0 + tb[TAB_COEF2 * NT] * x;
+            smp = mean + nz * expf(0.5f * tb[TAB_LOGVAR * NT]) * z;
+        } else {
+            const float e2 = (tb[TAB_SQRT_RECIP * NT] * x - x0) / tb[TAB_SQRT_RECIPM1 * NT];
+            const float ab = tb[TAB_ACP * NT], abp = tb[TAB_ACP_PREV * NT];
+            const float sigma = a.eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
+            const float mean = x0 * sqrtf(abp) + sqrtf(1.f - abp - sigma * sigma) * e2;
+            smp = mean + nz * sigma * z;
+        }
+        a.sample[i] = smp;
+        if (a.xstart) a.xstart[i] = x0;
+    }
+}
+
+int launch_posterior(const PosteriorArgs& a, hipStream_t s) {
+    const size_t total = (size_t)a.B * a.per;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(posterior_kernel, dim3(grid), dim3(256), 0, s, a);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// q_sample (gaussian_diffusion.py:190-206)
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* x0, const float* noise, const int64_t* t,
+                                                       const float* tab, int NT, size_t per, size_t total, float* out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        long long tt = t[i / per];
+        if (tt < 0) tt += NT;                   // t-1 at t=0 wraps like numpy/torch indexing (gaussian_diffusion.py:565-568)
+        out[i] = tab[TAB_SQRT_ACP * NT + tt] * x0[i] + tab[TAB_SQRT_1M_ACP * NT + tt] * noise[i];
+    }
+}
+
+int launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab, int num_timesteps, int B,
+                    long per, float* out, hipStream_t s) {
+    const size_t total = (size_t)B * per;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(q_sample_kernel, dim3(grid), dim3(256), 0, s, x0, noise, t, tab, num_timesteps, (size_t)per,
+                       total, out);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vd

@@ -1,0 +1,149 @@
+// Common definitions for the gfx950 kernels and the step engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace vd {
+
+// Error plumbing: every C-ABI entry returns 0 or a negative code; text via vd_last_error().
+void set_error(const std::string& msg);
+extern thread_local std::string g_last_error;
+
+#define VD_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            vd::set_error(std::string(#call) + ": " + hipGetErrorString(e_));          \
+            return -2;                                                                 \
+        }                                                                              \
+    } while (0)
+
+#define VD_REQUIRE(cond, msg)                                                          \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            vd::set_error(std::string("requirement failed: ") + #cond + " -- " + msg); \
+            return -1;                                                                 \
+        }                                                                              \
+    } while (0)
+
+// ---------------------------------------------------------------- kernel argument blocks
+// Implicit-GEMM convolution / linear layer on NHWC activations (see igemm.hip).
+struct IgemmArgs {
+    const float* src0;   // [nfr][Hs][Ws][C0]
+    const float* src1;   // [nfr][Hs][Ws][Cin-C0] or null  (virtual channel concat, unet.py:826-828)
+    int C0, Cin;
+    int nfr, Hs, Ws;     // stored source dims
+    int ups;             // 1: source is read through a nearest x2 upsample (unet.py:69)
+    int stride, pad, ksz;
+    int Ho, Wo;
+    const float* w;      // [ksz*ksz][Cout][Cin]
+    const float* bias;   // [Cout] or null
+    const float* affA;   // [nfr][Cin] per-frame per-channel scale  (GroupNorm/FiLM folded), or null
+    const float* affB;   // [nfr][Cin] shift
+    int act;             // 1: SiLU on the (affine-transformed) input
+    const float* res;    // [M][res_ld] residual added in the epilogue, or null
+    int res_ld;
+    const float* fbias;  // [nfr][fbias_ld] per-frame bias (ResBlock without scale-shift: h + emb_out, unet.py:196), or null
+    int fbias_ld;
+    float* out;          // [M][ldo]
+    int ldo;
+    int Cout, M;
+};
+
+struct AttnSpatialArgs {
+    const float* qkv;    // [nfr*L][3C]: q | k | v, each [heads][F]
+    float* out;          // [nfr*L][C]
+    int nfr, L, C, heads;
+    float scale;
+};
+
+struct AttnTemporalArgs {
+    const float* qkv;    // [B*T*HW][3C]
+    const float* Rk;     // [B][T][T][C] or null
+    const float* Rq;
+    const float* Rv;
+    const float* mask;   // [B][T] (1 = real frame) or null
+    float* out;          // [B*T*HW][C]
+    int B, T, HW, C, heads;
+    int allow_pad;       // allow_interactions_between_padding
+    float scale;
+};
+
+int launch_igemm(const IgemmArgs& a, hipStream_t s);
+int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s);
+int launch_attn_temporal(const AttnTemporalArgs& a, hipStream_t s);
+
+// GroupNorm statistics over (pixels x channels-of-group) of one frame, 32 groups, virtual concat.
+// part: workspace of nfr*split*C*2 doubles; meanrstd out: [nfr][32][2] floats.
+int launch_gn_stats(const float* src0, const float* src1, int C0, int C, int nfr, int HW, double* part, int split,
+                    float* meanrstd, hipStream_t s);
+int gn_stats_split(int nfr, int HW, int C);
+// affA/affB[n][c] = fold(mean, rstd, gamma, beta, FiLM scale/shift).  film: [nfr][film_ld], scale at +0, shift at +C.
+int launch_gn_affine(const float* meanrstd, const float* gamma, const float* beta, const float* film, int film_ld,
+                     int nfr, int C, float* affA, float* affB, hipStream_t s);
+// y = x*A[n][c] + B[n][c]  (materialised normalisation for the attention residual, unet.py:474,538)
+int launch_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y,
+                        hipStream_t s);
+// Temporal GroupNorm: stats over (T x C/32) for every (b, pixel); writes the normalised tensor.
+int launch_gn_temporal(const float* x, const float* gamma, const float* beta, int B, int T, int HW, int C, float* y,
+                       hipStream_t s);
+
+struct AssembleArgs {
+    const float* x;      // [B][T][3][H][W]
+    const float* obs_src;// frames substituted where obs_mask=1 (x0 / x / x_t_minus_1)
+    const float* obs_mask, *lat_mask, *km_mask;   // [B*T]
+    const float* t_model;// [B] value handed to the network (already mapped / rescaled)
+    int obs_t_mode;      // 0: 'x_0' (obs frames see t=0), 1: 'x_t', 2: 'x_t_minus_1'
+    int B, T, H, W, Cpad;
+    float* x_nhwc;       // [B*T][H][W][Cpad]  (5 real channels + zero pad)
+    float* t_frames;     // [B*T]
+    float* amask;        // [B*T] anything mask
+};
+int launch_assemble(const AssembleArgs& a, hipStream_t s);
+// out[n] = [cos(t*f) | sin(t*f)] with the frequency table built on the host (nn.py:89-107)
+int launch_sinus_embed(const float* t, int n, int dim, const float* freqs, float* out, hipStream_t s);
+// RPENet hidden: E[b,t,s,c] = silu(te[b*T+t][c] + Wd[c][:]*feat(d) + bd[c]), d = fi[b,t]-fi[b,s]  (unet.py:283-296)
+int launch_rpe_hidden(const float* te, int te_ld, const float* Wd, const float* bd, const int64_t* fidx, int B, int T,
+                      int C, float* E, hipStream_t s);
+// bucket-table path (unet.py:330-347): R[b,t,s,:] = table[bucket(d)]
+int launch_rpe_table(const float* table, const int64_t* fidx, int B, int T, int C, float alpha, float beta,
+                     float gamma, float* R, hipStream_t s);
+// h = x + P[pixel][c] (+ frame embedding [n][c])
+int launch_posenc_add(const float* x, const float* P, const float* femb, int nfr, int HW, int C, float* y,
+                      hipStream_t s);
+// tv[b*T+t] = fidx - (center ? mean_t fidx : 0)   (unet.py:914-926)
+int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hipStream_t s);
+// out conv: GN-affine + SiLU + conv3x3 (C -> Cout<=8), NHWC in, NCHW out  (unet.py:744-749,838)
+int launch_out_conv(const float* x, const float* affA, const float* affB, const float* w, const float* bias, int nfr,
+                    int H, int W, int C, int Cout, float* out_nchw, hipStream_t s);
+
+struct PosteriorArgs {
+    const float* x;      // x_t   [B][per]
+    const float* eps;    // model output
+    const float* noise;  // explicit noise or null (then Philox(seed, offset))
+    const int64_t* t;    // [B] respaced index
+    const float* tab;    // [NTAB][num_timesteps] float32 tables (gathered in f64 on host, cast like the reference)
+    int num_timesteps;
+    int B; long per;
+    int clip;
+    int mode;            // 0: p_sample, 1: ddim
+    float eta;
+    unsigned long long seed, offset;
+    float* sample; float* xstart;   // outputs (xstart may be null)
+};
+int launch_posterior(const PosteriorArgs& a, hipStream_t s);
+int launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab, int num_timesteps, int B,
+                    long per, float* out, hipStream_t s);
+int launch_randn(float* out, long n, unsigned long long seed, unsigned long long offset, hipStream_t s);
+
+enum { TAB_SQRT_RECIP = 0, TAB_SQRT_RECIPM1, TAB_COEF1, TAB_COEF2, TAB_LOGVAR, TAB_ACP, TAB_ACP_PREV,
+       TAB_SQRT_ACP, TAB_SQRT_1M_ACP, NTAB };
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+}  // namespace vd

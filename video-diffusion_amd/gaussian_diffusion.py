@@ -1,0 +1,276 @@
+"""Host-side mirror of the reference's diffusion process for the SAMPLING path.
+
+Same names, arguments, return values and error behaviour as
+`improved_diffusion/gaussian_diffusion.py` (reference file:line cited per
+method); the float64 schedule tables are built here with numpy exactly as the
+reference does and uploaded once (as their float32 casts, which is what
+`_extract_into_tensor`, gaussian_diffusion.py:1019-1031, feeds the arithmetic),
+and every tensor operation of a step runs in the HIP engine behind the C ABI.
+Training losses / bpd / gradient guidance are out of scope.
+"""
+import enum
+import math
+
+import numpy as np
+import torch as th
+
+from . import _lib
+
+
+def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
+    """gaussian_diffusion.py:20-52."""
+    if schedule_name in ("linear", "noisier_linear"):
+        scale = 1000 / num_diffusion_timesteps
+        end = 0.02 if schedule_name == "linear" else 0.025
+        return np.linspace(scale * 0.0001, scale * end, num_diffusion_timesteps, dtype=np.float64)
+    if schedule_name == "cosine":
+        return betas_for_alpha_bar(num_diffusion_timesteps,
+                                   lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2)
+    raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    """gaussian_diffusion.py:55-74."""
+    n = num_diffusion_timesteps
+    return np.array([min(1 - alpha_bar((i + 1) / n) / alpha_bar(i / n), max_beta) for i in range(n)])
+
+
+class ModelMeanType(enum.Enum):
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelVarType(enum.Enum):
+    LEARNED = enum.auto()
+    FIXED_SMALL = enum.auto()
+    FIXED_LARGE = enum.auto()
+    LEARNED_RANGE = enum.auto()
+
+
+class LossType(enum.Enum):
+    MSE = enum.auto()
+    RESCALED_MSE = enum.auto()
+    KL = enum.auto()
+    RESCALED_KL = enum.auto()
+
+    def is_vb(self):
+        return self in (LossType.KL, LossType.RESCALED_KL)
+
+
+_OBS_MODES = {"x_0": 0, "x_t": 1, "x_t_minus_1": 2}
+
+
+def _f32(t, device):
+    return t.to(device=device, dtype=th.float32).contiguous()
+
+
+class GaussianDiffusion:
+    """gaussian_diffusion.py:107-172 (tables) + the sampling methods."""
+
+    def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False):
+        self.model_mean_type = model_mean_type
+        self.model_var_type = model_var_type
+        self.loss_type = loss_type
+        self.rescale_timesteps = rescale_timesteps
+        betas = np.array(betas, dtype=np.float64)
+        self.betas = betas
+        assert len(betas.shape) == 1, "betas must be 1-D"
+        assert (betas > 0).all() and (betas <= 1).all()
+        self.num_timesteps = int(betas.shape[0])
+        alphas = 1.0 - betas
+        self.alphas = alphas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = np.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        if model_mean_type != ModelMeanType.EPSILON:
+            raise NotImplementedError("the HIP engine implements the epsilon-prediction parameterisation "
+                                      "(create_gaussian_diffusion default, script_util.py:429-431)")
+        if model_var_type not in (ModelVarType.FIXED_LARGE, ModelVarType.FIXED_SMALL):
+            raise NotImplementedError("learn_sigma=True (LEARNED_RANGE variance) is not supported by the HIP engine")
+
+    # -- schedule upload -------------------------------------------------------------------------
+    def _model_log_variance(self):
+        """gaussian_diffusion.py:299-317."""
+        if self.model_var_type == ModelVarType.FIXED_LARGE:
+            return np.log(np.append(self.posterior_variance[1], self.betas[1:]))
+        return self.posterior_log_variance_clipped
+
+    def _device_tables(self):
+        rows = [self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
+                self.posterior_mean_coef2, self._model_log_variance(), self.alphas_cumprod,
+                self.alphas_cumprod_prev, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod]
+        return np.ascontiguousarray(np.stack(rows).astype(np.float32))
+
+    def _timestep_map_and_scale(self):
+        scale = 1000.0 / self.num_timesteps if self.rescale_timesteps else 1.0
+        return list(range(self.num_timesteps)), scale
+
+    def _bind(self, model):
+        """Upload this process' tables into the model's engine (once per (diffusion, model) pair)."""
+        model = getattr(model, "model", model)            # accept a _WrappedModel
+        if getattr(model, "_bound_schedule", None) is not self:
+            tab = self._device_tables()
+            tmap, scale = self._timestep_map_and_scale()
+            tm = np.ascontiguousarray(np.array(tmap, dtype=np.int32))
+            _lib.check(_lib.lib().vd_set_schedule(model._handle, self.num_timesteps, _lib.ptr(tab), _lib.ptr(tm),
+                                                  float(np.float32(scale))))
+            model._bound_schedule = self
+        return model
+
+    def _scale_timesteps(self, t):
+        if self.rescale_timesteps:
+            return t.float() * (1000.0 / self.num_timesteps)
+        return t
+
+    # -- per-step entry points ---------------------------------------------------------------------
+    def _step(self, mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise,
+              return_attn_weights=False, use_gradient_method=False):
+        if denoised_fn is not None:
+            raise NotImplementedError("denoised_fn is not supported by the fused HIP step")
+        if use_gradient_method:
+            raise NotImplementedError("use_gradient_method needs a UNet backward pass (out of scope, SURVEY.md 8f-4)")
+        if return_attn_weights:
+            raise NotImplementedError("return_attn_weights (wandb visualisation) is not supported")
+        if model_kwargs is None:
+            model_kwargs = {}
+        model = self._bind(model)
+        B = x.shape[0]
+        assert t.shape == (B,)                                   # gaussian_diffusion.py:273
+        dev = model.device
+        xs = _f32(x, dev)
+        kw = model._pack_kwargs(xs, model_kwargs)
+        if noise is None:
+            noise = th.randn_like(xs)                            # gaussian_diffusion.py:438 / :628 (drawn even for eta=0)
+        else:
+            noise = _f32(noise, dev)
+        assert noise.shape == xs.shape
+        tt = t.to(device=dev, dtype=th.int64).contiguous()
+        sample = th.empty_like(xs)
+        xstart = th.empty_like(xs)
+        T = xs.shape[1]
+        L = _lib.lib()
+        common = (model._handle, B, T, _lib.ptr(xs), _lib.ptr(kw["obs_src"]), _lib.ptr(kw["obs_mask"]),
+                  _lib.ptr(kw["latent_mask"]), _lib.ptr(kw["kinda_marg_mask"]), _lib.ptr(kw["frame_indices"]),
+                  _lib.ptr(tt), kw["obs_mode"], 1 if clip_denoised else 0)
+        if mode == 0:
+            rc = L.vd_p_sample(*common, _lib.ptr(noise), 0, 0, _lib.ptr(sample), _lib.ptr(xstart), None,
+                               _lib.current_stream())
+        else:
+            rc = L.vd_ddim_sample(*common, float(eta), _lib.ptr(noise), 0, 0, _lib.ptr(sample), _lib.ptr(xstart), None,
+                                  _lib.current_stream())
+        _lib.check(rc)
+        return sample, xstart
+
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None,
+                 return_attn_weights=False, use_gradient_method=False):
+        """gaussian_diffusion.py:403-448.  `x` is not modified; returns fresh tensors."""
+        sample, xstart = self._step(0, model, x, t, clip_denoised, denoised_fn, model_kwargs, 0.0, None,
+                                    return_attn_weights, use_gradient_method)
+        return {"sample": sample, "pred_xstart": xstart, "attn": None}
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
+        """gaussian_diffusion.py:597-634."""
+        sample, xstart = self._step(1, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, None)
+        return {"sample": sample, "pred_xstart": xstart}
+
+    def q_sample(self, x_start, t, noise=None, model=None):
+        """gaussian_diffusion.py:190-206.  Needs an engine for its tables: pass `model` (or call after
+        any p_sample on the same diffusion object)."""
+        model = self._bind(model if model is not None else self._last_model())
+        dev = model.device
+        xs = _f32(x_start, dev)
+        if noise is None:
+            noise = th.randn_like(xs)
+        noise = _f32(noise, dev)
+        assert noise.shape == xs.shape
+        B = xs.shape[0]
+        tt = t.to(device=dev, dtype=th.int64).reshape(-1)
+        if tt.numel() == 1 and B != 1:
+            tt = tt.expand(B)
+        tt = tt.contiguous()
+        out = th.empty_like(xs)
+        _lib.check(_lib.lib().vd_q_sample(model._handle, B, xs[0].numel(), _lib.ptr(xs), _lib.ptr(tt), _lib.ptr(noise),
+                                          _lib.ptr(out), _lib.current_stream()))
+        return out
+
+    def _last_model(self):
+        m = getattr(self, "_model_hint", None)
+        if m is None:
+            raise RuntimeError("q_sample needs the model whose engine holds the schedule tables: pass model=")
+        return m
+
+    # -- loops -------------------------------------------------------------------------------------
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
+                      latent_mask=None, device=None, progress=False, return_attn_weights=False,
+                      use_gradient_method=False):
+        """gaussian_diffusion.py:450-526: returns (sample, attns) with attns == {} (no attention logging)."""
+        final = None
+        for sample in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
+                                                     denoised_fn=denoised_fn, model_kwargs=model_kwargs,
+                                                     latent_mask=latent_mask, device=device, progress=progress,
+                                                     return_attn_weights=return_attn_weights,
+                                                     use_gradient_method=use_gradient_method):
+            final = sample
+        return final["sample"], {}
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                  model_kwargs=None, latent_mask=None, device=None, progress=False,
+                                  return_attn_weights=False, use_gradient_method=False):
+        """gaussian_diffusion.py:528-595, including the per-step side draws that consume the global RNG
+        (x_t_minus_1, random_t, x_random) so a seeded run walks the generator like the reference."""
+        base = getattr(model, "model", model)
+        if device is None:
+            device = base.device
+        assert isinstance(shape, (tuple, list))
+        img = noise if noise is not None else th.randn(*shape, device=device)
+        self._model_hint = base
+        for i in list(range(self.num_timesteps))[::-1]:
+            t = th.tensor([i] * shape[0], device=device)
+            if "hybrid" in model_kwargs["observed_frames"]:
+                raise NotImplementedError("observed_frames='hybrid_<k>' is a training-time option")
+            model_kwargs["x_t_minus_1"] = self.q_sample(
+                model_kwargs["x0"], t - 1, noise=th.randn_like(_f32(model_kwargs["x0"], device)) if noise is None else noise,
+                model=base)
+            model_kwargs["random_t"] = th.floor(t * th.rand(t.shape).to(device)).long()   # CPU generator, as :569-570
+            if noise is None:
+                th.randn_like(_f32(model_kwargs["x0"], device))   # x_random's draw: consumed, never read in eval (unet.py:962)
+            out = self.p_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                model_kwargs=model_kwargs, return_attn_weights=return_attn_weights,
+                                use_gradient_method=use_gradient_method)
+            yield out
+            img = out["sample"]
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
+                         latent_mask=None, device=None, progress=False, eta=0.0):
+        """gaussian_diffusion.py:670-700: returns the sample only."""
+        final = None
+        for sample in self.ddim_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
+                                                        denoised_fn=denoised_fn, model_kwargs=model_kwargs,
+                                                        device=device, progress=progress, eta=eta):
+            final = sample
+        return final["sample"]
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                     model_kwargs=None, latent_mask=None, device=None, progress=False, eta=0.0):
+        """gaussian_diffusion.py:702-748."""
+        base = getattr(model, "model", model)
+        if device is None:
+            device = base.device
+        assert isinstance(shape, (tuple, list))
+        img = noise if noise is not None else th.randn(*shape, device=device)
+        for i in list(range(self.num_timesteps))[::-1]:
+            t = th.tensor([i] * shape[0], device=device)
+            out = self.ddim_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                   model_kwargs=model_kwargs, eta=eta)
+            yield out
+            img = out["sample"]

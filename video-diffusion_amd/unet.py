@@ -1,0 +1,230 @@
+"""Host-side handle of the video UNet: the reference's `CondMargVideoModel` call surface
+(improved_diffusion/unet.py:929-1026) over the HIP engine.
+
+Nothing here computes: the object owns an engine handle (topology + packed weights on the GPU) and
+marshals tensors across the C ABI.  Supported surface = what the sampling path uses
+(scripts/video_sample.py:562-567,151-168): construction from the `create_video_model` keywords,
+`load_state_dict`, `to`, `eval`, `parameters`, `state_dict` and `__call__` (Boundary A).
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch as th
+
+from . import _lib
+
+_OBS_MODES = {"x_0": 0, "x_t": 1, "x_t_minus_1": 2}
+
+
+class CondMargVideoModel:
+    def __init__(self, *, T, image_size, model_channels, num_res_blocks, attention_resolutions, num_heads=1,
+                 use_scale_shift_norm=False, use_spatial_encoding=False, use_frame_encoding=False,
+                 cross_frame_attention=True, enforce_position_invariance=False, use_rpe_net=False,
+                 bucket_params=None, cond_emb_type="channel", allow_interactions_between_padding=False,
+                 in_channels=3, out_channels=3, dropout=0, num_classes=None, num_heads_upsample=-1,
+                 use_checkpoint=False, temporal_augment_type=None, channel_mult=None, **unused):
+        if cond_emb_type.replace("-initzero", "") != "channel":
+            raise NotImplementedError(f"cond_emb_type={cond_emb_type!r}: the HIP engine implements 'channel'")
+        if not cross_frame_attention:
+            raise NotImplementedError("cross_frame_attention=False")
+        if num_classes is not None or out_channels != 3 or in_channels != 3:
+            raise NotImplementedError("class conditioning / learn_sigma / non-RGB inputs")
+        if num_heads_upsample not in (-1, num_heads):
+            raise NotImplementedError("num_heads_upsample != num_heads")
+        self.T = T
+        self.image_size = image_size
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.training = False
+        self.device = th.device("cpu")
+        cfg = _lib.VdConfig()
+        cfg.image_size, cfg.num_channels, cfg.num_res_blocks, cfg.num_heads = image_size, model_channels, num_res_blocks, num_heads
+        cfg.T = int(T)
+        ads = list(attention_resolutions)
+        cfg.n_attention_ds = len(ads)
+        for i, d in enumerate(ads):
+            cfg.attention_ds[i] = int(d)
+        cfg.use_scale_shift_norm = int(bool(use_scale_shift_norm))
+        cfg.use_spatial_encoding = int(bool(use_spatial_encoding))
+        cfg.use_frame_encoding = int(bool(use_frame_encoding))
+        cfg.enforce_position_invariance = int(bool(enforce_position_invariance))
+        cfg.use_rpe_net = int(bool(use_rpe_net))
+        cfg.allow_interactions_between_padding = int(bool(allow_interactions_between_padding))
+        bp = bucket_params or dict(alpha=1, beta=1, gamma=1)
+        assert bucket_params is not None                          # unet.py:423-427
+        cfg.rp_alpha, cfg.rp_beta, cfg.rp_gamma = float(bp["alpha"]), float(bp["beta"]), float(bp["gamma"])
+        cfg.time_embed_mult = 4
+        self._cfg = cfg
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().vd_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._handle = h
+        self._specs = self._read_specs()
+        self._host_sd = None          # CPU copy kept until the weights are on the device
+        self._wbuf = None             # packed device weights (a torch tensor: broadcastable over RCCL)
+        self._bound_schedule = None
+        self._pos_ch = _lib.lib().vd_pos_channels(h)
+        self._use_frame_encoding = bool(use_frame_encoding)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                _lib.lib().vd_destroy(h)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
+            self._handle = None
+
+    # -- parameters ----------------------------------------------------------------------------------
+    def _read_specs(self):
+        L = _lib.lib()
+        out = []
+        name = ctypes.create_string_buffer(256)
+        nd = ctypes.c_int()
+        shape = (ctypes.c_longlong * 4)()
+        for i in range(L.vd_param_count(self._handle)):
+            _lib.check(L.vd_param_info(self._handle, i, name, 256, ctypes.byref(nd), shape))
+            out.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value))))
+        return out
+
+    def param_specs(self):
+        """[(checkpoint key, shape)] in the reference's state_dict order."""
+        return list(self._specs)
+
+    def load_state_dict(self, state_dict, strict=True):
+        """nn.Module.load_state_dict semantics: missing / unexpected keys raise RuntimeError when strict."""
+        want = dict(self._specs)
+        missing = [k for k in want if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in want]
+        errs = []
+        if strict and missing:
+            errs.append("Missing key(s) in state_dict: " + ", ".join(repr(k) for k in missing))
+        if strict and unexpected:
+            errs.append("Unexpected key(s) in state_dict: " + ", ".join(repr(k) for k in unexpected))
+        sd = OrderedDict()
+        for k, shape in self._specs:
+            if k not in state_dict:
+                continue
+            v = state_dict[k]
+            v = th.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
+            if tuple(v.shape) != shape:
+                errs.append(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from checkpoint, "
+                            f"the shape in current model is {shape}.")
+                continue
+            sd[k] = v.detach().to(device="cpu", dtype=th.float32).contiguous()
+        if errs:
+            raise RuntimeError("Error(s) in loading state_dict for CondMargVideoModel:\n\t" + "\n\t".join(errs))
+        self._host_sd = sd
+        if self._wbuf is not None:
+            self._upload()
+        return self
+
+    def _ensure_storage(self):
+        if self._wbuf is None:
+            nbytes = _lib.lib().vd_weights_bytes(self._handle)
+            self._wbuf = th.zeros(nbytes // 4, dtype=th.float32, device=self.device)
+            _lib.check(_lib.lib().vd_set_weight_storage(self._handle, _lib.ptr(self._wbuf), nbytes))
+            self._upload_freqs()
+
+    def _upload(self):
+        L = _lib.lib()
+        for k, v in self._host_sd.items():
+            _lib.check(L.vd_load_weight(self._handle, k.encode(), _lib.ptr(v), v.numel()))
+
+    def _upload_freqs(self):
+        # nn.py:99-101 evaluated with the reference's own float32 expression (bit-identical angles)
+        half = self.model_channels // 2
+        tf = th.exp(-math.log(10000) * th.arange(start=0, end=half, dtype=th.float32) / half).contiguous()
+        ff, nf = None, 0
+        if self._use_frame_encoding:
+            nf = self._pos_ch // 2
+            ff = th.exp(-math.log(self.T * 10) * th.arange(start=0, end=nf, dtype=th.float32) / nf).contiguous()
+        _lib.check(_lib.lib().vd_set_freqs(self._handle, _lib.ptr(tf), half, _lib.ptr(ff), nf))
+
+    def to(self, device):
+        device = th.device(device)
+        if device.type != "cuda":
+            if device.type == "cpu" and self._wbuf is None:
+                return self
+            raise RuntimeError("the HIP engine runs on a GPU only (no CPU fallback in the product path)")
+        if device.index is None:
+            device = th.device("cuda", th.cuda.current_device())
+        if self._wbuf is not None and self.device != device:
+            raise RuntimeError("engine weights are already resident on " + str(self.device))
+        self.device = device
+        with th.cuda.device(device):
+            self._ensure_storage()
+            if self._host_sd is not None:
+                self._upload()
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("the HIP engine is inference-only")
+        return self
+
+    def parameters(self):
+        """Callers only use `next(model.parameters()).device` (video_sample.py:155)."""
+        if self._wbuf is None:
+            return iter([th.zeros(1)])
+        return iter([self._wbuf])
+
+    def state_dict(self):
+        if self._host_sd is None:
+            raise RuntimeError("no weights loaded")
+        return OrderedDict(self._host_sd)
+
+    def packed_weights(self):
+        """The single device buffer holding every parameter (for one RCCL broadcast)."""
+        self._ensure_storage()
+        return self._wbuf
+
+    def mark_weights_received(self):
+        _lib.check(_lib.lib().vd_mark_weights_loaded(self._handle))
+
+    # -- forward ---------------------------------------------------------------------------------------
+    def _pack_kwargs(self, x, kw):
+        """model_kwargs of video_sample.py:157-165 -> contiguous device buffers for the C ABI."""
+        B, T = x.shape[:2]
+        dev = x.device
+        mode = kw["observed_frames"]
+        if mode not in _OBS_MODES:
+            raise NotImplementedError(f"observed_frames={mode!r} (training-only option)")
+        src = {"x_0": kw["x0"], "x_t": x, "x_t_minus_1": kw["x_t_minus_1"]}[mode]   # KeyError like unet.py:961
+        f32 = lambda t: t.to(device=dev, dtype=th.float32).contiguous()  # noqa: E731
+        fi = kw.get("frame_indices")
+        if fi is None:
+            fi = th.arange(0, T, device=dev).view(1, T).expand(B, T)                 # unet.py:900-902
+        assert tuple(kw["obs_mask"].shape[:2]) == (B, T)
+        return dict(obs_src=f32(src), obs_mask=f32(kw["obs_mask"]).reshape(B * T),
+                    latent_mask=f32(kw["latent_mask"]).reshape(B * T),
+                    kinda_marg_mask=f32(kw["kinda_marg_mask"]).reshape(B * T),
+                    frame_indices=fi.to(device=dev, dtype=th.int64).contiguous(), obs_mode=_OBS_MODES[mode])
+
+    def __call__(self, x, timesteps, return_attn_weights=False, **kwargs):
+        """model(x, timesteps, **model_kwargs) -> (eps, None)   (unet.py:949-1026)."""
+        if return_attn_weights:
+            raise NotImplementedError("return_attn_weights")
+        if self._wbuf is None:
+            raise RuntimeError("model.to('cuda') first: the HIP engine has no CPU path")
+        B, T, C, H, W = x.shape
+        assert H == self.image_size and W == self.image_size and C == 3
+        xs = x.to(device=self.device, dtype=th.float32).contiguous()
+        kw = self._pack_kwargs(xs, kwargs)
+        tm = timesteps.to(device=self.device, dtype=th.float32).reshape(B).contiguous()
+        eps = th.empty_like(xs)
+        _lib.check(_lib.lib().vd_unet_forward(self._handle, B, T, _lib.ptr(xs), _lib.ptr(kw["obs_src"]),
+                                              _lib.ptr(kw["obs_mask"]), _lib.ptr(kw["latent_mask"]),
+                                              _lib.ptr(kw["kinda_marg_mask"]), _lib.ptr(kw["frame_indices"]),
+                                              _lib.ptr(tm), kw["obs_mode"], _lib.ptr(eps), _lib.current_stream()))
+        return eps, None
+
+    forward = __call__
