@@ -117,6 +117,15 @@ int vd_q_sample(vd_engine* e, int B, long long per_sample, const float* x_start,
 /* th.randn(*shape) replacement on the engine's own counter-based generator. */
 int vd_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream);
 
+/* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg; no
+ * reference counterpart).  Between begin and end every engine launch is bracketed by two events;
+ * vd_profile_end synchronises and writes, per class i, out[4i..4i+3] = {launches, total ms,
+ * algorithmic FLOPs, algorithmic bytes}. */
+int vd_profile_begin(void);
+int vd_profile_end(double* out, int cap);
+int vd_profile_classes(void);
+const char* vd_profile_class_name(int i);
+
 /* ---- single-operator entry points (parity tests call the kernels through these) -------------- */
 /* NHWC conv / linear on fp32 MFMA.  src1/C0: virtual channel concat; affA/affB: folded GroupNorm(+FiLM);
  * act: SiLU on the operand; res: residual in the epilogue; fbias: per-frame bias [nfr][fbias_ld]. */

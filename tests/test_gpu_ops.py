@@ -1,0 +1,283 @@
+"""GPU: every HIP kernel through its C-ABI entry point vs a plain fp32 torch-CPU statement of the
+same operator (reference semantics cited per test), seeded inputs, ragged / edge shapes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import close
+from video_diffusion_amd import _lib
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=1e-4, rtol=1e-4)          # the tier's stated fp32 tolerance
+
+
+def dev(t):
+    return t.to("cuda").contiguous()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def pack_conv(w):                          # OIHW -> [tap][O][I]   (engine layout, include/vd_amd.h)
+    O, I, kh, kw = w.shape
+    return w.permute(2, 3, 0, 1).reshape(kh * kw, O, I).contiguous()
+
+
+def run_conv(x0, x1, w, bias, *, ups=0, stride=1, affA=None, affB=None, act=0, res=None, fbias=None):
+    """x0/x1 NCHW cpu tensors; returns NCHW cpu tensor computed by the HIP kernel."""
+    N, C0, H, W = x0.shape
+    Cin = C0 + (x1.shape[1] if x1 is not None else 0)
+    O, _, k, _ = w.shape
+    pad = 1 if k == 3 else 0
+    Ho = ((H << ups) + 2 * pad - k) // stride + 1
+    out = torch.empty(N, Ho, Ho, O, device="cuda")
+    d = lambda t: None if t is None else dev(t)  # noqa: E731
+    bufs = [dev(nhwc(x0)), d(nhwc(x1)) if x1 is not None else None, dev(pack_conv(w)), d(bias), d(affA), d(affB),
+            d(nhwc(res)) if res is not None else None, d(fbias)]
+    rc = _lib.lib().vd_op_conv(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), C0, Cin, N, H, W, ups, stride, pad, k,
+                               _lib.ptr(bufs[2]), _lib.ptr(bufs[3]), _lib.ptr(bufs[4]), _lib.ptr(bufs[5]), act,
+                               _lib.ptr(bufs[6]), _lib.ptr(bufs[7]), 0 if fbias is None else fbias.shape[1],
+                               _lib.ptr(out), O, _lib.current_stream())
+    _lib.check(rc)
+    torch.cuda.synchronize()
+    return out.permute(0, 3, 1, 2).cpu()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H", [(3, 32, 64, 16), (2, 64, 32, 8), (5, 128, 128, 4), (1, 96, 160, 32),
+                                          (2, 32, 3, 8)])
+def test_conv3x3_plain(N, Cin, Cout, H):
+    x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, scale=(3.0 / (9 * Cin)) ** 0.5), rnd(Cout, scale=0.1)
+    close(run_conv(x, None, w, b), F.conv2d(x, w, b, padding=1), **TOL)
+
+
+def test_conv3x3_fused_norm_film_silu_residual_concat():
+    """ResBlock operand path (unet.py:185-198): conv(silu(x*A+B)) + bias + skip, input = cat([h, skip])."""
+    N, C0, C1, Cout, H = 3, 64, 32, 96, 16
+    h, s = rnd(N, C0, H, H), rnd(N, C1, H, H, seed=1)
+    A, B = rnd(N, C0 + C1, seed=2) + 1.5, rnd(N, C0 + C1, seed=3)
+    w, b, res = rnd(Cout, C0 + C1, 3, 3, scale=0.06), rnd(Cout, scale=0.1), rnd(N, Cout, H, H, seed=4)
+    x = torch.cat([h, s], 1)
+    ref = F.conv2d(F.silu(x * A[:, :, None, None] + B[:, :, None, None]), w, b, padding=1) + res
+    close(run_conv(h, s, w, b, affA=A, affB=B, act=1, res=res), ref, **TOL)
+
+
+def test_conv3x3_upsample_fused():
+    """Upsample (unet.py:63-72): nearest x2 read through the gather, zero padding at the UPSAMPLED border."""
+    x, w, b = rnd(2, 64, 8, 8), rnd(64, 64, 3, 3, scale=0.07), rnd(64, scale=0.1)
+    close(run_conv(x, None, w, b, ups=1), F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1),
+          **TOL)
+
+
+@pytest.mark.parametrize("H", [16, 8, 2])
+def test_conv3x3_stride2(H):
+    """Downsample (unet.py:88-95)."""
+    x, w, b = rnd(3, 32, H, H), rnd(32, 32, 3, 3, scale=0.1), rnd(32, scale=0.1)
+    close(run_conv(x, None, w, b, stride=2), F.conv2d(x, w, b, stride=2, padding=1), **TOL)
+
+
+def test_conv1x1_skip_and_frame_bias():
+    x0, x1 = rnd(2, 64, 8, 8), rnd(2, 64, 8, 8, seed=5)
+    w, b, fb = rnd(96, 128, 1, 1, scale=0.15), rnd(96, scale=0.1), rnd(2, 200, seed=6)
+    ref = F.conv2d(torch.cat([x0, x1], 1), w, b) + fb[:, :96, None, None]
+    close(run_conv(x0, x1, w, b, fbias=fb), ref, **TOL)
+
+
+@pytest.mark.parametrize("M,K,Nout", [(128, 128, 512), (7, 512, 1500), (4099, 96, 288), (33, 32, 40), (300, 1024, 64)])
+def test_linear_ragged(M, K, Nout):
+    """nn.Linear as a 1x1 'convolution' over M rows: M, N not multiples of any tile."""
+    a, w, b = rnd(M, K), rnd(Nout, K, scale=(3.0 / K) ** 0.5), rnd(Nout, scale=0.1)
+    got = run_conv(a.view(M, K, 1, 1), None, w.view(Nout, K, 1, 1), b, act=1).view(M, Nout)
+    close(got, F.linear(F.silu(a), w, b), **TOL)
+
+
+def test_conv_is_deterministic_and_linear_at_scale():
+    """Size-independent properties at a BASELINE-sized layer (N=128 frames, 64x64, 128->128):
+    bit-identical reruns, and linearity conv(a*x) = a*conv(x) - (a-1)*bias."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(128, 64, 64, 128, generator=g, device="cpu").cuda() - 0.5        # already NHWC
+    w = dev(pack_conv(rnd(128, 128, 3, 3, scale=0.03)))
+    b = dev(rnd(128, scale=0.1))
+    outs = []
+    for scale in (1.0, 1.0, 2.0):
+        xs = (x * scale).contiguous()
+        o = torch.empty(128, 64, 64, 128, device="cuda")
+        _lib.check(_lib.lib().vd_op_conv(_lib.ptr(xs), None, 128, 128, 128, 64, 64, 0, 1, 1, 3, _lib.ptr(w), _lib.ptr(b),
+                                         None, None, 0, None, None, 0, _lib.ptr(o), 128, _lib.current_stream()))
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    lin = 2 * outs[0] - b.view(1, 1, 1, -1)
+    assert (outs[2] - lin).abs().max().item() < 1e-5
+
+
+def _gn_fold(x0, x1, gamma, beta, film):
+    N, C0, H, W = x0.shape
+    C = C0 + (x1.shape[1] if x1 is not None else 0)
+    A = torch.empty(N, C, device="cuda")
+    B = torch.empty(N, C, device="cuda")
+    bufs = [dev(nhwc(x0)), dev(nhwc(x1)) if x1 is not None else None, dev(gamma), dev(beta),
+            dev(film) if film is not None else None]
+    _lib.check(_lib.lib().vd_op_gn_fold(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), C0, C, N, H * W, _lib.ptr(bufs[2]),
+                                        _lib.ptr(bufs[3]), _lib.ptr(bufs[4]), 0 if film is None else film.shape[1],
+                                        _lib.ptr(A), _lib.ptr(B), _lib.current_stream()))
+    torch.cuda.synchronize()
+    return A.cpu(), B.cpu()
+
+
+@pytest.mark.parametrize("N,C0,C1,H", [(4, 32, 0, 32), (3, 64, 32, 8), (2, 128, 96, 4), (5, 384, 0, 16), (2, 512, 384, 8),
+                                       (1, 1024, 0, 2)])
+def test_groupnorm_fold(N, C0, C1, H):
+    """GroupNorm32 (nn.py:15-17,80-86) + FiLM (unet.py:190-194) folded to x*A+B; groups may straddle the concat."""
+    C = C0 + C1
+    x0 = rnd(N, C0, H, H) * 2 + 0.7
+    x1 = rnd(N, C1, H, H, seed=7) if C1 else None
+    x = torch.cat([x0, x1], 1) if C1 else x0
+    gamma, beta, film = rnd(C, seed=8) + 1, rnd(C, seed=9), rnd(N, 2 * C + 8, seed=10)
+    A, B = _gn_fold(x0, x1, gamma, beta, film)
+    ref = F.group_norm(x, 32, gamma, beta, eps=1e-5) * (1 + film[:, :C, None, None]) + film[:, C:2 * C, None, None]
+    close(x * A[:, :, None, None] + B[:, :, None, None], ref, atol=2e-5, rtol=2e-5)
+    A2, B2 = _gn_fold(x0, x1, gamma, beta, None)
+    close(x * A2[:, :, None, None] + B2[:, :, None, None], F.group_norm(x, 32, gamma, beta, eps=1e-5), atol=2e-5,
+          rtol=2e-5)
+
+
+def test_groupnorm_fold_large_mean():
+    """fp64 accumulation: a large common offset must not destroy the variance."""
+    x = rnd(2, 64, 16, 16) * 0.01 + 100.0
+    gamma, beta = torch.ones(64), torch.zeros(64)
+    A, B = _gn_fold(x, None, gamma, beta, None)
+    close(x * A[:, :, None, None] + B[:, :, None, None], F.group_norm(x, 32, gamma, beta, eps=1e-5), atol=5e-3,
+          rtol=1e-3)
+
+
+@pytest.mark.parametrize("B,T,HW,C", [(2, 4, 64, 64), (1, 16, 16, 384), (2, 20, 9, 96), (1, 1, 5, 32), (1, 32, 3, 128)])
+def test_groupnorm_temporal(B, T, HW, C):
+    """RPEAttention norm on the (B*HW, C, T) view (unet.py:472-475): statistics over (T x C/32)."""
+    x = rnd(B, T, HW, C) * 1.5 + 0.3
+    gamma, beta = rnd(C, seed=1) + 1, rnd(C, seed=2)
+    y = torch.empty(B, T, HW, C, device="cuda")
+    bufs = [dev(x), dev(gamma), dev(beta)]
+    _lib.check(_lib.lib().vd_op_gn_temporal(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), _lib.ptr(bufs[2]), B, T, HW, C,
+                                            _lib.ptr(y), _lib.current_stream()))
+    torch.cuda.synchronize()
+    ref = F.group_norm(x.permute(0, 2, 3, 1).reshape(B * HW, C, T), 32, gamma, beta, eps=1e-5)
+    close(y.cpu(), ref.view(B, HW, C, T).permute(0, 3, 1, 2), atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("N,L,C,heads", [(3, 256, 64, 4), (2, 64, 128, 4), (2, 100, 384, 4), (1, 16, 32, 4), (2, 257, 512, 4),
+                                         (1, 40, 96, 2)])
+def test_attention_spatial(N, L, C, heads):
+    """softmax(q*s k^T) v per (frame, head) (unet.py:477-489,525-536 with no RPE, no mask); ragged L."""
+    qkv = rnd(N, L, 3 * C) * 2
+    out = torch.empty(N, L, C, device="cuda")
+    buf = dev(qkv)
+    _lib.check(_lib.lib().vd_op_attn_spatial(_lib.ptr(buf), N, L, C, heads, _lib.ptr(out), _lib.current_stream()))
+    torch.cuda.synchronize()
+    Fd = C // heads
+    q, k, v = qkv.view(N, L, 3, heads, Fd).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax((q * Fd ** -0.5) @ k.transpose(-1, -2), -1) @ v).permute(0, 2, 1, 3).reshape(N, L, C)
+    close(out.cpu(), ref, **TOL)
+
+
+def test_attention_spatial_peaked_scores():
+    """Online-softmax rescale path: one key dominates late in the sequence (guide rule: force the rare branch)."""
+    N, L, C, heads = 1, 128, 64, 4
+    qkv = rnd(N, L, 3 * C)
+    qkv[0, 100, C:2 * C] *= 40.0
+    out = torch.empty(N, L, C, device="cuda")
+    buf = dev(qkv)
+    _lib.check(_lib.lib().vd_op_attn_spatial(_lib.ptr(buf), N, L, C, heads, _lib.ptr(out), _lib.current_stream()))
+    torch.cuda.synchronize()
+    Fd = C // heads
+    q, k, v = qkv.view(N, L, 3, heads, Fd).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax((q * Fd ** -0.5) @ k.transpose(-1, -2), -1) @ v).permute(0, 2, 1, 3).reshape(N, L, C)
+    close(out.cpu(), ref, **TOL)
+
+
+@pytest.mark.parametrize("B,T,HW,C,heads,rpe,mask,allow", [(2, 4, 64, 64, 4, True, False, 1), (1, 16, 16, 384, 4, True, True, 1),
+                                                           (2, 20, 9, 96, 4, True, True, 0), (1, 5, 33, 32, 4, False, True, 1),
+                                                           (1, 32, 4, 128, 4, True, False, 1), (1, 1, 7, 32, 2, True, False, 1)])
+def test_attention_temporal(B, T, HW, C, heads, rpe, mask, allow):
+    """unet.py:486-536 + RPE einsums :357-378 + mask rule :511-524."""
+    qkv = rnd(B, T, HW, 3 * C) * 1.5
+    Rk, Rq, Rv = (rnd(B, T, T, C, seed=s) for s in (1, 2, 3))
+    m = None
+    if mask:
+        m = torch.ones(B, T)
+        m[:, T // 2] = 0
+        if T > 2:
+            m[0, 0] = 0
+    out = torch.empty(B, T, HW, C, device="cuda")
+    bufs = [dev(qkv)] + [dev(r) if rpe else None for r in (Rk, Rq, Rv)] + [dev(m) if mask else None]
+    _lib.check(_lib.lib().vd_op_attn_temporal(*[_lib.ptr(b) for b in bufs], B, T, HW, C, heads, allow, _lib.ptr(out),
+                                              _lib.current_stream()))
+    torch.cuda.synchronize()
+    Fd = C // heads
+    scale = Fd ** -0.5
+    x = qkv.permute(0, 2, 1, 3).reshape(B, HW, T, 3, heads, Fd).permute(3, 0, 1, 4, 2, 5)     # t B D H T F
+    q, k, v = x[0] * scale, x[1], x[2]
+    w = q @ k.transpose(-1, -2)
+    if rpe:
+        rk, rq, rv = (r.view(B, T, T, heads, Fd) for r in (Rk, Rq, Rv))
+        w = w + torch.einsum("bdhtf,btshf->bdhts", q, rk)
+        w = w + torch.einsum("bdhtf,btshf->bdhts", k * scale, rq).transpose(-1, -2)
+    if mask:
+        ok = m.view(B, 1, T) * m.view(B, T, 1)
+        if allow:
+            ok = ok + (1 - m.view(B, 1, T)) * (1 - m.view(B, T, 1))
+        else:
+            ok = ok.clone()
+            ok[:, range(T), range(T)] = 1.0
+        w = w - torch.where(ok == 0, torch.tensor(float("inf")), torch.tensor(0.0)).view(B, 1, 1, T, T)
+    a = torch.softmax(w, -1)
+    o = a @ v
+    if rpe:
+        o = o + torch.einsum("bdhts,btshf->bdhtf", a, rv)
+    ref = o.permute(0, 3, 1, 2, 4).reshape(B, T, HW, C)
+    close(out.cpu(), ref, **TOL)
+
+
+@pytest.mark.parametrize("N,H,C", [(2, 32, 32), (3, 16, 128), (1, 20, 64), (2, 4, 32)])
+def test_output_head(N, H, C):
+    """out = conv3x3(silu(GN(h))) to 3 channels, written NCHW (unet.py:744-749,838)."""
+    x = rnd(N, C, H, H)
+    A, B = rnd(N, C, seed=1) + 1.2, rnd(N, C, seed=2)
+    w, b = rnd(3, C, 3, 3, scale=0.1), rnd(3, scale=0.1)
+    out = torch.empty(N, 3, H, H, device="cuda")
+    bufs = [dev(nhwc(x)), dev(A), dev(B), dev(pack_conv(w)), dev(b)]
+    _lib.check(_lib.lib().vd_op_out_conv(*[_lib.ptr(t) for t in bufs], N, H, H, C, 3, _lib.ptr(out),
+                                         _lib.current_stream()))
+    torch.cuda.synchronize()
+    ref = F.conv2d(F.silu(x * A[:, :, None, None] + B[:, :, None, None]), w, b, padding=1)
+    close(out.cpu(), ref, **TOL)
+
+
+def test_affine_apply():
+    x, A, B = rnd(3, 10, 10, 64), rnd(3, 64, seed=1), rnd(3, 64, seed=2)
+    y = torch.empty(3, 10, 10, 64, device="cuda")
+    bufs = [dev(x), dev(A), dev(B)]
+    _lib.check(_lib.lib().vd_op_affine_apply(*[_lib.ptr(t) for t in bufs], 3, 100, 64, _lib.ptr(y), _lib.current_stream()))
+    torch.cuda.synchronize()
+    close(y.cpu(), x * A[:, None, None, :] + B[:, None, None, :], atol=1e-6, rtol=1e-6)
+
+
+def test_randn_moments_and_reproducibility():
+    a = torch.empty(1 << 20, device="cuda")
+    b = torch.empty(1 << 20, device="cuda")
+    L = _lib.lib()
+    _lib.check(L.vd_randn(_lib.ptr(a), a.numel(), 5, 0, _lib.current_stream()))
+    _lib.check(L.vd_randn(_lib.ptr(b), b.numel(), 5, 0, _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3
+    assert abs((a ** 4).mean().item() - 3) < 0.05 and torch.isfinite(a).all()
+    _lib.check(L.vd_randn(_lib.ptr(b), b.numel(), 6, 0, _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert not torch.equal(a, b)

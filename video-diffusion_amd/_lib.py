@@ -78,6 +78,10 @@ SIGNATURES = {
     "vd_posterior_update": (_I, [_P, _I, _I, _L, _P, _P, _P, _I, _F, _P, _U, _U, _P, _P, _P]),
     "vd_q_sample": (_I, [_P, _I, _L, _P, _P, _P, _P, _P]),
     "vd_randn": (_I, [_P, _L, _U, _U, _P]),
+    "vd_profile_begin": (_I, []),
+    "vd_profile_end": (_I, [_P, _I]),
+    "vd_profile_classes": (_I, []),
+    "vd_profile_class_name": (ctypes.c_char_p, [_I]),
     "vd_op_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P]),
     "vd_op_gn_fold": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "vd_op_affine_apply": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),

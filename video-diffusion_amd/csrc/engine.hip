@@ -66,6 +66,39 @@ struct Arena {
     }
 };
 
+// ---- per-class kernel timing with HIP events on the launch stream (bench.py's live roofline figure)
+enum ProfClass { PC_IGEMM_128x128 = 0, PC_IGEMM_128x64, PC_IGEMM_64x128, PC_IGEMM_64x64, PC_GN_STATS, PC_GN_TEMPORAL,
+                 PC_ATTN_SPATIAL, PC_ATTN_TEMPORAL, PC_OUT_CONV, PC_ELEMENTWISE, PC_POSTERIOR, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"igemm_kernel<128,128>", "igemm_kernel<128,64>", "igemm_kernel<64,128>",
+                                           "igemm_kernel<64,64>", "gn_stats", "gn_temporal", "attn_spatial",
+                                           "attn_temporal", "out_conv", "elementwise", "posterior"};
+struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
+struct Profiler {
+    bool on = false;
+    std::vector<ProfRec> recs;
+};
+static Profiler g_prof;
+
+struct ProfScope {
+    hipStream_t st; bool live;
+    ProfScope(int cls, double flops, double bytes, hipStream_t s) : st(s), live(g_prof.on) {
+        if (!live) return;
+        ProfRec r{cls, flops, bytes, nullptr, nullptr};
+        (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, st);
+        g_prof.recs.push_back(r);
+    }
+    ~ProfScope() { if (live) (void)hipEventRecord(g_prof.recs.back().b, st); }
+};
+
+static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
+    const double taps = (double)g.ksz * g.ksz, cin = cin_alg ? cin_alg : g.Cin;
+    const double in_pix = (double)g.nfr * g.Hs * g.Ws;
+    const double bytes = 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout);
+    ProfScope ps(igemm_tile_class(g.M, g.Cout), 2.0 * g.M * g.Cout * cin * taps, bytes, st);
+    return launch_igemm(g, st);
+}
+
 struct FwdIn {
     int B, T;
     const float *x, *obs_src, *obs, *lat, *km, *t_model;
@@ -302,7 +335,7 @@ int vd_engine::linear(const float* a, int M, int K, int, int, int Nout, const fl
     g.w = wptr; g.bias = bptr; g.affA = nullptr; g.affB = nullptr; g.act = act;
     g.res = resid; g.res_ld = Nout; g.fbias = nullptr; g.fbias_ld = 0;
     g.out = out; g.ldo = Nout; g.Cout = Nout; g.M = M;
-    return launch_igemm(g, st);
+    return igemm_p(g, st);
 }
 
 int vd_engine::gn_fold(const float* s0, const float* s1, int C0, int C, int N, int HW, int gw, int gb,
@@ -313,6 +346,7 @@ int vd_engine::gn_fold(const float* s0, const float* s1, int C0, int C, int N, i
     *A = ar.get<float>((size_t)N * C);
     *Bp = ar.get<float>((size_t)N * C);
     if (ar.dry) return 0;
+    ProfScope ps(PC_GN_STATS, 0.0, 4.0 * N * HW * C, st);
     int rc = launch_gn_stats(s0, s1, C0, C, N, HW, part, split, mr, st);
     if (rc) return rc;
     return launch_gn_affine(mr, W(gw), W(gb), film, film_ld, N, C, *A, *Bp, st);
@@ -345,7 +379,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         g.w = W(r.c1w); g.bias = W(r.c1b); g.affA = A1; g.affB = B1; g.act = 1;
         g.out = h; g.ldo = r.cout; g.Cout = r.cout;
         if (!cfg.use_scale_shift_norm) { g.fbias = film; g.fbias_ld = film_total; }    // h + emb_out (unet.py:196)
-        if ((rc = launch_igemm(g, st))) return rc;
+        if ((rc = igemm_p(g, st))) return rc;
     }
     rc = gn_fold(h, nullptr, r.cout, r.cout, N, HW, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr,
                  film_total, st, ar, &A2, &B2);
@@ -356,7 +390,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         if (!ar.dry) {
             IgemmArgs g = conv_args(x0, x1, N, 1, 1, 0);
             g.w = W(r.skw); g.bias = W(r.skb); g.out = sk; g.ldo = r.cout; g.Cout = r.cout;
-            if ((rc = launch_igemm(g, st))) return rc;
+            if ((rc = igemm_p(g, st))) return rc;
         }
         skip = sk;
     } else {
@@ -368,7 +402,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         IgemmArgs g = conv_args(ht, nullptr, N, 3, 1, 0);
         g.w = W(r.c2w); g.bias = W(r.c2b); g.affA = A2; g.affB = B2; g.act = 1;
         g.res = skip; g.res_ld = r.cout; g.out = o; g.ldo = r.cout; g.Cout = r.cout;
-        if ((rc = launch_igemm(g, st))) return rc;
+        if ((rc = igemm_p(g, st))) return rc;
     }
     *out = Tens{o, r.cout, H};
     return 0;
@@ -391,7 +425,9 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
     float* o = ar.get<float>(tok * C);
     float* xt = ar.get<float>(tok * C);
     if (!ar.dry) {
-        if ((rc = launch_gn_temporal(x.p, W(a.tp.normw), W(a.tp.normb), B, T, HW, C, xn, st))) return rc;
+        { ProfScope ps(PC_GN_TEMPORAL, 0.0, 8.0 * tok * C, st);
+          rc = launch_gn_temporal(x.p, W(a.tp.normw), W(a.tp.normb), B, T, HW, C, xn, st); }
+        if (rc) return rc;
         if ((rc = linear(xn, (int)tok, C, 0, 0, 3 * C, W(a.tp.qkvw), W(a.tp.qkvb), 0, nullptr, qkv, st))) return rc;
         for (int i = 0; i < 3; ++i) {
             if (cfg.use_rpe_net) {
@@ -405,7 +441,10 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
         }
         AttnTemporalArgs ta{qkv, R[0], R[1], R[2], amask, o, B, T, HW, C, cfg.num_heads,
                             cfg.allow_interactions_between_padding, scale};
-        if ((rc = launch_attn_temporal(ta, st))) return rc;
+        { const double Fd = C / cfg.num_heads;
+          ProfScope ps(PC_ATTN_TEMPORAL, 10.0 * B * HW * cfg.num_heads * T * T * Fd, 16.0 * tok * C + 12.0 * rrows * C, st);
+          rc = launch_attn_temporal(ta, st); }
+        if (rc) return rc;
         // proj_out + residual on the NORMALISED activations (unet.py:537-538)
         if ((rc = linear(o, (int)tok, C, 0, 0, C, W(a.tp.projw), W(a.tp.projb), 0, xn, xt, st))) return rc;
     }
@@ -417,10 +456,12 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
     float* o2 = ar.get<float>(tok * C);
     float* xs = ar.get<float>(tok * C);
     if (!ar.dry) {
-        if ((rc = launch_affine_apply(xt, A, Bf, N, HW, C, xn2, st))) return rc;
+        { ProfScope ps(PC_ELEMENTWISE, 0.0, 8.0 * tok * C, st); rc = launch_affine_apply(xt, A, Bf, N, HW, C, xn2, st); }
+        if (rc) return rc;
         if ((rc = linear(xn2, (int)tok, C, 0, 0, 3 * C, W(a.sp.qkvw), W(a.sp.qkvb), 0, nullptr, qkv2, st))) return rc;
         AttnSpatialArgs sa{qkv2, o2, N, HW, C, cfg.num_heads, scale};
-        if ((rc = launch_attn_spatial(sa, st))) return rc;
+        { ProfScope ps(PC_ATTN_SPATIAL, 4.0 * N * (double)HW * HW * C, 16.0 * tok * C, st); rc = launch_attn_spatial(sa, st); }
+        if (rc) return rc;
         if ((rc = linear(o2, (int)tok, C, 0, 0, C, W(a.sp.projw), W(a.sp.projb), 0, xn2, xs, st))) return rc;
     }
     *out = Tens{xs, C, H};
@@ -476,7 +517,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
                 float* o = ar.get<float>((size_t)g.M * c.c);
                 if (!ar.dry) {
                     g.w = W(c.w); g.bias = W(c.b); g.out = o; g.ldo = c.c; g.Cout = c.c;
-                    if ((rc = launch_igemm(g, st))) return rc;
+                    if ((rc = igemm_p(g, st, L.type == 0 ? 5 : 0))) return rc;
                 }
                 nxt = Tens{o, c.c, g.Ho};
             }
@@ -510,7 +551,9 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
     if ((rc = gn_fold(h.p, nullptr, h.C, h.C, N, S * S, p_outgw, p_outgb, nullptr, 0, st, ar, &A, &Bf))) return rc;
     if (!ar.dry) {
         VD_REQUIRE(h.H == S && h.C == final_ch, "output head shape");
-        if ((rc = launch_out_conv(h.p, A, Bf, W(p_outw), W(p_outb), N, S, S, h.C, 3, in.eps, st))) return rc;
+        { ProfScope ps(PC_OUT_CONV, 2.0 * N * S * S * h.C * 27.0, 4.0 * N * S * S * (h.C + 3.0), st);
+          rc = launch_out_conv(h.p, A, Bf, W(p_outw), W(p_outb), N, S, S, h.C, 3, in.eps, st); }
+        if (rc) return rc;
     }
     return 0;
 }
@@ -711,6 +754,7 @@ static int sample_impl(vd_engine* e, int mode, int B, int T, const float* x, con
     if ((rc = e->forward(fi, st, ar))) return rc;
     PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
                      mode, eta, seed, offset, sample, xstart};
+    ProfScope ps(PC_POSTERIOR, 0.0, 4.0 * B * per * 5.0, st);
     return launch_posterior(pa, st);
 }
 
@@ -751,6 +795,31 @@ int vd_randn(float* out, long long n, unsigned long long seed, unsigned long lon
     VD_REQUIRE(out && n >= 0, "arguments");
     return launch_randn(out, (long)n, seed, offset, static_cast<hipStream_t>(stream));
 }
+
+int vd_profile_begin(void) {
+    for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.recs.clear();
+    g_prof.on = true;
+    return 0;
+}
+
+int vd_profile_end(double* out, int cap) {
+    g_prof.on = false;
+    VD_REQUIRE(out && cap >= 4 * PC_COUNT, "output needs 4*vd_profile_classes() doubles");
+    for (int i = 0; i < 4 * PC_COUNT; ++i) out[i] = 0.0;
+    for (auto& r : g_prof.recs) {
+        VD_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        VD_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        out[r.cls * 4 + 0] += 1.0; out[r.cls * 4 + 1] += ms; out[r.cls * 4 + 2] += r.flops; out[r.cls * 4 + 3] += r.bytes;
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.recs.clear();
+    return 0;
+}
+
+int vd_profile_classes(void) { return PC_COUNT; }
+const char* vd_profile_class_name(int i) { return i >= 0 && i < PC_COUNT ? kProfNames[i] : ""; }
 
 // ---- single-operator entry points ---------------------------------------------------------------
 int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, int ups, int stride,

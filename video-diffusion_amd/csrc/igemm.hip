@@ -194,15 +194,23 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     VD_REQUIRE(a.ksz == 1 || a.ksz == 3, "kernel size 1 or 3");
     VD_REQUIRE(a.M > 0 && a.Cout > 0, "empty problem");
     VD_REQUIRE(a.M == a.nfr * a.Ho * a.Wo, "M != nfr*Ho*Wo");
-    // Tile choice: big tiles when the grid still fills 256 CUs x 2 blocks, smaller ones otherwise.
-    const long t128 = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-    if (a.Cout <= 64) {
-        return a.M >= 128 * 512 ? launch_t<128, 64>(a, s) : launch_t<64, 64>(a, s);
+    switch (igemm_tile_class(a.M, a.Cout)) {
+        case 0: return launch_t<128, 128>(a, s);
+        case 1: return launch_t<128, 64>(a, s);
+        case 2: return launch_t<64, 128>(a, s);
+        default: return launch_t<64, 64>(a, s);
     }
-    if (t128 >= 512) return launch_t<128, 128>(a, s);
-    const long t64n = (long)((a.M + 63) / 64) * ((a.Cout + 127) / 128);
-    if (t64n >= 384) return launch_t<64, 128>(a, s);
-    return launch_t<64, 64>(a, s);
+}
+
+// Tile choice: big tiles when the grid still fills 256 CUs x 2 blocks, smaller ones otherwise.
+// 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
+int igemm_tile_class(int M, int Cout) {
+    const long t128 = (long)((M + 127) / 128) * ((Cout + 127) / 128);
+    if (Cout <= 64) return M >= 128 * 512 ? 1 : 3;
+    if (t128 >= 512) return 0;
+    const long t64n = (long)((M + 63) / 64) * ((Cout + 127) / 128);
+    if (t64n >= 384) return 2;
+    return 3;
 }
 
 }  // namespace vd

@@ -75,6 +75,7 @@ struct AttnTemporalArgs {
 };
 
 int launch_igemm(const IgemmArgs& a, hipStream_t s);
+int igemm_tile_class(int M, int Cout);   // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
 int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s);
 int launch_attn_temporal(const AttnTemporalArgs& a, hipStream_t s);
 

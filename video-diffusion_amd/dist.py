@@ -1,0 +1,84 @@
+"""One process per GPU, test-set sharding, one weight broadcast.
+
+The reference shards SAMPLING by launching one process per GPU with a `--task_id`
+(command_launchers.py:32-62 -> scripts/video_sample.py:577-582: indices =
+range(task_id*bs, (task_id+1)*bs)); there is no collective in the denoise loop.
+Its only parameter exchange is `sync_params`, one `dist.broadcast` per tensor
+(dist_util.py:139-143).  Here: `torch.distributed` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests), rank r takes tasks r, r+R, ..., and the
+EMA weights travel as ONE packed buffer in a single broadcast.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def task_ids(num_tasks, rank, world):
+    """Tasks (= dataloader batches, video_sample.py:577-582) owned by `rank`: r, r+R, r+2R, ..."""
+    return list(range(rank, num_tasks, world))
+
+
+def indices_for_task(task_id, batch_size, dataset_len=None):
+    """video_sample.py:577-582: the dataset indices of one task."""
+    idx = list(range(task_id * batch_size, (task_id + 1) * batch_size))
+    if dataset_len is not None:
+        idx = [i for i in idx if i < dataset_len]
+    return idx
+
+
+def broadcast_packed(buf, src=0):
+    """One collective for the whole parameter set (464 MB fp32 for the default 64x64 model)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(buf, src=src)
+    return buf
+
+
+def share_weights(model, state_dict_fn, rank):
+    """Rank 0 materialises the state_dict (disk / generator) and uploads it; everyone else receives the
+    engine's packed device buffer over RCCL and marks it loaded."""
+    if rank == 0:
+        model.load_state_dict(state_dict_fn())
+    buf = model.packed_weights()
+    broadcast_packed(buf, src=0)
+    if rank != 0:
+        model.mark_weights_received()
+    return model
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device=None):
+    """Timing reduction of the bench contract: the slowest rank defines the job's time."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
