@@ -194,6 +194,11 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     VD_REQUIRE(a.ksz == 1 || a.ksz == 3, "kernel size 1 or 3");
     VD_REQUIRE(a.M > 0 && a.Cout > 0, "empty problem");
     VD_REQUIRE(a.M == a.nfr * a.Ho * a.Wo, "M != nfr*Ho*Wo");
+    static const bool no_halo = getenv("VD_NO_HALO") != nullptr;     // A/B switch for tools/bench_conv.py
+    if (!no_halo && conv_halo_supported(a)) {
+        const int rc = launch_conv_halo(a, igemm_tile_class(a.M, a.Cout), s);
+        if (rc <= 0) return rc;            // 1: shape not covered by the halo tiling -> generic path below
+    }
     switch (igemm_tile_class(a.M, a.Cout)) {
         case 0: return launch_t<128, 128>(a, s);
         case 1: return launch_t<128, 64>(a, s);

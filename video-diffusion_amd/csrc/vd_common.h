@@ -76,6 +76,9 @@ struct AttnTemporalArgs {
 
 int launch_igemm(const IgemmArgs& a, hipStream_t s);
 int igemm_tile_class(int M, int Cout);   // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
+// 3x3 stride-1 path with an LDS-staged, once-transformed input halo tile (conv_halo.hip)
+bool conv_halo_supported(const IgemmArgs& a);
+int launch_conv_halo(const IgemmArgs& a, int tile_class, hipStream_t s);
 int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s);
 int launch_attn_temporal(const AttnTemporalArgs& a, hipStream_t s);
 
