@@ -1,0 +1,83 @@
+"""CPU, world_size 2 over gloo: the N>1 path of bench.py / the sampling driver -- task sharding, the single
+packed-weight broadcast, barrier and max-over-ranks timing (video-diffusion_amd/dist.py)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from video_diffusion_amd import dist as vdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeModel:
+    """Stands in for the engine handle: what share_weights touches (no GPU in this test)."""
+
+    def __init__(self):
+        self.buf = torch.zeros(1000)
+        self.received = False
+
+    def load_state_dict(self, sd):
+        self.buf.copy_(sd["w"])
+
+    def packed_weights(self):
+        return self.buf
+
+    def mark_weights_received(self):
+        self.received = True
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, lr, w = vdist.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    model = _FakeModel()
+    built = []
+
+    def make_sd():
+        built.append(1)
+        return {"w": torch.arange(1000, dtype=torch.float32) * 0.5}
+
+    vdist.share_weights(model, make_sd, rank)
+    assert torch.equal(model.buf, torch.arange(1000, dtype=torch.float32) * 0.5)
+    assert len(built) == (1 if rank == 0 else 0)            # only rank 0 touches the checkpoint
+    assert model.received == (rank != 0)
+    vdist.barrier()
+    slow = vdist.max_over_ranks(1.0 + rank)                 # the slowest rank defines the job time
+    total = vdist.sum_over_ranks(10.0)
+    tasks = vdist.task_ids(7, rank, world)
+    out.put((rank, slow, total, tasks))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_weight_broadcast():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [2.0, 2.0] and [r[2] for r in res] == [20.0, 20.0]
+    assert res[0][3] == [0, 2, 4, 6] and res[1][3] == [1, 3, 5]
+    assert sorted(res[0][3] + res[1][3]) == list(range(7))   # a partition: nothing dropped, nothing doubled
+
+
+def test_task_to_indices_mapping():
+    """video_sample.py:577-582: indices = range(task_id*bs, (task_id+1)*bs)."""
+    assert vdist.indices_for_task(3, 8) == list(range(24, 32))
+    assert vdist.indices_for_task(3, 8, dataset_len=27) == [24, 25, 26]
+    assert vdist.task_ids(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert vdist.max_over_ranks(3.5) == 3.5                  # single-process fallthrough

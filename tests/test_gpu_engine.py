@@ -212,3 +212,48 @@ def test_baseline_batch_properties():
     one = {k: (v[5:6] if torch.is_tensor(v) else v) for k, v in c.items()}
     s1, _ = diff._step(0, model, one["x"], t[:1], True, None, kwargs_of(one), 0.0, noise[5:6])
     close(a[5:6].cpu(), s1.cpu(), atol=2e-5, rtol=2e-5)
+
+
+def test_infer_video_autoreg_vs_oracle(monkeypatch):
+    """The caller (scripts/video_sample.py:50-190): 4 autoregressive windows x 5 steps, frames written back
+    between windows, against the same loop run on the CPU oracle with the identical noise draws."""
+    from video_diffusion_amd import gaussian_diffusion as gdm
+    from video_diffusion_amd import inference_util as iu
+    from video_diffusion_amd.video_sample import get_masks, infer_video, to_uint8
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=4, rp_beta=4, rp_gamma=4,
+                                                              timestep_respacing="ddim5")}
+    model, diff, ora = _oracle(cfg)
+    B, T, obs_len, max_frames, step = 2, 6, 2, 4, 1
+    g = torch.Generator().manual_seed(4)
+    batch = torch.rand(B, T, 3, 32, 32, generator=g) * 2 - 1
+    draws = []
+    gen = torch.Generator().manual_seed(99)
+
+    def fake_randn_like(x, *a, **k):
+        z = torch.randn(x.shape, generator=gen)
+        draws.append(z)
+        return z.to(x.device)
+
+    monkeypatch.setattr(gdm.th, "randn_like", fake_randn_like)
+    got, _ = infer_video("autoreg", model, diff, batch.cuda(), max_frames, obs_len, step)
+    monkeypatch.undo()
+
+    samples = torch.zeros_like(batch)
+    samples[:, :obs_len] = batch[:, :obs_len]
+    it, k = iter(draws), 0
+    for obs_idx, lat_idx in iu.inference_strategies["autoreg"](video_length=T, num_obs=obs_len, max_frames=max_frames,
+                                                                step_size=step):
+        x0 = torch.cat([samples[:, obs_idx], samples[:, lat_idx]], dim=1).clone()
+        fi = torch.tensor(obs_idx + lat_idx).repeat(B, 1)
+        om, lm, km = get_masks(x0, len(obs_idx))
+        kw = dict(x0=x0, obs_mask=om, latent_mask=lm, kinda_marg_mask=km, frame_indices=fi)
+        local = x0.clone()
+        for ts in range(diff.num_timesteps)[::-1]:
+            local = ora.p_sample(local, torch.tensor([ts] * B), kw, next(it))["sample"]
+        samples[:, lat_idx] = local[:, -len(lat_idx):]
+        k += 1
+    assert k == 4 and len(draws) == 4 * 5
+    close(got, samples.numpy(), atol=1e-3, rtol=1e-3)          # 4 chained windows x 5 stochastic steps
+    assert np.array_equal(got[:, :obs_len], batch[:, :obs_len].numpy())      # observed frames pass through untouched
+    assert to_uint8(got).dtype == np.uint8 and to_uint8(np.array([1.0, -1.0, 0.0])).tolist() == [255, 0, 127]

@@ -1,0 +1,163 @@
+"""Windowed conditional sampling: the caller of the hot path (scripts/video_sample.py:31-47, 50-190,
+266-271 of the reference), driving the HIP engine.
+
+    python -m video_diffusion_amd.video_sample --synthetic --inference_mode autoreg --T 32 \
+        --obs_length 4 --max_frames 10 --step_size 2 --timestep_respacing ddim50 --out_dir /tmp/samples
+
+`infer_video` keeps the reference's contract: `batch` (B, T, C, H, W) in [-1, 1]; the first
+`obs_length` frames are observed; each window starts from `x0.clone()` (observed frames + whatever
+the latent slots currently hold, zeros at first -- SURVEY F5), walks every respaced timestep through
+`diffusion.p_sample`, and writes the last `n_latent` frames back.  One H2D transfer of the window's
+inputs and one D2H of its result per window; nothing crosses the host inside the step loop.
+No datasets or checkpoints ship with the reference: the CLI samples from synthetic
+videos and either a checkpoint given on the command line or the closed-form weights.
+"""
+import argparse
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import inference_util
+from .script_util import (args_to_dict, create_video_model_and_diffusion, str2bool,
+                          video_model_and_diffusion_defaults)
+from .weights_init import synth_param
+
+logger = logging.getLogger("video_sample")
+drange = [-1, 1]
+
+
+def get_masks(x0, num_obs):
+    """video_sample.py:31-47: first `num_obs` frames observed, the rest latent, none kinda-marginal."""
+    obs_mask = torch.zeros_like(x0[:, :, :1, :1, :1])
+    obs_mask[:, :num_obs] = 1
+    latent_mask = 1 - obs_mask
+    kinda_marg_mask = torch.zeros_like(x0[:, :, :1, :1, :1])
+    return obs_mask, latent_mask, kinda_marg_mask
+
+
+@torch.no_grad()
+def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size=1, optimal_schedule_path=None, *,
+                use_gradient_method=False, observed_frames="x_0", sampler="p_sample", eta=0.0):
+    """video_sample.py:50-190 (non-adaptive modes).  Returns (samples ndarray (B,T,C,H,W), None)."""
+    if "adaptive" in mode or "goal-directed" in mode:
+        raise NotImplementedError(f"inference mode {mode!r} needs the LPIPS network (out of scope)")
+    B, T, C, H, W = batch.shape
+    device = model.device
+    samples = torch.zeros_like(batch).cpu()
+    samples[:, :obs_length] = batch[:, :obs_length].cpu()
+    schedule = iter(inference_util.inference_strategies[mode](
+        video_length=T, num_obs=obs_length, max_frames=max_frames, step_size=step_size,
+        optimal_schedule_path=optimal_schedule_path))
+    timesteps = list(range(diffusion.num_timesteps))[::-1]
+    t_tensors = None
+    for obs_frame_indices, latent_frame_indices in schedule:
+        logger.info(f"Conditioning on {sorted(obs_frame_indices)} frames, predicting {sorted(latent_frame_indices)}.")
+        x0 = torch.cat([samples[:, obs_frame_indices], samples[:, latent_frame_indices]], dim=1).clone()
+        frame_indices = torch.cat([torch.tensor(obs_frame_indices, dtype=torch.int64),
+                                   torch.tensor(latent_frame_indices, dtype=torch.int64)], dim=0).repeat((B, 1))
+        obs_mask, latent_mask, kinda_marg_mask = get_masks(x0, len(obs_frame_indices))
+        n_latent = len(latent_frame_indices)
+        x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices = [
+            v.to(device) for v in (x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices)]
+        model_kwargs = dict(frame_indices=frame_indices, x0=x0, obs_mask=obs_mask, latent_mask=latent_mask,
+                            kinda_marg_mask=kinda_marg_mask, x_t_minus_1=x0, observed_frames=observed_frames)
+        if t_tensors is None:          # the reference re-creates this tensor every step (video_sample.py:154-155)
+            t_tensors = [torch.tensor([ts] * B, device=device) for ts in range(diffusion.num_timesteps)]
+        local_samples = x0.clone()
+        for timestep in timesteps:
+            if sampler == "p_sample":
+                local_samples = diffusion.p_sample(model, local_samples, t=t_tensors[timestep], clip_denoised=True,
+                                                   model_kwargs=model_kwargs, return_attn_weights=False,
+                                                   use_gradient_method=use_gradient_method)["sample"]
+            else:
+                local_samples = diffusion.ddim_sample(model, local_samples, t=t_tensors[timestep], clip_denoised=True,
+                                                      model_kwargs=model_kwargs, eta=eta)["sample"]
+        samples[:, latent_frame_indices] = local_samples[:, -n_latent:].cpu()
+    return samples.numpy(), None
+
+
+def to_uint8(recon):
+    """video_sample.py:266-268: ((x+1)/2*255) truncated to uint8."""
+    return ((recon - drange[0]) / (drange[1] - drange[0]) * 255).astype(np.uint8)
+
+
+def save_samples(recon, out_dir, first_index=0, sample_idx=0):
+    """samples/sample_%04d-%d.npy, uint8 (T,3,H,W); existing files are skipped (video_sample.py:231-236,269-271)."""
+    os.makedirs(os.path.join(out_dir, "samples"), exist_ok=True)
+    written = []
+    u8 = to_uint8(recon)
+    for i in range(len(u8)):
+        path = os.path.join(out_dir, "samples", f"sample_{first_index + i:04d}-{sample_idx}.npy")
+        if not os.path.exists(path):
+            np.save(path, u8[i])
+            written.append(path)
+    return written
+
+
+def load_model(args, device):
+    """video_sample.py:547-567: checkpoint dict {'state_dict','config','step'} -> (model, diffusion)."""
+    defaults = video_model_and_diffusion_defaults()
+    if args.checkpoint_path:
+        data = torch.load(args.checkpoint_path, map_location="cpu")
+        cfg = dict(data["config"])
+        cfg.setdefault("enforce_position_invariance", False)      # back-compat fills, video_sample.py:25-28,557-559
+        cfg.setdefault("cond_emb_type", "channel")
+        state_dict = data["state_dict"]
+    else:
+        cfg = dict(defaults, T=args.max_frames, image_size=args.image_size, num_channels=args.num_channels,
+                   num_res_blocks=args.num_res_blocks, rp_alpha=args.max_frames, rp_beta=args.max_frames,
+                   rp_gamma=args.max_frames)
+        state_dict = None
+    cfg["timestep_respacing"] = args.timestep_respacing
+    ns = argparse.Namespace(**cfg)
+    model, diffusion = create_video_model_and_diffusion(**args_to_dict(ns, defaults.keys()))
+    if state_dict is None:
+        state_dict = {k: torch.from_numpy(synth_param(k, s)) for k, s in model.param_specs()}
+    model.load_state_dict(state_dict)
+    model.to(device)
+    model.eval()
+    return model, diffusion
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("checkpoint_path", nargs="?", default="")
+    ap.add_argument("--synthetic", type=str2bool, nargs="?", const=True, default=True)
+    ap.add_argument("--inference_mode", default="autoreg", choices=sorted(inference_util.inference_strategies))
+    ap.add_argument("--T", type=int, default=16, help="video length")
+    ap.add_argument("--max_frames", type=int, default=10)
+    ap.add_argument("--obs_length", type=int, default=4)
+    ap.add_argument("--step_size", type=int, default=1)
+    ap.add_argument("--batch_size", type=int, default=2)
+    ap.add_argument("--num_videos", type=int, default=2)
+    ap.add_argument("--timestep_respacing", default="ddim50")
+    ap.add_argument("--observed_frames", default="x_0")
+    ap.add_argument("--image_size", type=int, default=64)
+    ap.add_argument("--num_channels", type=int, default=128)
+    ap.add_argument("--num_res_blocks", type=int, default=2)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out_dir", default="results/synthetic")
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO)
+    from . import dist as vdist
+    rank, local_rank, world = vdist.init()
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    torch.manual_seed(args.seed + rank)
+    model, diffusion = load_model(args, device)
+    n_tasks = (args.num_videos + args.batch_size - 1) // args.batch_size
+    for task in vdist.task_ids(n_tasks, rank, world):                       # video_sample.py:577-582
+        idx = vdist.indices_for_task(task, args.batch_size, args.num_videos)
+        g = torch.Generator().manual_seed(1234 + task)
+        batch = torch.rand(len(idx), args.T, 3, args.image_size, args.image_size, generator=g) * 2 - 1
+        recon, _ = infer_video(args.inference_mode, model, diffusion, batch, args.max_frames, args.obs_length,
+                               args.step_size, observed_frames=args.observed_frames)
+        for p in save_samples(recon, args.out_dir, first_index=idx[0]):
+            logger.info(f"*** Saved {p} ***")
+    vdist.barrier()
+
+
+if __name__ == "__main__":
+    main()
