@@ -190,7 +190,7 @@ def main():
     if not args.no_roofline:
         classes = profile_step(stepper, order[0])
         if rank == 0:
-            name = max((k for k in classes if k.startswith("igemm")), key=lambda k: classes[k]["ms"])
+            name = max((k for k in classes if k.startswith(("igemm", "conv3x3"))), key=lambda k: classes[k]["ms"])
             c = classes[name]
             achieved = c["gflop"] / c["ms"]                                   # GFLOP/ms = TFLOP/s
             traffic = None

@@ -129,9 +129,15 @@ const char* vd_profile_class_name(int i);
 /* ---- single-operator entry points (parity tests call the kernels through these) -------------- */
 /* NHWC conv / linear on fp32 MFMA.  src1/C0: virtual channel concat; affA/affB: folded GroupNorm(+FiLM);
  * act: SiLU on the operand; res: residual in the epilogue; fbias: per-frame bias [nfr][fbias_ld]. */
+/* w_packed: [tap][Cout][Cin] (generic kernel; may be NULL when w_frag covers the shape);
+ * w_frag: MFMA-fragment-major 3x3 weights from vd_pack_conv3_frag (3x3 stride-1, >= 8x8, Cout % 32 == 0), or NULL. */
 int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, int ups, int stride,
-               int pad, int ksz, const float* w_packed, const float* bias, const float* affA, const float* affB,
-               int act, const float* res, const float* fbias, int fbias_ld, float* out, int Cout, void* stream);
+               int pad, int ksz, const float* w_packed, const float* w_frag, const float* bias, const float* affA,
+               const float* affB, int act, const float* res, const float* fbias, int fbias_ld, float* out, int Cout,
+               void* stream);
+/* Host repack OIHW (O, I multiples of 32) -> [tap][I/32][O/32][kgroup 4][lane 64][4]: lane 32h+r of k-group kg holds
+ * w[co = 32*blk + r][ci = 32*chunk + 8*kg + 4*h + e]; one coalesced 1 KiB load per wave per MFMA k-group. */
+int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I);
 /* GroupNorm32 statistics folded to y = x*A + B per (frame, channel); film ([nfr][2C] scale|shift) optional. */
 int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, int HW, const float* gamma,
                   const float* beta, const float* film, int film_ld, float* affA, float* affB, void* stream);

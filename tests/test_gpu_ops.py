@@ -25,7 +25,19 @@ def pack_conv(w):                          # OIHW -> [tap][O][I]   (engine layou
     return w.permute(2, 3, 0, 1).reshape(kh * kw, O, I).contiguous()
 
 
-def run_conv(x0, x1, w, bias, *, ups=0, stride=1, affA=None, affB=None, act=0, res=None, fbias=None):
+def pack_frag(w):
+    """OIHW -> MFMA-fragment-major [tap][I/32][O/32][4][64][4] through the library's own host packer."""
+    O, I = w.shape[:2]
+    src = w.contiguous().float()
+    out = torch.empty(9 * O * I)
+    _lib.check(_lib.lib().vd_pack_conv3_frag(_lib.ptr(src), _lib.ptr(out), O, I))
+    # the layout is a pure permutation: check it against the closed form once
+    ref = w.permute(2, 3, 0, 1).reshape(9, O // 32, 32, I // 32, 4, 2, 4).permute(0, 3, 1, 4, 5, 2, 6).reshape(-1)
+    assert torch.equal(out, ref)
+    return out
+
+
+def run_conv(x0, x1, w, bias, *, ups=0, stride=1, affA=None, affB=None, act=0, res=None, fbias=None, generic=False):
     """x0/x1 NCHW cpu tensors; returns NCHW cpu tensor computed by the HIP kernel."""
     N, C0, H, W = x0.shape
     Cin = C0 + (x1.shape[1] if x1 is not None else 0)
@@ -36,8 +48,9 @@ def run_conv(x0, x1, w, bias, *, ups=0, stride=1, affA=None, affB=None, act=0, r
     d = lambda t: None if t is None else dev(t)  # noqa: E731
     bufs = [dev(nhwc(x0)), d(nhwc(x1)) if x1 is not None else None, dev(pack_conv(w)), d(bias), d(affA), d(affB),
             d(nhwc(res)) if res is not None else None, d(fbias)]
+    wfrag = dev(pack_frag(w)) if (k == 3 and O % 32 == 0 and Cin % 32 == 0 and not generic) else None
     rc = _lib.lib().vd_op_conv(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), C0, Cin, N, H, W, ups, stride, pad, k,
-                               _lib.ptr(bufs[2]), _lib.ptr(bufs[3]), _lib.ptr(bufs[4]), _lib.ptr(bufs[5]), act,
+                               _lib.ptr(bufs[2]), _lib.ptr(wfrag), _lib.ptr(bufs[3]), _lib.ptr(bufs[4]), _lib.ptr(bufs[5]), act,
                                _lib.ptr(bufs[6]), _lib.ptr(bufs[7]), 0 if fbias is None else fbias.shape[1],
                                _lib.ptr(out), O, _lib.current_stream())
     _lib.check(rc)
@@ -54,7 +67,9 @@ def rnd(*shape, seed=0, scale=1.0):
                                           (2, 32, 3, 8)])
 def test_conv3x3_plain(N, Cin, Cout, H):
     x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, scale=(3.0 / (9 * Cin)) ** 0.5), rnd(Cout, scale=0.1)
-    close(run_conv(x, None, w, b), F.conv2d(x, w, b, padding=1), **TOL)
+    ref = F.conv2d(x, w, b, padding=1)
+    close(run_conv(x, None, w, b), ref, **TOL)                       # halo kernel where the shape allows
+    close(run_conv(x, None, w, b, generic=True), ref, **TOL)         # generic per-tap kernel
 
 
 def test_conv3x3_fused_norm_film_silu_residual_concat():
@@ -102,19 +117,23 @@ def test_conv_is_deterministic_and_linear_at_scale():
     bit-identical reruns, and linearity conv(a*x) = a*conv(x) - (a-1)*bias."""
     g = torch.Generator().manual_seed(3)
     x = torch.rand(128, 64, 64, 128, generator=g, device="cpu").cuda() - 0.5        # already NHWC
-    w = dev(pack_conv(rnd(128, 128, 3, 3, scale=0.03)))
+    w_oihw = rnd(128, 128, 3, 3, scale=0.03)
+    w, wf = dev(pack_conv(w_oihw)), dev(pack_frag(w_oihw))
     b = dev(rnd(128, scale=0.1))
     outs = []
-    for scale in (1.0, 1.0, 2.0):
+    for scale, frag in ((1.0, wf), (1.0, wf), (2.0, wf), (1.0, None)):
         xs = (x * scale).contiguous()
         o = torch.empty(128, 64, 64, 128, device="cuda")
-        _lib.check(_lib.lib().vd_op_conv(_lib.ptr(xs), None, 128, 128, 128, 64, 64, 0, 1, 1, 3, _lib.ptr(w), _lib.ptr(b),
-                                         None, None, 0, None, None, 0, _lib.ptr(o), 128, _lib.current_stream()))
+        _lib.check(_lib.lib().vd_op_conv(_lib.ptr(xs), None, 128, 128, 128, 64, 64, 0, 1, 1, 3, _lib.ptr(w), _lib.ptr(frag),
+                                         _lib.ptr(b), None, None, 0, None, None, 0, _lib.ptr(o), 128,
+                                         _lib.current_stream()))
         outs.append(o)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1])
     lin = 2 * outs[0] - b.view(1, 1, 1, -1)
     assert (outs[2] - lin).abs().max().item() < 1e-5
+    # the halo/fragment kernel and the generic per-tap kernel are two implementations of the same sum
+    assert (outs[0] - outs[3]).abs().max().item() < 2e-5
 
 
 def _gn_fold(x0, x1, gamma, beta, film):

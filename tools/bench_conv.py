@@ -52,10 +52,14 @@ def main():
         out = torch.empty(nfr, Ho, Ho, Cout, device="cuda")
         res = torch.rand(nfr, Ho, Ho, Cout, device="cuda", generator=g) if pro and k == 3 else None
 
+        wf = None
+        if k == 3 and stride == 1 and not os.environ.get("VD_NO_HALO"):
+            wf = torch.rand(9 * Cout * Cin, device="cuda", generator=g) * 0.05     # timing only: any values
+
         def run():
             _lib.check(L.vd_op_conv(_lib.ptr(x0), _lib.ptr(x1), C0, Cin, nfr, H, H, ups, stride, pad, k, _lib.ptr(w),
-                                    _lib.ptr(b), _lib.ptr(A), _lib.ptr(B), pro, _lib.ptr(res), None, 0, _lib.ptr(out),
-                                    Cout, _lib.current_stream()))
+                                    _lib.ptr(wf), _lib.ptr(b), _lib.ptr(A), _lib.ptr(B), pro, _lib.ptr(res), None, 0,
+                                    _lib.ptr(out), Cout, _lib.current_stream()))
         run()
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

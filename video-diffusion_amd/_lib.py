@@ -82,7 +82,8 @@ SIGNATURES = {
     "vd_profile_end": (_I, [_P, _I]),
     "vd_profile_classes": (_I, []),
     "vd_profile_class_name": (ctypes.c_char_p, [_I]),
-    "vd_op_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P]),
+    "vd_op_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P]),
+    "vd_pack_conv3_frag": (_I, [_P, _P, _I, _I]),
     "vd_op_gn_fold": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "vd_op_affine_apply": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "vd_op_gn_temporal": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
@@ -98,8 +99,11 @@ def lib():
     """The loaded library with argtypes set; builds it on first use if the .so is missing/stale."""
     global _lib
     if _lib is None:
-        build()
-        L = ctypes.CDLL(SO_PATH)
+        path = os.environ.get("VD_LIB")            # kernel-experiment builds (tools/); default: the in-tree library
+        if not path:
+            build()
+            path = SO_PATH
+        L = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

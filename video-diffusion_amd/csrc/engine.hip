@@ -23,7 +23,8 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 
 int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hipStream_t s);
 
-enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV };
+enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_CONV3F };   // CONV3F: MFMA-fragment-major (conv_halo.hip)
+void pack_conv3_frag(const float* oihw, float* out, int O, int I);
 
 struct Param {
     std::string name;
@@ -68,10 +69,13 @@ struct Arena {
 
 // ---- per-class kernel timing with HIP events on the launch stream (bench.py's live roofline figure)
 enum ProfClass { PC_IGEMM_128x128 = 0, PC_IGEMM_128x64, PC_IGEMM_64x128, PC_IGEMM_64x64, PC_GN_STATS, PC_GN_TEMPORAL,
-                 PC_ATTN_SPATIAL, PC_ATTN_TEMPORAL, PC_OUT_CONV, PC_ELEMENTWISE, PC_POSTERIOR, PC_COUNT };
+                 PC_ATTN_SPATIAL, PC_ATTN_TEMPORAL, PC_OUT_CONV, PC_ELEMENTWISE, PC_POSTERIOR,
+                 PC_CONV_128x128, PC_CONV_128x64, PC_CONV_64x128, PC_CONV_64x64, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"igemm_kernel<128,128>", "igemm_kernel<128,64>", "igemm_kernel<64,128>",
                                            "igemm_kernel<64,64>", "gn_stats", "gn_temporal", "attn_spatial",
-                                           "attn_temporal", "out_conv", "elementwise", "posterior"};
+                                           "attn_temporal", "out_conv", "elementwise", "posterior",
+                                           "conv3x3_frag_kernel<128,128>", "conv3x3_frag_kernel<128,64>",
+                                           "conv3x3_frag_kernel<64,128>", "conv3x3_frag_kernel<64,64>"};
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
 struct Profiler {
     bool on = false;
@@ -95,7 +99,8 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     const double taps = (double)g.ksz * g.ksz, cin = cin_alg ? cin_alg : g.Cin;
     const double in_pix = (double)g.nfr * g.Hs * g.Ws;
     const double bytes = 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout);
-    ProfScope ps(igemm_tile_class(g.M, g.Cout), 2.0 * g.M * g.Cout * cin * taps, bytes, st);
+    const int cls = igemm_tile_class(g.M, g.Cout) + (conv_halo_supported(g) ? (int)PC_CONV_128x128 : 0);
+    ProfScope ps(cls, 2.0 * g.M * g.Cout * cin * taps, bytes, st);
     return launch_igemm(g, st);
 }
 
@@ -144,6 +149,9 @@ struct vd_engine {
     }
 
     const float* W(int p) const { return wbuf + params[p].off; }
+    void set_w(vd::IgemmArgs& g, int p) const {
+        if (params[p].kind == PK_CONV3F) { g.wfrag = W(p); g.w = nullptr; } else { g.w = W(p); g.wfrag = nullptr; }
+    }
 
     int add(const std::string& name, std::initializer_list<long long> shape, int kind = PK_RAW) {
         Param p;
@@ -195,14 +203,16 @@ int vd_engine::build() {
     p_te0w = add("time_embed.0.weight", {E, mc}); p_te0b = add("time_embed.0.bias", {E});
     p_te2w = add("time_embed.2.weight", {E, E}); p_te2b = add("time_embed.2.bias", {E});
 
-    auto add_res = [&](const std::string& pre, int cin, int cout) {
+    // 3x3 stride-1 convs at >= 8x8 run on the halo kernel and store their weights fragment-major
+    auto k3 = [&](int res_out, int cout) { return res_out >= 8 && cout % 32 == 0 ? PK_CONV3F : PK_CONV3; };
+    auto add_res = [&](const std::string& pre, int cin, int cout, int rs) {
         ResP r; r.cin = cin; r.cout = cout;
         r.gn1w = add(pre + ".in_layers.0.weight", {cin}); r.gn1b = add(pre + ".in_layers.0.bias", {cin});
-        r.c1w = add(pre + ".in_layers.2.weight", {cout, cin, 3, 3}, PK_CONV3); r.c1b = add(pre + ".in_layers.2.bias", {cout});
+        r.c1w = add(pre + ".in_layers.2.weight", {cout, cin, 3, 3}, k3(rs, cout)); r.c1b = add(pre + ".in_layers.2.bias", {cout});
         const int eo = cfg.use_scale_shift_norm ? 2 * cout : cout;
         r.embw = add(pre + ".emb_layers.1.weight", {eo, E}); r.embb = add(pre + ".emb_layers.1.bias", {eo});
         r.gn2w = add(pre + ".out_layers.0.weight", {cout}); r.gn2b = add(pre + ".out_layers.0.bias", {cout});
-        r.c2w = add(pre + ".out_layers.3.weight", {cout, cout, 3, 3}, PK_CONV3); r.c2b = add(pre + ".out_layers.3.bias", {cout});
+        r.c2w = add(pre + ".out_layers.3.weight", {cout, cout, 3, 3}, k3(rs, cout)); r.c2b = add(pre + ".out_layers.3.bias", {cout});
         if (cin != cout) {
             r.skw = add(pre + ".skip_connection.weight", {cout, cin, 1, 1}); r.skb = add(pre + ".skip_connection.bias", {cout});
         }
@@ -255,7 +265,7 @@ int vd_engine::build() {
             if (in_att(ds) && n_before_attn < 0) { n_before_attn = (int)input_blocks.size(); first_ds = ds; first_ch = ch; }
             const std::string pre = "input_blocks." + std::to_string(input_blocks.size());
             std::vector<Layer> blk;
-            int ri = add_res(pre + ".0", ch, mult[lvl] * mc);
+            int ri = add_res(pre + ".0", ch, mult[lvl] * mc, cfg.image_size / ds);
             blk.push_back(Layer{1, ri});
             ch = mult[lvl] * mc;
             if (in_att(ds)) { int ai = add_attn(pre + ".1", ch); if (ai < 0) return ai; blk.push_back(Layer{2, ai}); }
@@ -277,9 +287,9 @@ int vd_engine::build() {
         p.numel = p.packed = (size_t)pos_ch * pos_res * pos_res;
     }
     {
-        int r0 = add_res("middle_block.0", ch, ch);
+        int r0 = add_res("middle_block.0", ch, ch, cfg.image_size / ds);
         int a0 = add_attn("middle_block.1", ch); if (a0 < 0) return a0;
-        int r1 = add_res("middle_block.2", ch, ch);
+        int r1 = add_res("middle_block.2", ch, ch, cfg.image_size / ds);
         middle = {Layer{1, r0}, Layer{2, a0}, Layer{1, r1}};
     }
     for (int lvl = nlev - 1; lvl >= 0; --lvl) {
@@ -287,12 +297,12 @@ int vd_engine::build() {
             const std::string pre = "output_blocks." + std::to_string(output_blocks.size());
             std::vector<Layer> blk;
             const int skip = chans.back(); chans.pop_back();
-            blk.push_back(Layer{1, add_res(pre + ".0", ch + skip, mc * mult[lvl])});
+            blk.push_back(Layer{1, add_res(pre + ".0", ch + skip, mc * mult[lvl], cfg.image_size / ds)});
             ch = mc * mult[lvl];
             int li = 1;
             if (in_att(ds)) { int ai = add_attn(pre + "." + std::to_string(li++), ch); if (ai < 0) return ai; blk.push_back(Layer{2, ai}); }
             if (lvl && i == nrb) {
-                blk.push_back(Layer{4, add_conv(pre + "." + std::to_string(li++) + ".conv", ch, ch, PK_CONV3)});
+                blk.push_back(Layer{4, add_conv(pre + "." + std::to_string(li++) + ".conv", ch, ch, k3(2 * cfg.image_size / ds, ch))});
                 ds /= 2;
             }
             output_blocks.push_back(blk);
@@ -376,7 +386,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     const float* film = film_all + r.film_off;
     if (!ar.dry) {
         IgemmArgs g = conv_args(x0, x1, N, 3, 1, 0);
-        g.w = W(r.c1w); g.bias = W(r.c1b); g.affA = A1; g.affB = B1; g.act = 1;
+        set_w(g, r.c1w); g.bias = W(r.c1b); g.affA = A1; g.affB = B1; g.act = 1;
         g.out = h; g.ldo = r.cout; g.Cout = r.cout;
         if (!cfg.use_scale_shift_norm) { g.fbias = film; g.fbias_ld = film_total; }    // h + emb_out (unet.py:196)
         if ((rc = igemm_p(g, st))) return rc;
@@ -400,7 +410,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     if (!ar.dry) {
         Tens ht{h, r.cout, H};
         IgemmArgs g = conv_args(ht, nullptr, N, 3, 1, 0);
-        g.w = W(r.c2w); g.bias = W(r.c2b); g.affA = A2; g.affB = B2; g.act = 1;
+        set_w(g, r.c2w); g.bias = W(r.c2b); g.affA = A2; g.affB = B2; g.act = 1;
         g.res = skip; g.res_ld = r.cout; g.out = o; g.ldo = r.cout; g.Cout = r.cout;
         if ((rc = igemm_p(g, st))) return rc;
     }
@@ -516,7 +526,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
                 IgemmArgs g = conv_args(cur, nullptr, N, 3, stride, ups);
                 float* o = ar.get<float>((size_t)g.M * c.c);
                 if (!ar.dry) {
-                    g.w = W(c.w); g.bias = W(c.b); g.out = o; g.ldo = c.c; g.Cout = c.c;
+                    set_w(g, c.w); g.bias = W(c.b); g.out = o; g.ldo = c.c; g.Cout = c.c;
                     if ((rc = igemm_p(g, st, L.type == 0 ? 5 : 0))) return rc;
                 }
                 nxt = Tens{o, c.c, g.Ho};
@@ -623,7 +633,11 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
     }
     std::vector<float> tmp;
     const float* src = host;
-    if (p.kind == PK_CONV3 || p.kind == PK_OUTCONV || p.kind == PK_STEM) {
+    if (p.kind == PK_CONV3F) {
+        tmp.resize(p.numel);
+        pack_conv3_frag(host, tmp.data(), (int)p.shape[0], (int)p.shape[1]);
+        src = tmp.data();
+    } else if (p.kind == PK_CONV3 || p.kind == PK_OUTCONV || p.kind == PK_STEM) {
         const int O = (int)p.shape[0], I = (int)p.shape[1];
         const int Ip = p.kind == PK_STEM ? STEM_CPAD : I;
         tmp.assign((size_t)9 * O * Ip, 0.f);
@@ -796,6 +810,12 @@ int vd_randn(float* out, long long n, unsigned long long seed, unsigned long lon
     return launch_randn(out, (long)n, seed, offset, static_cast<hipStream_t>(stream));
 }
 
+int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I) {
+    VD_REQUIRE(host_oihw && host_out && O % 32 == 0 && I % 32 == 0, "O and I multiples of 32");
+    pack_conv3_frag(host_oihw, host_out, O, I);
+    return 0;
+}
+
 int vd_profile_begin(void) {
     for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.recs.clear();
@@ -823,14 +843,14 @@ const char* vd_profile_class_name(int i) { return i >= 0 && i < PC_COUNT ? kProf
 
 // ---- single-operator entry points ---------------------------------------------------------------
 int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, int ups, int stride,
-               int pad, int ksz, const float* w, const float* bias, const float* affA, const float* affB, int act,
+               int pad, int ksz, const float* w, const float* w_frag, const float* bias, const float* affA, const float* affB, int act,
                const float* res, const float* fbias, int fbias_ld, float* out, int Cout, void* stream) {
     IgemmArgs g{};
     g.src0 = src0; g.src1 = src1; g.C0 = C0; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws; g.ups = ups;
     g.stride = stride; g.pad = pad; g.ksz = ksz;
     g.Ho = ((Hs << ups) + 2 * pad - ksz) / stride + 1;
     g.Wo = ((Ws << ups) + 2 * pad - ksz) / stride + 1;
-    g.w = w; g.bias = bias; g.affA = affA; g.affB = affB; g.act = act; g.res = res; g.res_ld = Cout;
+    g.w = w; g.wfrag = w_frag; g.bias = bias; g.affA = affA; g.affB = affB; g.act = act; g.res = res; g.res_ld = Cout;
     g.fbias = fbias; g.fbias_ld = fbias_ld; g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
     return launch_igemm(g, static_cast<hipStream_t>(stream));
 }

@@ -71,20 +71,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             int iy = py[j] + kh, ix = px[j] + kw;
-            bool ok = pn[j] >= 0 && iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
-            if (ok) {
-                size_t pix = ((size_t)pn[j] * a.Hs + (iy >> a.ups)) * a.Ws + (ix >> a.ups);
-                ra[j] = *reinterpret_cast<const f32x4*>(base + pix * ld + cc);
-                avalid |= 1u << j;
-            } else {
-                ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            const bool ok = pn[j] >= 0 && iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+            // unconditional load (out-of-image taps read pixel 0 and are zeroed when staged): a branch around a
+            // load makes hipcc drain the whole queue (vmcnt(0)) at the join
+            const size_t pix = ok ? ((size_t)pn[j] * a.Hs + (iy >> a.ups)) * a.Ws + (ix >> a.ups) : 0;
+            ra[j] = *reinterpret_cast<const f32x4*>(base + pix * ld + cc);
+            avalid |= (ok ? 1u : 0u) << j;
         }
         const float* wt = a.w + ((size_t)tap * a.Cout) * a.Cin + c;
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
-            int co = n0 + lrow + 32 * j;
-            rb[j] = co < a.Cout ? *reinterpret_cast<const f32x4*>(wt + (size_t)co * a.Cin) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int co = min(n0 + lrow + 32 * j, a.Cout - 1);       // rows past Cout: duplicates, masked at the store
+            rb[j] = *reinterpret_cast<const f32x4*>(wt + (size_t)co * a.Cin);
         }
     };
 
@@ -96,14 +94,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             f32x4 v = ra[j];
-            if (avalid & (1u << j)) {     // zero padding is applied AFTER norm+activation (conv pads its input)
-                if (a.affA) {
-                    const f32x4 sa = *reinterpret_cast<const f32x4*>(a.affA + (size_t)pn[j] * a.Cin + c);
-                    const f32x4 sb = *reinterpret_cast<const f32x4*>(a.affB + (size_t)pn[j] * a.Cin + c);
-                    v = v * sa + sb;
-                }
-                if (a.act) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            if (a.affA) {
+                const size_t fr = (size_t)max(pn[j], 0) * a.Cin + c;
+                const f32x4 sa = *reinterpret_cast<const f32x4*>(a.affA + fr);
+                const f32x4 sb = *reinterpret_cast<const f32x4*>(a.affB + fr);
+                v = v * sa + sb;
             }
+            if (a.act) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            if (!(avalid & (1u << j))) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding AFTER norm+activation (conv pads its input)
             *reinterpret_cast<f32x4*>(Ad + (lrow + 32 * j) * LDP + lq * 4) = v;
         }
 #pragma unroll
@@ -158,15 +156,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            // residual loads batched ahead of the stores (unconditional, row clamped): one wait per tile
+            // instead of one drained L2 round trip per element
+            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
+            f32x16 v = acc[i][j];
+            if (a.res) {
+                f32x16 rv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rv[r] = a.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), a.M - 1) * a.res_ld + co];
+                v += rv;
+            }
+            if (a.fbias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    v[r] += a.fbias[(size_t)(min(mb + (r & 3) + 8 * (r >> 2), a.M - 1) / HWo) * a.fbias_ld + co];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < a.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (a.res) v += a.res[(size_t)m * a.res_ld + co];
-                    if (a.fbias) v += a.fbias[(size_t)(m / HWo) * a.fbias_ld + co];
-                    a.out[(size_t)m * a.ldo + co] = v;
-                }
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < a.M) a.out[(size_t)m * a.ldo + co] = v[r] + bv;
             }
         }
     }
@@ -199,6 +208,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
         const int rc = launch_conv_halo(a, igemm_tile_class(a.M, a.Cout), s);
         if (rc <= 0) return rc;            // 1: shape not covered by the halo tiling -> generic path below
     }
+    VD_REQUIRE(a.w != nullptr, "this shape runs on the generic kernel and needs [tap][Cout][Cin] weights");
     switch (igemm_tile_class(a.M, a.Cout)) {
         case 0: return launch_t<128, 128>(a, s);
         case 1: return launch_t<128, 64>(a, s);
@@ -210,6 +220,8 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
 // Tile choice: big tiles when the grid still fills 256 CUs x 2 blocks, smaller ones otherwise.
 // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
 int igemm_tile_class(int M, int Cout) {
+    static const char* force = getenv("VD_TILE");          // experiment switch for tools/bench_conv.py
+    if (force) return atoi(force);
     const long t128 = (long)((M + 127) / 128) * ((Cout + 127) / 128);
     if (Cout <= 64) return M >= 128 * 512 ? 1 : 3;
     if (t128 >= 512) return 0;

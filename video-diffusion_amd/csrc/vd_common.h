@@ -41,7 +41,8 @@ struct IgemmArgs {
     int ups;             // 1: source is read through a nearest x2 upsample (unet.py:69)
     int stride, pad, ksz;
     int Ho, Wo;
-    const float* w;      // [ksz*ksz][Cout][Cin]
+    const float* w;      // [ksz*ksz][Cout][Cin]           (generic kernel)
+    const float* wfrag;  // [tap][Cin/32][Cout/32][4][64][4] fragment-major (3x3 halo kernel), or null
     const float* bias;   // [Cout] or null
     const float* affA;   // [nfr][Cin] per-frame per-channel scale  (GroupNorm/FiLM folded), or null
     const float* affB;   // [nfr][Cin] shift
