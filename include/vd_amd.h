@@ -138,6 +138,9 @@ int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, i
 /* Host repack OIHW (O, I multiples of 32) -> [tap][I/32][O/32][kgroup 4][lane 64][4]: lane 32h+r of k-group kg holds
  * w[co = 32*blk + r][ci = 32*chunk + 8*kg + 4*h + e]; one coalesced 1 KiB load per wave per MFMA k-group. */
 int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I);
+/* Same for an nn.Linear / 1x1-conv weight [N][K] (N, K multiples of 32) -> [K/32][N/32][4][64][4]; pass the result as
+ * w_frag with ksz = 1. */
+int vd_pack_linear_frag(const float* host_w, float* host_out, int N, int K);
 /* GroupNorm32 statistics folded to y = x*A + B per (frame, channel); film ([nfr][2C] scale|shift) optional. */
 int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, int HW, const float* gamma,
                   const float* beta, const float* film, int film_ld, float* affA, float* affB, void* stream);

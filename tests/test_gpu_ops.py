@@ -37,6 +37,17 @@ def pack_frag(w):
     return out
 
 
+def pack_lin_frag(w):
+    """[N][K] -> [K/32][N/32][4][64][4] through the library's host packer (+ closed-form check)."""
+    N, K = w.shape
+    src = w.contiguous().float()
+    out = torch.empty(N * K)
+    _lib.check(_lib.lib().vd_pack_linear_frag(_lib.ptr(src), _lib.ptr(out), N, K))
+    ref = w.reshape(N // 32, 32, K // 32, 4, 2, 4).permute(2, 0, 3, 4, 1, 5).reshape(-1)
+    assert torch.equal(out, ref)
+    return out
+
+
 def run_conv(x0, x1, w, bias, *, ups=0, stride=1, affA=None, affB=None, act=0, res=None, fbias=None, generic=False):
     """x0/x1 NCHW cpu tensors; returns NCHW cpu tensor computed by the HIP kernel."""
     N, C0, H, W = x0.shape
@@ -48,7 +59,12 @@ def run_conv(x0, x1, w, bias, *, ups=0, stride=1, affA=None, affB=None, act=0, r
     d = lambda t: None if t is None else dev(t)  # noqa: E731
     bufs = [dev(nhwc(x0)), d(nhwc(x1)) if x1 is not None else None, dev(pack_conv(w)), d(bias), d(affA), d(affB),
             d(nhwc(res)) if res is not None else None, d(fbias)]
-    wfrag = dev(pack_frag(w)) if (k == 3 and O % 32 == 0 and Cin % 32 == 0 and not generic) else None
+    wfrag = None
+    if O % 32 == 0 and Cin % 32 == 0 and not generic:
+        if k == 3:
+            wfrag = dev(pack_frag(w))
+        elif affA is None and fbias is None:
+            wfrag = dev(pack_lin_frag(w.reshape(O, Cin)))
     rc = _lib.lib().vd_op_conv(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), C0, Cin, N, H, W, ups, stride, pad, k,
                                _lib.ptr(bufs[2]), _lib.ptr(wfrag), _lib.ptr(bufs[3]), _lib.ptr(bufs[4]), _lib.ptr(bufs[5]), act,
                                _lib.ptr(bufs[6]), _lib.ptr(bufs[7]), 0 if fbias is None else fbias.shape[1],
@@ -102,6 +118,16 @@ def test_conv1x1_skip_and_frame_bias():
     w, b, fb = rnd(96, 128, 1, 1, scale=0.15), rnd(96, scale=0.1), rnd(2, 200, seed=6)
     ref = F.conv2d(torch.cat([x0, x1], 1), w, b) + fb[:, :96, None, None]
     close(run_conv(x0, x1, w, b, fbias=fb), ref, **TOL)
+
+
+def test_conv1x1_concat_residual_fragment_path():
+    """ResBlock skip connection over cat([h, skip]) (unet.py:171-173,198) on the fragment-major GEMM, and
+    proj_out + residual (unet.py:537-538); both against the generic kernel as well."""
+    x0, x1 = rnd(3, 96, 16, 16), rnd(3, 32, 16, 16, seed=5)
+    w, b, res = rnd(160, 128, 1, 1, scale=0.15), rnd(160, scale=0.1), rnd(3, 160, 16, 16, seed=7)
+    ref = F.conv2d(torch.cat([x0, x1], 1), w, b) + res
+    close(run_conv(x0, x1, w, b, res=res), ref, **TOL)
+    close(run_conv(x0, x1, w, b, res=res, generic=True), ref, **TOL)
 
 
 @pytest.mark.parametrize("M,K,Nout", [(128, 128, 512), (7, 512, 1500), (4099, 96, 288), (33, 32, 40), (300, 1024, 64)])

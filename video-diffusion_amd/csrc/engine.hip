@@ -23,8 +23,8 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 
 int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hipStream_t s);
 
-enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_CONV3F };   // CONV3F: MFMA-fragment-major (conv_halo.hip)
-void pack_conv3_frag(const float* oihw, float* out, int O, int I);
+// CONV3F / LINF: MFMA-fragment-major images (conv_halo.hip / gemm_frag.hip)
+enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_CONV3F, PK_LINF };
 
 struct Param {
     std::string name;
@@ -35,6 +35,9 @@ struct Param {
     size_t off = 0;          // float offset in the packed buffer
     int kind = PK_RAW;
     bool loaded = false;
+    // PK_LINF members of a batched matrix (all FiLM projections / all RPE time projections are ONE GEMM):
+    // `off` is the base of the whole fragment-major image, rows [frag_row0, +shape[0]) of frag_rows in total
+    int frag_rows = 0, frag_row0 = 0;
 };
 
 struct ResP {
@@ -150,7 +153,8 @@ struct vd_engine {
 
     const float* W(int p) const { return wbuf + params[p].off; }
     void set_w(vd::IgemmArgs& g, int p) const {
-        if (params[p].kind == PK_CONV3F) { g.wfrag = W(p); g.w = nullptr; } else { g.w = W(p); g.wfrag = nullptr; }
+        const int k = params[p].kind;
+        if (k == PK_CONV3F || k == PK_LINF) { g.wfrag = W(p); g.w = nullptr; } else { g.w = W(p); g.wfrag = nullptr; }
     }
 
     int add(const std::string& name, std::initializer_list<long long> shape, int kind = PK_RAW) {
@@ -200,8 +204,8 @@ int vd_engine::build() {
     // The reference registers spatial_encoding first (a Parameter of the root module), but its shape is
     // known only after the input blocks are laid out; reserve the slot now.
     if (cfg.use_spatial_encoding) p_posenc = add("spatial_encoding", {1, 1, 1, 1}, PK_POSENC);
-    p_te0w = add("time_embed.0.weight", {E, mc}); p_te0b = add("time_embed.0.bias", {E});
-    p_te2w = add("time_embed.2.weight", {E, E}); p_te2b = add("time_embed.2.bias", {E});
+    p_te0w = add("time_embed.0.weight", {E, mc}, PK_LINF); p_te0b = add("time_embed.0.bias", {E});
+    p_te2w = add("time_embed.2.weight", {E, E}, PK_LINF); p_te2b = add("time_embed.2.bias", {E});
 
     // 3x3 stride-1 convs at >= 8x8 run on the halo kernel and store their weights fragment-major
     auto k3 = [&](int res_out, int cout) { return res_out >= 8 && cout % 32 == 0 ? PK_CONV3F : PK_CONV3; };
@@ -210,19 +214,19 @@ int vd_engine::build() {
         r.gn1w = add(pre + ".in_layers.0.weight", {cin}); r.gn1b = add(pre + ".in_layers.0.bias", {cin});
         r.c1w = add(pre + ".in_layers.2.weight", {cout, cin, 3, 3}, k3(rs, cout)); r.c1b = add(pre + ".in_layers.2.bias", {cout});
         const int eo = cfg.use_scale_shift_norm ? 2 * cout : cout;
-        r.embw = add(pre + ".emb_layers.1.weight", {eo, E}); r.embb = add(pre + ".emb_layers.1.bias", {eo});
+        r.embw = add(pre + ".emb_layers.1.weight", {eo, E}, PK_LINF); r.embb = add(pre + ".emb_layers.1.bias", {eo});
         r.gn2w = add(pre + ".out_layers.0.weight", {cout}); r.gn2b = add(pre + ".out_layers.0.bias", {cout});
         r.c2w = add(pre + ".out_layers.3.weight", {cout, cout, 3, 3}, k3(rs, cout)); r.c2b = add(pre + ".out_layers.3.bias", {cout});
         if (cin != cout) {
-            r.skw = add(pre + ".skip_connection.weight", {cout, cin, 1, 1}); r.skb = add(pre + ".skip_connection.bias", {cout});
+            r.skw = add(pre + ".skip_connection.weight", {cout, cin, 1, 1}, PK_LINF); r.skb = add(pre + ".skip_connection.bias", {cout});
         }
         res.push_back(r);
         return (int)res.size() - 1;
     };
     auto add_att = [&](const std::string& pre, int C) {
         AttP a;
-        a.qkvw = add(pre + ".qkv.weight", {3 * C, C}); a.qkvb = add(pre + ".qkv.bias", {3 * C});
-        a.projw = add(pre + ".proj_out.weight", {C, C}); a.projb = add(pre + ".proj_out.bias", {C});
+        a.qkvw = add(pre + ".qkv.weight", {3 * C, C}, PK_LINF); a.qkvb = add(pre + ".qkv.bias", {3 * C});
+        a.projw = add(pre + ".proj_out.weight", {C, C}, PK_LINF); a.projb = add(pre + ".proj_out.bias", {C});
         a.normw = add(pre + ".norm.weight", {C}); a.normb = add(pre + ".norm.bias", {C});
         return a;
     };
@@ -230,8 +234,8 @@ int vd_engine::build() {
         RpeP r;
         if (cfg.use_rpe_net) {
             r.dw = add(pre + ".rpe_net.embed_distances.weight", {C, 3}); r.db = add(pre + ".rpe_net.embed_distances.bias", {C});
-            r.tw = add(pre + ".rpe_net.embed_diffusion_time.weight", {C, E}); r.tb = add(pre + ".rpe_net.embed_diffusion_time.bias", {C});
-            r.ow = add(pre + ".rpe_net.out.weight", {C, C}); r.ob = add(pre + ".rpe_net.out.bias", {C});
+            r.tw = add(pre + ".rpe_net.embed_diffusion_time.weight", {C, E}, PK_LINF); r.tb = add(pre + ".rpe_net.embed_diffusion_time.bias", {C});
+            r.ow = add(pre + ".rpe_net.out.weight", {C, C}, PK_LINF); r.ob = add(pre + ".rpe_net.out.bias", {C});
         } else {
             r.table = add(pre + ".lookup_table_weight", {2 * (long long)cfg.rp_beta + 1, cfg.num_heads, C / cfg.num_heads});
         }
@@ -332,7 +336,16 @@ int vd_engine::build() {
     if (cfg.use_rpe_net) for (auto& a : attn) for (RpeP* r : {&a.rq, &a.rk, &a.rv}) { placed[r->tw] = placed[r->tb] = 1; }
     for (size_t i = 0; i < params.size(); ++i) if (!placed[i]) place((int)i);
     packed_total = off;
-    // FiLM rows must be contiguous for the single batched GEMM: every 2*cout / cout is a multiple of 4.
+    // The batched projections are ONE fragment-major matrix each: members share the region base and own a row range.
+    for (auto& r : res) { Param& p = params[r.embw]; p.off = film_w_off; p.frag_rows = film_total; p.frag_row0 = r.film_off; }
+    if (cfg.use_rpe_net)
+        for (auto& a : attn)
+            for (RpeP* r : {&a.rq, &a.rk, &a.rv}) { Param& p = params[r->tw]; p.off = te_w_off; p.frag_rows = te_total; p.frag_row0 = r->te_off; }
+    for (auto& p : params)
+        if (p.kind == PK_LINF) {
+            if (!p.frag_rows) p.frag_rows = (int)p.shape[0];
+            VD_REQUIRE(p.shape[0] % 32 == 0 && p.shape[1] % 32 == 0 && p.frag_row0 % 32 == 0, "linear layer dims must be multiples of 32");
+        }
     return 0;
 }
 
@@ -342,7 +355,8 @@ int vd_engine::linear(const float* a, int M, int K, int, int, int Nout, const fl
     IgemmArgs g{};
     g.src0 = a; g.src1 = nullptr; g.C0 = K; g.Cin = K;
     g.nfr = M; g.Hs = 1; g.Ws = 1; g.ups = 0; g.stride = 1; g.pad = 0; g.ksz = 1; g.Ho = 1; g.Wo = 1;
-    g.w = wptr; g.bias = bptr; g.affA = nullptr; g.affB = nullptr; g.act = act;
+    g.w = nullptr; g.wfrag = wptr;           // every nn.Linear weight is stored fragment-major (PK_LINF)
+    g.bias = bptr; g.affA = nullptr; g.affB = nullptr; g.act = act;
     g.res = resid; g.res_ld = Nout; g.fbias = nullptr; g.fbias_ld = 0;
     g.out = out; g.ldo = Nout; g.Cout = Nout; g.M = M;
     return igemm_p(g, st);
@@ -352,14 +366,13 @@ int vd_engine::gn_fold(const float* s0, const float* s1, int C0, int C, int N, i
                        const float* film, int film_ld, hipStream_t st, Arena& ar, float** A, float** Bp) {
     const int split = gn_stats_split(N, HW, C);
     double* part = ar.get<double>((size_t)N * split * C * 2);
-    float* mr = ar.get<float>((size_t)N * 64);
     *A = ar.get<float>((size_t)N * C);
     *Bp = ar.get<float>((size_t)N * C);
     if (ar.dry) return 0;
     ProfScope ps(PC_GN_STATS, 0.0, 4.0 * N * HW * C, st);
-    int rc = launch_gn_stats(s0, s1, C0, C, N, HW, part, split, mr, st);
+    int rc = launch_gn_stats(s0, s1, C0, C, N, HW, part, split, st);
     if (rc) return rc;
-    return launch_gn_affine(mr, W(gw), W(gb), film, film_ld, N, C, *A, *Bp, st);
+    return launch_gn_affine(part, split, (double)HW * (C / 32), W(gw), W(gb), film, film_ld, N, C, *A, *Bp, st);
 }
 
 static IgemmArgs conv_args(Tens x0, const Tens* x1, int N, int ksz, int stride, int ups) {
@@ -399,7 +412,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         float* sk = ar.get<float>((size_t)N * HW * r.cout);
         if (!ar.dry) {
             IgemmArgs g = conv_args(x0, x1, N, 1, 1, 0);
-            g.w = W(r.skw); g.bias = W(r.skb); g.out = sk; g.ldo = r.cout; g.Cout = r.cout;
+            set_w(g, r.skw); g.bias = W(r.skb); g.out = sk; g.ldo = r.cout; g.Cout = r.cout;
             if ((rc = igemm_p(g, st))) return rc;
         }
         skip = sk;
@@ -633,6 +646,19 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
     }
     std::vector<float> tmp;
     const float* src = host;
+    if (p.kind == PK_LINF) {
+        // rows [row0, row0+rows) of a [frag_rows][K] matrix -> K/32 contiguous pieces of its fragment-major image
+        const int rows = (int)p.shape[0], K = (int)p.shape[1];
+        tmp.resize(p.numel);
+        pack_linear_frag(host, tmp.data(), rows, K, rows, 0);
+        const size_t piece = (size_t)(rows / 32) * 1024;
+        for (int ch = 0; ch < K / 32; ++ch) {
+            float* dst = e->wbuf + p.off + ((size_t)ch * (p.frag_rows / 32) + p.frag_row0 / 32) * 1024;
+            VD_HIP(hipMemcpy(dst, tmp.data() + ch * piece, piece * sizeof(float), hipMemcpyHostToDevice));
+        }
+        p.loaded = true;
+        return 0;
+    }
     if (p.kind == PK_CONV3F) {
         tmp.resize(p.numel);
         pack_conv3_frag(host, tmp.data(), (int)p.shape[0], (int)p.shape[1]);
@@ -816,6 +842,12 @@ int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I) {
     return 0;
 }
 
+int vd_pack_linear_frag(const float* host_w, float* host_out, int N, int K) {
+    VD_REQUIRE(host_w && host_out && N % 32 == 0 && K % 32 == 0, "N and K multiples of 32");
+    pack_linear_frag(host_w, host_out, N, K, N, 0);
+    return 0;
+}
+
 int vd_profile_begin(void) {
     for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.recs.clear();
@@ -859,13 +891,12 @@ int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, 
                   const float* beta, const float* film, int film_ld, float* affA, float* affB, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int split = gn_stats_split(nfr, HW, C);
-    double* part; float* mr;
+    double* part;
     VD_HIP(hipMalloc(reinterpret_cast<void**>(&part), (size_t)nfr * split * C * 2 * sizeof(double)));
-    VD_HIP(hipMalloc(reinterpret_cast<void**>(&mr), (size_t)nfr * 64 * sizeof(float)));
-    int rc = launch_gn_stats(src0, src1, C0, C, nfr, HW, part, split, mr, st);
-    if (!rc) rc = launch_gn_affine(mr, gamma, beta, film, film_ld, nfr, C, affA, affB, st);
+    int rc = launch_gn_stats(src0, src1, C0, C, nfr, HW, part, split, st);
+    if (!rc) rc = launch_gn_affine(part, split, (double)HW * (C / 32), gamma, beta, film, film_ld, nfr, C, affA, affB, st);
     (void)hipStreamSynchronize(st);
-    (void)hipFree(part); (void)hipFree(mr);
+    (void)hipFree(part);
     return rc;
 }
 

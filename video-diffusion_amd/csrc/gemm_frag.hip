@@ -1,0 +1,167 @@
+// Linear layers and 1x1 convolutions on fp32 MFMA with fragment-major weights, gfx950.
+//
+//   out[m][n] = bias[n] + res[m][n] + sum_k f(A[m][k]) * W[n][k]        f = identity | SiLU
+//
+// Same operand plan as conv_halo.hip, minus the halo: the A tile [BM][32] of a K-chunk goes through LDS
+// (coalesced 128-byte row segments in, ds_read_b128 fragments out, double-buffered, ONE barrier per
+// chunk), the B operand is fetched by each wave straight from L2 in MFMA-fragment order
+//     [K/32][N/32][kgroup 4][lane 64][4 floats]
+// one coalesced 1 KiB load per k-group, two k-groups ahead in a 4-deep register ring.
+// A may be a virtual concat of two row-major sources (ResBlock skip connection over cat([h, skip])).
+#include "vd_common.h"
+
+namespace vd {
+
+constexpr int GLD = 36;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
+    constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];          // [2][BM][GLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int lrow = tid >> 3, lq = tid & 7;
+    const int nchunk = a.Cin >> 5, ncoblk = a.Cout >> 5;
+    const int C1 = a.Cin - a.C0;
+
+    size_t arow[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) arow[j] = (size_t)min(m0 + lrow + 32 * j, a.M - 1);   // rows past M: duplicates, masked at store
+
+    int cob[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) cob[j] = min(blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1);
+    const float* wl = a.wfrag + lane * 4;
+
+    f32x4 ra[AR], bfr[4][NI], afr[2][MI];      // weight ring of 4 = k-groups per chunk: slot == kg, compile-time
+    auto a_prefetch = [&](int chunk) {
+        const int c = chunk * 32 + lq * 4;
+        const float* base; int cc, ld;
+        if (c < a.C0) { base = a.src0; cc = c; ld = a.C0; } else { base = a.src1; cc = c - a.C0; ld = C1; }
+#pragma unroll
+        for (int j = 0; j < AR; ++j) ra[j] = *reinterpret_cast<const f32x4*>(base + arow[j] * ld + cc);
+    };
+    auto a_store = [&](float* Ad) {
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            f32x4 v = ra[j];
+            if (a.act) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            *reinterpret_cast<f32x4*>(Ad + (lrow + 32 * j) * GLD + lq * 4) = v;
+        }
+    };
+    auto b_load = [&](int slot, int chunk, int kg) {
+        const float* p = wl + ((size_t)chunk * ncoblk) * 1024 + kg * 256;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[slot][j] = *reinterpret_cast<const f32x4*>(p + (size_t)cob[j] * 1024);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    a_prefetch(0);
+    b_load(0, 0, 0);
+    b_load(1, 0, 1);
+    a_store(smem);
+    __syncthreads();
+
+    const int aoff = (wm * (BM / 2) + lr) * GLD + lh * 4;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const int nxt = min(chunk + 1, nchunk - 1);           // last chunk: redundant prefetch instead of a branch
+        const float* Acur = smem + (chunk & 1) * BM * GLD + aoff;
+        float* Anext = smem + ((chunk + 1) & 1) * BM * GLD;
+        a_prefetch(nxt);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) afr[0][i] = *reinterpret_cast<const f32x4*>(Acur + i * 32 * GLD);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            if (kg + 2 < 4) b_load(kg + 2, chunk, kg + 2);      // two groups ahead; slot (kg+2)&3 was consumed two groups ago
+            else b_load(kg - 2, nxt, kg - 2);
+            if (kg + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    afr[(kg + 1) & 1][i] = *reinterpret_cast<const f32x4*>(Acur + i * 32 * GLD + (kg + 1) * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);               // keep the prefetches ahead of the MFMAs (see conv_halo.hip)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kg & 1][i][e], bfr[kg][j][e], acc[i][j], 0, 0, 0);
+            if (kg == 3) a_store(Anext);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int co = n0 + wn * (BN / 2) + j * 32 + lr;
+        if (co >= a.Cout) continue;
+        const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
+            f32x16 v = acc[i][j];
+            if (a.res) {
+                f32x16 rv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rv[r] = a.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), a.M - 1) * a.res_ld + co];
+                v += rv;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < a.M) a.out[(size_t)m * a.ldo + co] = v[r] + bv;
+            }
+        }
+    }
+}
+
+bool gemm_frag_supported(const IgemmArgs& a) {
+    return a.wfrag != nullptr && a.ksz == 1 && a.stride == 1 && a.pad == 0 && a.ups == 0 && a.Cout % 32 == 0 &&
+           a.affA == nullptr && a.fbias == nullptr;
+}
+
+template <int BM, int BN>
+static int launch_gf(const IgemmArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * BM * GLD * sizeof(float);
+    dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_frag_kernel<BM, BN>), grid, dim3(256), lds, s, a);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_frag(const IgemmArgs& a, int tile_class, hipStream_t s) {
+    switch (tile_class) {
+        case 0: return launch_gf<128, 128>(a, s);
+        case 1: return launch_gf<128, 64>(a, s);
+        case 2: return launch_gf<64, 128>(a, s);
+        default: return launch_gf<64, 64>(a, s);
+    }
+}
+
+// host-side repack of `rows` rows of a [N_total][K] row-major matrix (rows row0 .. row0+rows-1, all multiples of 32)
+// into the fragment-major image of the WHOLE matrix: [K/32][N_total/32][4][64][4]
+void pack_linear_frag(const float* w, float* out_base, int rows, int K, int n_total, int row0) {
+    const int nchunk = K / 32, ncoblk = n_total / 32;
+    for (int ch = 0; ch < nchunk; ++ch)
+        for (int cb = 0; cb < rows / 32; ++cb)
+            for (int kg = 0; kg < 4; ++kg)
+                for (int h = 0; h < 2; ++h)
+                    for (int r = 0; r < 32; ++r)
+                        for (int e = 0; e < 4; ++e)
+                            out_base[((((size_t)ch * ncoblk + row0 / 32 + cb) * 4 + kg) * 64 + h * 32 + r) * 4 + e] =
+                                w[(size_t)(cb * 32 + r) * K + ch * 32 + kg * 8 + h * 4 + e];
+}
+
+}  // namespace vd

@@ -46,24 +46,6 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const float* __restrict_
     }
 }
 
-// grid nfr, 64 threads: lane g < 32 reduces group g over splits and its channels.
-__global__ void gn_stats_final(const double* __restrict__ part, int C, int split, double count,
-                               float* __restrict__ meanrstd) {
-    const int n = blockIdx.x, g = threadIdx.x;
-    if (g >= 32) return;
-    const int cg = C / 32;
-    double s = 0, ss = 0;
-    for (int sp = 0; sp < split; ++sp) {
-        const double* p = part + (((size_t)n * split + sp) * C + g * cg) * 2;
-        for (int k = 0; k < cg; ++k) { s += p[2 * k]; ss += p[2 * k + 1]; }
-    }
-    const double mean = s / count;
-    double var = ss / count - mean * mean;
-    if (var < 0) var = 0;
-    meanrstd[(n * 32 + g) * 2] = (float)mean;
-    meanrstd[(n * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
-}
-
 int gn_stats_split(int nfr, int HW, int C) {
     const int ppi = 256 / (C / 4);
     int split = 1;
@@ -73,40 +55,61 @@ int gn_stats_split(int nfr, int HW, int C) {
 }
 
 int launch_gn_stats(const float* src0, const float* src1, int C0, int C, int nfr, int HW, double* part, int split,
-                    float* meanrstd, hipStream_t s) {
+                    hipStream_t s) {
     VD_REQUIRE(C % 32 == 0 && C <= 1024 && C0 % 4 == 0, "GroupNorm32 channel constraints");
     hipLaunchKernelGGL(gn_stats_partial, dim3(split, nfr), dim3(256), 0, s, src0, src1, C0, C, HW, split, part);
-    hipLaunchKernelGGL(gn_stats_final, dim3(nfr), dim3(64), 0, s, part, C, split, (double)HW * (C / 32), meanrstd);
     VD_HIP(hipGetLastError());
     return 0;
 }
 
-// ------------------------------------------------------------------ fold into per-(frame,channel) affine
+// ------------------------------------------------------------------ group statistics -> per-(frame,channel) affine
 //   y = ((x-mean)*rstd*gamma + beta) * (1+scale) + shift  =  x*A + B
-__global__ void gn_affine_kernel(const float* __restrict__ meanrstd, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, const float* __restrict__ film, int film_ld, int C,
-                                 float* __restrict__ affA, float* __restrict__ affB) {
-    const int n = blockIdx.y;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const int g = c / (C / 32);
-    const float mean = meanrstd[(n * 32 + g) * 2], rstd = meanrstd[(n * 32 + g) * 2 + 1];
-    float A = rstd * gamma[c];
-    float B = beta[c] - mean * A;
-    if (film) {
-        const float sc = 1.0f + film[(size_t)n * film_ld + c];
-        const float sh = film[(size_t)n * film_ld + C + c];
-        A *= sc;
-        B = B * sc + sh;
+// One block per frame: 8 lanes per group reduce the (split x C/32) fp64 partials with shuffles, then all
+// 256 threads fold mean/rstd/gamma/beta and the FiLM pair into A, B.
+__global__ __launch_bounds__(256) void gn_final_affine_kernel(const double* __restrict__ part, int split, double count,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ film, int film_ld, int C,
+                                                              float* __restrict__ affA, float* __restrict__ affB) {
+    __shared__ float mr[64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int g = tid >> 3, l = tid & 7;
+    const int cg = C / 32;
+    double s = 0, ss = 0;
+    for (int k = l; k < split * cg; k += 8) {
+        const int sp = k / cg, c = k - sp * cg;
+        const double* p = part + (((size_t)n * split + sp) * C + g * cg + c) * 2;
+        s += p[0]; ss += p[1];
     }
-    affA[(size_t)n * C + c] = A;
-    affB[(size_t)n * C + c] = B;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 8); ss += __shfl_xor(ss, o, 8); }
+    if (l == 0) {
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
+        if (var < 0) var = 0;
+        mr[g * 2] = (float)mean;
+        mr[g * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int gg = c / cg;
+        float A = mr[gg * 2 + 1] * gamma[c];
+        float B = beta[c] - mr[gg * 2] * A;
+        if (film) {
+            const float sc = 1.0f + film[(size_t)n * film_ld + c];
+            const float sh = film[(size_t)n * film_ld + C + c];
+            A *= sc;
+            B = B * sc + sh;
+        }
+        affA[(size_t)n * C + c] = A;
+        affB[(size_t)n * C + c] = B;
+    }
 }
 
-int launch_gn_affine(const float* meanrstd, const float* gamma, const float* beta, const float* film, int film_ld,
-                     int nfr, int C, float* affA, float* affB, hipStream_t s) {
-    hipLaunchKernelGGL(gn_affine_kernel, dim3((C + 127) / 128, nfr), dim3(128), 0, s, meanrstd, gamma, beta, film,
-                       film_ld, C, affA, affB);
+int launch_gn_affine(const double* part, int split, double count, const float* gamma, const float* beta,
+                     const float* film, int film_ld, int nfr, int C, float* affA, float* affB, hipStream_t s) {
+    hipLaunchKernelGGL(gn_final_affine_kernel, dim3(nfr), dim3(256), 0, s, part, split, count, gamma, beta, film, film_ld,
+                       C, affA, affB);
     VD_HIP(hipGetLastError());
     return 0;
 }

@@ -80,17 +80,23 @@ int igemm_tile_class(int M, int Cout);   // 0: 128x128, 1: 128x64, 2: 64x128, 3:
 // 3x3 stride-1 path with an LDS-staged, once-transformed input halo tile (conv_halo.hip)
 bool conv_halo_supported(const IgemmArgs& a);
 int launch_conv_halo(const IgemmArgs& a, int tile_class, hipStream_t s);
+// linear / 1x1 path with fragment-major weights (gemm_frag.hip); wfrag = [K/32][N/32][4][64][4]
+bool gemm_frag_supported(const IgemmArgs& a);
+int launch_gemm_frag(const IgemmArgs& a, int tile_class, hipStream_t s);
+void pack_linear_frag(const float* w, float* out_base, int rows, int K, int n_total, int row0);
+void pack_conv3_frag(const float* oihw, float* out, int O, int I);
 int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s);
 int launch_attn_temporal(const AttnTemporalArgs& a, hipStream_t s);
 
 // GroupNorm statistics over (pixels x channels-of-group) of one frame, 32 groups, virtual concat.
-// part: workspace of nfr*split*C*2 doubles; meanrstd out: [nfr][32][2] floats.
+// part: workspace of nfr*split*C*2 doubles (per-channel fp64 sum / sum of squares per pixel range).
 int launch_gn_stats(const float* src0, const float* src1, int C0, int C, int nfr, int HW, double* part, int split,
-                    float* meanrstd, hipStream_t s);
+                    hipStream_t s);
 int gn_stats_split(int nfr, int HW, int C);
 // affA/affB[n][c] = fold(mean, rstd, gamma, beta, FiLM scale/shift).  film: [nfr][film_ld], scale at +0, shift at +C.
-int launch_gn_affine(const float* meanrstd, const float* gamma, const float* beta, const float* film, int film_ld,
-                     int nfr, int C, float* affA, float* affB, hipStream_t s);
+// count = elements per group (HW * C/32)
+int launch_gn_affine(const double* part, int split, double count, const float* gamma, const float* beta,
+                     const float* film, int film_ld, int nfr, int C, float* affA, float* affB, hipStream_t s);
 // y = x*A[n][c] + B[n][c]  (materialised normalisation for the attention residual, unet.py:474,538)
 int launch_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y,
                         hipStream_t s);
