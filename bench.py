@@ -193,10 +193,14 @@ def main():
             name = max((k for k in classes if k.startswith(("igemm", "conv3x3"))), key=lambda k: classes[k]["ms"])
             c = classes[name]
             achieved = c["gflop"] / c["ms"]                                   # GFLOP/ms = TFLOP/s
+            # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+            # runs, gfx950 x2 correction on FETCH_SIZE; tools/profile_bench.sh): PMC cannot be read inside this process
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_igemm.json")
+            pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
             if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                if rec.get("kernel") == name:
+                    traffic = round(rec["hbm_bytes_per_launch"])
             roofline = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
                             unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                             launches_per_step=c["launches"], avg_launch_us=round(1e3 * c["ms"] / c["launches"], 1),

@@ -261,3 +261,64 @@ def test_infer_video_autoreg_vs_oracle(monkeypatch):
     close(got, samples.numpy(), atol=3e-2, rtol=1e-2)
     assert np.array_equal(got[:, :obs_len], batch[:, :obs_len].numpy())      # observed frames pass through untouched
     assert to_uint8(got).dtype == np.uint8 and to_uint8(np.array([1.0, -1.0, 0.0])).tolist() == [255, 0, 127]
+
+
+@pytest.mark.parametrize("size,mc,B,T,n_obs", [(128, 32, 1, 4, 2), (64, 64, 2, 20, 13), (32, 64, 1, 32, 16)])
+def test_other_baseline_shapes_vs_oracle(size, mc, B, T, n_obs):
+    """BASELINE configs 3-5 in miniature: the 128x128 topology (channel_mult (1,1,2,3,4), five levels, script_util.py:255-264),
+    Tw = 20 autoregressive windows (TMAX=32 code paths of the temporal kernels) and the 32-frame limit."""
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=T, image_size=size, num_channels=mc, num_res_blocks=1,
+                                                              rp_alpha=T, rp_beta=T, rp_gamma=T,
+                                                              timestep_respacing="ddim50")}
+    model, diff, ora = _oracle(cfg)
+    c = _rand_window(B, T, size, n_obs, seed=size + T)
+    t = torch.tensor([11] * B)
+    kw = {k: v for k, v in c.items() if k not in ("x", "observed_frames")}
+    want = ora.eps(c["x"], t, kw)
+    got, _ = diff._wrap_model(model)(c["x"].cuda(), t.cuda(), **kwargs_of(c))
+    close(got.cpu(), want, atol=1e-4, rtol=1e-4)
+
+
+def test_exp_past_window_order_vs_oracle():
+    """exp-past feeds the observed frames in its own, unsorted order (inference_util.py:275-293):
+    frame_indices carry that order into the relative-position terms."""
+    from video_diffusion_amd import inference_util as iu
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=16, image_size=32, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=16, rp_beta=16, rp_gamma=16,
+                                                              timestep_respacing="ddim50")}
+    model, diff, ora = _oracle(cfg)
+    sched = list(iu.inference_strategies["exp-past"](video_length=16, num_obs=4, max_frames=16, step_size=4))
+    obs_idx, lat_idx = sched[1]
+    assert [int(i) for i in obs_idx] == [7, 6, 4, 5, 3, 2, 1, 0]
+    T = len(obs_idx) + len(lat_idx)
+    c = _rand_window(2, T, 32, len(obs_idx), seed=77)
+    c["frame_indices"] = torch.tensor([int(i) for i in obs_idx] + list(lat_idx)).repeat(2, 1)
+    t = torch.tensor([30] * 2)
+    kw = {k: v for k, v in c.items() if k not in ("x", "observed_frames")}
+    want = ora.eps(c["x"], t, kw)
+    got, _ = diff._wrap_model(model)(c["x"].cuda(), t.cuda(), **kwargs_of(c))
+    close(got.cpu(), want, atol=1e-4, rtol=1e-4)
+
+
+def test_p_sample_loop_and_ddim_loop_contracts():
+    """Return arity and shapes of the loops (gaussian_diffusion.py:450-526 returns (sample, attns); :670-700 returns
+    sample), x_t_minus_1 refreshed per step by q_sample (:565-568), seeded reproducibility of the whole loop."""
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=4, rp_beta=4, rp_gamma=4,
+                                                              timestep_respacing="ddim5")}
+    model, diff = engine(cfg)
+    c = _rand_window(2, 4, 32, 2, seed=3)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        kw = kwargs_of(c, observed_frames="x_t_minus_1")
+        sample, attns = diff.p_sample_loop(model, (2, 4, 3, 32, 32), model_kwargs=kw)
+        assert attns == {} and sample.shape == (2, 4, 3, 32, 32) and torch.isfinite(sample).all()
+        assert kw["x_t_minus_1"].shape == sample.shape and "random_t" in kw
+        outs.append(sample)
+    assert torch.equal(outs[0], outs[1])
+    torch.manual_seed(7)
+    d = diff.ddim_sample_loop(model, (2, 4, 3, 32, 32), model_kwargs=kwargs_of(c), eta=0.0)
+    assert torch.is_tensor(d) and d.shape == (2, 4, 3, 32, 32) and torch.isfinite(d).all()
+    n = sum(1 for _ in diff.ddim_sample_loop_progressive(model, (2, 4, 3, 32, 32), model_kwargs=kwargs_of(c)))
+    assert n == diff.num_timesteps == 5

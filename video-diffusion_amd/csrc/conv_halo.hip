@@ -113,13 +113,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_frag_kernel(IgemmArgs a, HaloG
         }
     };
 
+    // Accumulators start at bias + residual (+ per-frame bias): the residual tile is fetched while the first halo is
+    // being staged instead of behind a drained wait in the epilogue, and costs no extra registers.
+    auto out_frame = [&](int i, int r) {
+        const int m = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        return min(f0 + (m >> (g.tw_log + g.th_log)), a.nfr - 1);
+    };
+    auto out_pixel = [&](int i, int r, bool& ok) -> size_t {
+        const int m = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int x = m & (TW - 1), y = (m >> g.tw_log) & (TH - 1), f = m >> (g.tw_log + g.th_log);
+        const int n = f0 + f;
+        ok = n < a.nfr;
+        return ((size_t)min(n, a.nfr - 1) * Hl + ty0 + y) * Wl + tx0 + x;
+    };
     f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NI; ++j) {
+        const int co = min(n0 + wn * (BN / 2) + j * 32 + lr, a.Cout - 1);
+        const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+            if (a.res) {          // one branch around all 16 loads (a branch per load would drain the queue each time)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { bool ok; acc[i][j][r] += a.res[out_pixel(i, r, ok) * a.res_ld + co]; }
+            }
+            if (a.fbias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += a.fbias[(size_t)out_frame(i, r) * a.fbias_ld + co];
+            }
+        }
+    }
 
     f32x4 bfr[3][NI], afr[2][MI];
     auto b_load = [&](int slot, int chunk, int tap, int kg) {
@@ -178,36 +203,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_frag_kernel(IgemmArgs a, HaloG
     for (int j = 0; j < NI; ++j) {
         const int co = n0 + wn * (BN / 2) + j * 32 + lr;
         if (co >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            // all 16 residual loads of the tile are issued together (unconditional, frame clamped), then one wait:
-            // a per-element `if (res) v += load` costs one drained L2 round trip per element
-            size_t pix[16];
-            bool ok[16];
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int x = m & (TW - 1), y = (m >> g.tw_log) & (TH - 1), f = m >> (g.tw_log + g.th_log);
-                const int n = f0 + f;
-                ok[r] = n < a.nfr;
-                pix[r] = ((size_t)min(n, a.nfr - 1) * Hl + ty0 + y) * Wl + tx0 + x;
+                bool ok;
+                const size_t pix = out_pixel(i, r, ok);
+                if (ok) a.out[pix * a.ldo + co] = acc[i][j][r];
             }
-            f32x16 v = acc[i][j];
-            if (a.res) {
-                f32x16 rv;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = a.res[pix[r] * a.res_ld + co];
-                v += rv;
-            }
-            if (a.fbias) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += a.fbias[(pix[r] / ((size_t)Hl * Wl)) * a.fbias_ld + co];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (ok[r]) a.out[pix[r] * a.ldo + co] = v[r] + bv;
-        }
     }
 }
 

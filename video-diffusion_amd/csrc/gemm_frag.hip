@@ -57,13 +57,24 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
         for (int j = 0; j < NI; ++j) bfr[slot][j] = *reinterpret_cast<const f32x4*>(p + (size_t)cob[j] * 1024);
     };
 
+    // accumulators start at bias + residual: the residual tile streams in under the first A-tile staging
     f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NI; ++j) {
+        const int co = min(n0 + wn * (BN / 2) + j * 32 + lr, a.Cout - 1);
+        const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int i = 0; i < MI; ++i) {
+            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+            if (a.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] += a.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), a.M - 1) * a.res_ld + co];
+            }
+        }
+    }
 
     a_prefetch(0);
     b_load(0, 0, 0);
@@ -106,22 +117,13 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
     for (int j = 0; j < NI; ++j) {
         const int co = n0 + wn * (BN / 2) + j * 32 + lr;
         if (co >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
-            f32x16 v = acc[i][j];
-            if (a.res) {
-                f32x16 rv;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    rv[r] = a.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), a.M - 1) * a.res_ld + co];
-                v += rv;
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < a.M) a.out[(size_t)m * a.ldo + co] = v[r] + bv;
+                if (m < a.M) a.out[(size_t)m * a.ldo + co] = acc[i][j][r];
             }
         }
     }

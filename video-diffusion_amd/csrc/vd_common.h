@@ -155,6 +155,8 @@ int launch_randn(float* out, long n, unsigned long long seed, unsigned long long
 enum { TAB_SQRT_RECIP = 0, TAB_SQRT_RECIPM1, TAB_COEF1, TAB_COEF2, TAB_LOGVAR, TAB_ACP, TAB_ACP_PREV,
        TAB_SQRT_ACP, TAB_SQRT_1M_ACP, NTAB };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (each <= 1 ulp): 5 VALU instructions instead of the ~15 of an IEEE
+// division.  The operand transform of the conv kernels runs this on every staged input element.
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 }  // namespace vd
