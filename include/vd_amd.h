@@ -130,14 +130,18 @@ const char* vd_profile_class_name(int i);
 /* NHWC conv / linear on fp32 MFMA.  src1/C0: virtual channel concat; affA/affB: folded GroupNorm(+FiLM);
  * act: SiLU on the operand; res: residual in the epilogue; fbias: per-frame bias [nfr][fbias_ld]. */
 /* w_packed: [tap][Cout][Cin] (generic kernel; may be NULL when w_frag covers the shape);
- * w_frag: MFMA-fragment-major 3x3 weights from vd_pack_conv3_frag (3x3 stride-1, >= 8x8, Cout % 32 == 0), or NULL. */
+ * w_frag: MFMA-fragment-major weights from vd_pack_conv3_frag / vd_pack_linear_frag, or NULL;
+ * w_wino: Winograd-transformed 3x3 weights from vd_pack_conv3_wino, or NULL (preferred when given and supported). */
 int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, int ups, int stride,
-               int pad, int ksz, const float* w_packed, const float* w_frag, const float* bias, const float* affA,
-               const float* affB, int act, const float* res, const float* fbias, int fbias_ld, float* out, int Cout,
-               void* stream);
+               int pad, int ksz, const float* w_packed, const float* w_frag, const float* w_wino, const float* bias,
+               const float* affA, const float* affB, int act, const float* res, const float* fbias, int fbias_ld,
+               float* out, int Cout, void* stream);
 /* Host repack OIHW (O, I multiples of 32) -> [tap][I/32][O/32][kgroup 4][lane 64][4]: lane 32h+r of k-group kg holds
  * w[co = 32*blk + r][ci = 32*chunk + 8*kg + 4*h + e]; one coalesced 1 KiB load per wave per MFMA k-group. */
 int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I);
+/* Winograd F(2x2,3x3) image of a 3x3 weight: U = G g G^T per (cout, cin), 16*O*I floats in
+ * [I/16][16][O/32][2][64][4]; pass as w_wino (3x3 stride-1, >= 8x8, O % 64 == 0, I % 16 == 0). */
+int vd_pack_conv3_wino(const float* host_oihw, float* host_out, int O, int I);
 /* Same for an nn.Linear / 1x1-conv weight [N][K] (N, K multiples of 32) -> [K/32][N/32][4][64][4]; pass the result as
  * w_frag with ksz = 1. */
 int vd_pack_linear_frag(const float* host_w, float* host_out, int N, int K);

@@ -48,7 +48,21 @@ def pack_lin_frag(w):
     return out
 
 
-def run_conv(x0, x1, w, bias, *, ups=0, stride=1, affA=None, affB=None, act=0, res=None, fbias=None, generic=False):
+def pack_wino(w):
+    """OIHW -> Winograd F(2x2,3x3) image U = G g G^T in [I/16][16][O/32][2][64][4] (library packer + closed form)."""
+    O, I = w.shape[:2]
+    src = w.contiguous().float()
+    out = torch.empty(16 * O * I)
+    _lib.check(_lib.lib().vd_pack_conv3_wino(_lib.ptr(src), _lib.ptr(out), O, I))
+    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
+    U = torch.einsum("ik,ockl,jl->ijoc", G, w.double(), G).float().reshape(16, O, I)          # [xi][co][ci]
+    ref = U.reshape(16, O // 32, 32, I // 16, 2, 2, 4).permute(3, 0, 1, 4, 5, 2, 6).reshape(-1)
+    assert torch.equal(out, ref)
+    return out
+
+
+def run_conv(x0, x1, w, bias, *, ups=0, stride=1, affA=None, affB=None, act=0, res=None, fbias=None, generic=False,
+             wino=True):
     """x0/x1 NCHW cpu tensors; returns NCHW cpu tensor computed by the HIP kernel."""
     N, C0, H, W = x0.shape
     Cin = C0 + (x1.shape[1] if x1 is not None else 0)
@@ -59,14 +73,17 @@ def run_conv(x0, x1, w, bias, *, ups=0, stride=1, affA=None, affB=None, act=0, r
     d = lambda t: None if t is None else dev(t)  # noqa: E731
     bufs = [dev(nhwc(x0)), d(nhwc(x1)) if x1 is not None else None, dev(pack_conv(w)), d(bias), d(affA), d(affB),
             d(nhwc(res)) if res is not None else None, d(fbias)]
-    wfrag = None
+    wfrag = wwino = None
     if O % 32 == 0 and Cin % 32 == 0 and not generic:
         if k == 3:
             wfrag = dev(pack_frag(w))
+            if O % 64 == 0 and wino:
+                wwino = dev(pack_wino(w))
         elif affA is None and fbias is None:
             wfrag = dev(pack_lin_frag(w.reshape(O, Cin)))
     rc = _lib.lib().vd_op_conv(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), C0, Cin, N, H, W, ups, stride, pad, k,
-                               _lib.ptr(bufs[2]), _lib.ptr(wfrag), _lib.ptr(bufs[3]), _lib.ptr(bufs[4]), _lib.ptr(bufs[5]), act,
+                               _lib.ptr(bufs[2]), _lib.ptr(wfrag), _lib.ptr(wwino), _lib.ptr(bufs[3]), _lib.ptr(bufs[4]),
+                               _lib.ptr(bufs[5]), act,
                                _lib.ptr(bufs[6]), _lib.ptr(bufs[7]), 0 if fbias is None else fbias.shape[1],
                                _lib.ptr(out), O, _lib.current_stream())
     _lib.check(rc)
@@ -84,26 +101,30 @@ def rnd(*shape, seed=0, scale=1.0):
 def test_conv3x3_plain(N, Cin, Cout, H):
     x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, scale=(3.0 / (9 * Cin)) ** 0.5), rnd(Cout, scale=0.1)
     ref = F.conv2d(x, w, b, padding=1)
-    close(run_conv(x, None, w, b), ref, **TOL)                       # halo kernel where the shape allows
+    close(run_conv(x, None, w, b), ref, **TOL)                       # Winograd / halo kernel where the shape allows
+    close(run_conv(x, None, w, b, wino=False), ref, **TOL)           # direct fragment-major halo kernel
     close(run_conv(x, None, w, b, generic=True), ref, **TOL)         # generic per-tap kernel
 
 
-def test_conv3x3_fused_norm_film_silu_residual_concat():
-    """ResBlock operand path (unet.py:185-198): conv(silu(x*A+B)) + bias + skip, input = cat([h, skip])."""
-    N, C0, C1, Cout, H = 3, 64, 32, 96, 16
-    h, s = rnd(N, C0, H, H), rnd(N, C1, H, H, seed=1)
+@pytest.mark.parametrize("N,C0,C1,Cout,H", [(3, 64, 32, 96, 16), (3, 64, 32, 128, 16), (5, 32, 32, 64, 8), (2, 96, 0, 192, 32)])
+def test_conv3x3_fused_norm_film_silu_residual_concat(N, C0, C1, Cout, H):
+    """ResBlock operand path (unet.py:185-198): conv(silu(x*A+B)) + bias + skip, input = cat([h, skip]).
+    Cout % 64 == 0 runs the Winograd kernel (8x8: four frames per block, 5 frames -> ragged last block)."""
+    h, s = rnd(N, C0, H, H), (rnd(N, C1, H, H, seed=1) if C1 else None)
     A, B = rnd(N, C0 + C1, seed=2) + 1.5, rnd(N, C0 + C1, seed=3)
     w, b, res = rnd(Cout, C0 + C1, 3, 3, scale=0.06), rnd(Cout, scale=0.1), rnd(N, Cout, H, H, seed=4)
-    x = torch.cat([h, s], 1)
+    x = torch.cat([h, s], 1) if C1 else h
     ref = F.conv2d(F.silu(x * A[:, :, None, None] + B[:, :, None, None]), w, b, padding=1) + res
     close(run_conv(h, s, w, b, affA=A, affB=B, act=1, res=res), ref, **TOL)
+    close(run_conv(h, s, w, b, affA=A, affB=B, act=1, res=res, wino=False), ref, **TOL)
 
 
 def test_conv3x3_upsample_fused():
     """Upsample (unet.py:63-72): nearest x2 read through the gather, zero padding at the UPSAMPLED border."""
     x, w, b = rnd(2, 64, 8, 8), rnd(64, 64, 3, 3, scale=0.07), rnd(64, scale=0.1)
-    close(run_conv(x, None, w, b, ups=1), F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1),
-          **TOL)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    close(run_conv(x, None, w, b, ups=1), ref, **TOL)
+    close(run_conv(x, None, w, b, ups=1, wino=False), ref, **TOL)
 
 
 @pytest.mark.parametrize("H", [16, 8, 2])
@@ -144,22 +165,23 @@ def test_conv_is_deterministic_and_linear_at_scale():
     g = torch.Generator().manual_seed(3)
     x = torch.rand(128, 64, 64, 128, generator=g, device="cpu").cuda() - 0.5        # already NHWC
     w_oihw = rnd(128, 128, 3, 3, scale=0.03)
-    w, wf = dev(pack_conv(w_oihw)), dev(pack_frag(w_oihw))
+    w, wf, ww = dev(pack_conv(w_oihw)), dev(pack_frag(w_oihw)), dev(pack_wino(w_oihw))
     b = dev(rnd(128, scale=0.1))
     outs = []
-    for scale, frag in ((1.0, wf), (1.0, wf), (2.0, wf), (1.0, None)):
+    for scale, frag, wino in ((1.0, wf, ww), (1.0, wf, ww), (2.0, wf, ww), (1.0, wf, None), (1.0, None, None)):
         xs = (x * scale).contiguous()
         o = torch.empty(128, 64, 64, 128, device="cuda")
         _lib.check(_lib.lib().vd_op_conv(_lib.ptr(xs), None, 128, 128, 128, 64, 64, 0, 1, 1, 3, _lib.ptr(w), _lib.ptr(frag),
-                                         _lib.ptr(b), None, None, 0, None, None, 0, _lib.ptr(o), 128,
+                                         _lib.ptr(wino), _lib.ptr(b), None, None, 0, None, None, 0, _lib.ptr(o), 128,
                                          _lib.current_stream()))
         outs.append(o)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1])
     lin = 2 * outs[0] - b.view(1, 1, 1, -1)
-    assert (outs[2] - lin).abs().max().item() < 1e-5
-    # the halo/fragment kernel and the generic per-tap kernel are two implementations of the same sum
-    assert (outs[0] - outs[3]).abs().max().item() < 2e-5
+    assert (outs[2] - lin).abs().max().item() < 2e-5
+    # Winograd, direct halo/fragment and generic per-tap kernels are three implementations of the same sum
+    assert (outs[0] - outs[3]).abs().max().item() < 5e-5
+    assert (outs[3] - outs[4]).abs().max().item() < 2e-5
 
 
 def _gn_fold(x0, x1, gamma, beta, film):

@@ -52,15 +52,17 @@ def main():
         out = torch.empty(nfr, Ho, Ho, Cout, device="cuda")
         res = torch.rand(nfr, Ho, Ho, Cout, device="cuda", generator=g) if pro and k == 3 else None
 
-        wf = None
+        wf = ww = None
         if k == 1:
             A = B = None                 # linear layers of the engine use SiLU-only prologues (time_embed, FiLM)
         if stride == 1 and not os.environ.get("VD_NO_HALO"):
             wf = torch.rand(9 * Cout * Cin, device="cuda", generator=g) * 0.05     # timing only: any values
+            if k == 3 and Cout % 64 == 0 and not os.environ.get("VD_NO_WINO"):
+                ww = torch.rand(16 * Cout * Cin, device="cuda", generator=g) * 0.05
 
         def run():
             _lib.check(L.vd_op_conv(_lib.ptr(x0), _lib.ptr(x1), C0, Cin, nfr, H, H, ups, stride, pad, k, _lib.ptr(w),
-                                    _lib.ptr(wf), _lib.ptr(b), _lib.ptr(A), _lib.ptr(B), pro, _lib.ptr(res), None, 0,
+                                    _lib.ptr(wf), _lib.ptr(ww), _lib.ptr(b), _lib.ptr(A), _lib.ptr(B), pro, _lib.ptr(res), None, 0,
                                     _lib.ptr(out), Cout, _lib.current_stream()))
         run()
         torch.cuda.synchronize()

@@ -14,7 +14,7 @@ def make(nfr, C, Cout, H, pro, res):
     r = torch.rand(nfr, H, H, Cout, device="cuda", generator=g) if res else None
     out = torch.empty(nfr, H, H, Cout, device="cuda")
     def f():
-        _lib.check(L.vd_op_conv(_lib.ptr(x), None, C, C, nfr, H, H, 0, 1, 1, 3, None, _lib.ptr(wf), _lib.ptr(b), _lib.ptr(A),
+        _lib.check(L.vd_op_conv(_lib.ptr(x), None, C, C, nfr, H, H, 0, 1, 1, 3, None, _lib.ptr(wf), None, _lib.ptr(b), _lib.ptr(A),
                                 _lib.ptr(B), 1 if pro else 0, _lib.ptr(r), None, 0, _lib.ptr(out), Cout, _lib.current_stream()))
     return f, 2.0 * nfr * H * H * Cout * C * 9
 samples = []

@@ -24,7 +24,8 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hipStream_t s);
 
 // CONV3F / LINF: MFMA-fragment-major images (conv_halo.hip / gemm_frag.hip)
-enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_CONV3F, PK_LINF };
+// CONV3W: Winograd F(2x2,3x3)-transformed weights, 16/9 of the checkpoint size (conv_wino.hip)
+enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_CONV3F, PK_LINF, PK_CONV3W };
 
 struct Param {
     std::string name;
@@ -73,12 +74,12 @@ struct Arena {
 // ---- per-class kernel timing with HIP events on the launch stream (bench.py's live roofline figure)
 enum ProfClass { PC_IGEMM_128x128 = 0, PC_IGEMM_128x64, PC_IGEMM_64x128, PC_IGEMM_64x64, PC_GN_STATS, PC_GN_TEMPORAL,
                  PC_ATTN_SPATIAL, PC_ATTN_TEMPORAL, PC_OUT_CONV, PC_ELEMENTWISE, PC_POSTERIOR,
-                 PC_CONV_128x128, PC_CONV_128x64, PC_CONV_64x128, PC_CONV_64x64, PC_COUNT };
+                 PC_CONV_128x128, PC_CONV_128x64, PC_CONV_64x128, PC_CONV_64x64, PC_CONV_WINO, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"igemm_kernel<128,128>", "igemm_kernel<128,64>", "igemm_kernel<64,128>",
                                            "igemm_kernel<64,64>", "gn_stats", "gn_temporal", "attn_spatial",
                                            "attn_temporal", "out_conv", "elementwise", "posterior",
                                            "conv3x3_frag_kernel<128,128>", "conv3x3_frag_kernel<128,64>",
-                                           "conv3x3_frag_kernel<64,128>", "conv3x3_frag_kernel<64,64>"};
+                                           "conv3x3_frag_kernel<64,128>", "conv3x3_frag_kernel<64,64>", "conv3x3_wino_kernel"};
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
 struct Profiler {
     bool on = false;
@@ -102,7 +103,8 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     const double taps = (double)g.ksz * g.ksz, cin = cin_alg ? cin_alg : g.Cin;
     const double in_pix = (double)g.nfr * g.Hs * g.Ws;
     const double bytes = 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout);
-    const int cls = igemm_tile_class(g.M, g.Cout) + (conv_halo_supported(g) ? (int)PC_CONV_128x128 : 0);
+    const int cls = conv_wino_supported(g) ? (int)PC_CONV_WINO
+                                           : igemm_tile_class(g.M, g.Cout) + (conv_halo_supported(g) ? (int)PC_CONV_128x128 : 0);
     ProfScope ps(cls, 2.0 * g.M * g.Cout * cin * taps, bytes, st);
     return launch_igemm(g, st);
 }
@@ -154,7 +156,10 @@ struct vd_engine {
     const float* W(int p) const { return wbuf + params[p].off; }
     void set_w(vd::IgemmArgs& g, int p) const {
         const int k = params[p].kind;
-        if (k == PK_CONV3F || k == PK_LINF) { g.wfrag = W(p); g.w = nullptr; } else { g.w = W(p); g.wfrag = nullptr; }
+        g.w = g.wfrag = g.wwino = nullptr;
+        if (k == PK_CONV3W) g.wwino = W(p);
+        else if (k == PK_CONV3F || k == PK_LINF) g.wfrag = W(p);
+        else g.w = W(p);
     }
 
     int add(const std::string& name, std::initializer_list<long long> shape, int kind = PK_RAW) {
@@ -167,6 +172,7 @@ struct vd_engine {
         p.kind = kind;
         p.packed = p.numel;
         if (kind == PK_STEM) p.packed = (size_t)9 * p.shape[0] * STEM_CPAD;
+        if (kind == PK_CONV3W) p.packed = (size_t)16 * p.shape[0] * p.shape[1];
         params.push_back(p);
         pidx[name] = (int)params.size() - 1;
         return (int)params.size() - 1;
@@ -208,7 +214,12 @@ int vd_engine::build() {
     p_te2w = add("time_embed.2.weight", {E, E}, PK_LINF); p_te2b = add("time_embed.2.bias", {E});
 
     // 3x3 stride-1 convs at >= 8x8 run on the halo kernel and store their weights fragment-major
-    auto k3 = [&](int res_out, int cout) { return res_out >= 8 && cout % 32 == 0 ? PK_CONV3F : PK_CONV3; };
+    //   (Winograd F(2x2,3x3) where Cout is a multiple of 64; VD_CONV=direct keeps the direct kernel for A/B runs)
+    static const bool no_wino = getenv("VD_CONV") && std::string(getenv("VD_CONV")) == "direct";
+    auto k3 = [&](int res_out, int cout) {
+        if (res_out >= 8 && cout % 64 == 0 && !no_wino) return (int)PK_CONV3W;
+        return res_out >= 8 && cout % 32 == 0 ? (int)PK_CONV3F : (int)PK_CONV3;
+    };
     auto add_res = [&](const std::string& pre, int cin, int cout, int rs) {
         ResP r; r.cin = cin; r.cout = cout;
         r.gn1w = add(pre + ".in_layers.0.weight", {cin}); r.gn1b = add(pre + ".in_layers.0.bias", {cin});
@@ -659,7 +670,11 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
         p.loaded = true;
         return 0;
     }
-    if (p.kind == PK_CONV3F) {
+    if (p.kind == PK_CONV3W) {
+        tmp.resize(p.packed);
+        pack_conv3_wino(host, tmp.data(), (int)p.shape[0], (int)p.shape[1]);
+        src = tmp.data();
+    } else if (p.kind == PK_CONV3F) {
         tmp.resize(p.numel);
         pack_conv3_frag(host, tmp.data(), (int)p.shape[0], (int)p.shape[1]);
         src = tmp.data();
@@ -842,6 +857,12 @@ int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I) {
     return 0;
 }
 
+int vd_pack_conv3_wino(const float* host_oihw, float* host_out, int O, int I) {
+    VD_REQUIRE(host_oihw && host_out && O % 64 == 0 && I % 16 == 0, "O multiple of 64, I multiple of 16");
+    pack_conv3_wino(host_oihw, host_out, O, I);
+    return 0;
+}
+
 int vd_pack_linear_frag(const float* host_w, float* host_out, int N, int K) {
     VD_REQUIRE(host_w && host_out && N % 32 == 0 && K % 32 == 0, "N and K multiples of 32");
     pack_linear_frag(host_w, host_out, N, K, N, 0);
@@ -875,14 +896,15 @@ const char* vd_profile_class_name(int i) { return i >= 0 && i < PC_COUNT ? kProf
 
 // ---- single-operator entry points ---------------------------------------------------------------
 int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, int ups, int stride,
-               int pad, int ksz, const float* w, const float* w_frag, const float* bias, const float* affA, const float* affB, int act,
+               int pad, int ksz, const float* w, const float* w_frag, const float* w_wino, const float* bias, const float* affA,
+               const float* affB, int act,
                const float* res, const float* fbias, int fbias_ld, float* out, int Cout, void* stream) {
     IgemmArgs g{};
     g.src0 = src0; g.src1 = src1; g.C0 = C0; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws; g.ups = ups;
     g.stride = stride; g.pad = pad; g.ksz = ksz;
     g.Ho = ((Hs << ups) + 2 * pad - ksz) / stride + 1;
     g.Wo = ((Ws << ups) + 2 * pad - ksz) / stride + 1;
-    g.w = w; g.wfrag = w_frag; g.bias = bias; g.affA = affA; g.affB = affB; g.act = act; g.res = res; g.res_ld = Cout;
+    g.w = w; g.wfrag = w_frag; g.wwino = w_wino; g.bias = bias; g.affA = affA; g.affB = affB; g.act = act; g.res = res; g.res_ld = Cout;
     g.fbias = fbias; g.fbias_ld = fbias_ld; g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
     return launch_igemm(g, static_cast<hipStream_t>(stream));
 }

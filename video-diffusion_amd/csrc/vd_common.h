@@ -42,7 +42,8 @@ struct IgemmArgs {
     int stride, pad, ksz;
     int Ho, Wo;
     const float* w;      // [ksz*ksz][Cout][Cin]           (generic kernel)
-    const float* wfrag;  // [tap][Cin/32][Cout/32][4][64][4] fragment-major (3x3 halo kernel), or null
+    const float* wfrag;  // [tap][Cin/32][Cout/32][4][64][4] fragment-major (3x3 halo kernel / linear), or null
+    const float* wwino;  // Winograd-transformed 3x3 weights [Cin/16][16][Cout/32][2][64][4] (conv_wino.hip), or null
     const float* bias;   // [Cout] or null
     const float* affA;   // [nfr][Cin] per-frame per-channel scale  (GroupNorm/FiLM folded), or null
     const float* affB;   // [nfr][Cin] shift
@@ -85,6 +86,10 @@ bool gemm_frag_supported(const IgemmArgs& a);
 int launch_gemm_frag(const IgemmArgs& a, int tile_class, hipStream_t s);
 void pack_linear_frag(const float* w, float* out_base, int rows, int K, int n_total, int row0);
 void pack_conv3_frag(const float* oihw, float* out, int O, int I);
+// Winograd F(2x2,3x3) path (conv_wino.hip): 2.25x fewer MFMAs than the direct 3x3 kernels
+bool conv_wino_supported(const IgemmArgs& a);
+int launch_conv_wino(const IgemmArgs& a, hipStream_t s);
+void pack_conv3_wino(const float* oihw, float* out, int O, int I);      // out: 16*O*I floats
 int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s);
 int launch_attn_temporal(const AttnTemporalArgs& a, hipStream_t s);
 
