@@ -49,13 +49,16 @@ def pack_lin_frag(w):
 
 
 def pack_wino(w):
-    """OIHW -> Winograd F(2x2,3x3) image U = G g G^T in [I/16][16][O/32][2][64][4] (library packer + closed form)."""
+    """OIHW -> Winograd F(2x2,3x3) image U = G g G^T in [I/16][16][O/32][2][64][4] (library packer + closed form).
+    Row 2 of U is stored negated: the kernel takes row 2 of B^T negated as well (one fma per value)."""
     O, I = w.shape[:2]
     src = w.contiguous().float()
     out = torch.empty(16 * O * I)
     _lib.check(_lib.lib().vd_pack_conv3_wino(_lib.ptr(src), _lib.ptr(out), O, I))
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
-    U = torch.einsum("ik,ockl,jl->ijoc", G, w.double(), G).float().reshape(16, O, I)          # [xi][co][ci]
+    U = torch.einsum("ik,ockl,jl->ijoc", G, w.double(), G).float()                            # [i][j][co][ci]
+    U[2] = -U[2]
+    U = U.reshape(16, O, I)
     ref = U.reshape(16, O // 32, 32, I // 16, 2, 2, 4).permute(3, 0, 1, 4, 5, 2, 6).reshape(-1)
     assert torch.equal(out, ref)
     return out

@@ -27,7 +27,9 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # -fno-slp-vectorize: packed-f32 VALU (v_pk_fma_f32 ...) beside MFMAs is slower than the scalar pair it replaces
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-fno-slp-vectorize",
            *[os.path.join(_CSRC, s) for s in SOURCES], "-o", SO_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))

@@ -61,14 +61,19 @@ constexpr int STEM_CPAD = 32;
 
 struct Arena {
     char* base = nullptr;
-    size_t cap = 0, used = 0;
+    size_t cap = 0, used = 0, peak = 0;
     bool dry = false;
     template <class Tp> Tp* get(size_t n) {
         size_t bytes = (n * sizeof(Tp) + 255) & ~(size_t)255;
         char* p = dry ? reinterpret_cast<char*>(0x1000) : base + used;
         used += bytes;
+        peak = std::max(peak, used);
         return reinterpret_cast<Tp*>(p);
     }
+    // stack discipline for transients: everything is stream-ordered on one stream, so a released range may be handed
+    // out again by the next get()
+    size_t mark() const { return used; }
+    void release(size_t m) { used = m; }
 };
 
 // ---- per-class kernel timing with HIP events on the launch stream (bench.py's live roofline figure)
@@ -107,6 +112,12 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
                                            : igemm_tile_class(g.M, g.Cout) + (conv_halo_supported(g) ? (int)PC_CONV_128x128 : 0);
     ProfScope ps(cls, 2.0 * g.M * g.Cout * cin * taps, bytes, st);
     return launch_igemm(g, st);
+}
+
+static int affine_act(const float* src0, const float* src1, int C0, int C, const float* A, const float* B, int N, int HW,
+                      float* y, hipStream_t st) {
+    ProfScope ps(PC_ELEMENTWISE, 0.0, 8.0 * N * HW * C, st);
+    return launch_affine_act(src0, src1, C0, C, A, B, N, HW, 1, y, st);
 }
 
 struct FwdIn {
@@ -408,12 +419,19 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     if (rc) return rc;
     float* h = ar.get<float>((size_t)N * HW * r.cout);
     const float* film = film_all + r.film_off;
-    if (!ar.dry) {
-        IgemmArgs g = conv_args(x0, x1, N, 3, 1, 0);
-        set_w(g, r.c1w); g.bias = W(r.c1b); g.affA = A1; g.affB = B1; g.act = 1;
-        g.out = h; g.ldo = r.cout; g.Cout = r.cout;
-        if (!cfg.use_scale_shift_norm) { g.fbias = film; g.fbias_ld = film_total; }    // h + emb_out (unet.py:196)
-        if ((rc = igemm_p(g, st))) return rc;
+    {   // SiLU(GroupNorm(concat(x0, x1))) once, into a transient; the conv then reads plain activations (norm.hip)
+        const size_t mk = ar.mark();
+        float* a1 = ar.get<float>((size_t)N * HW * cin);
+        if (!ar.dry) {
+            if ((rc = affine_act(x0.p, s1, x0.C, cin, A1, B1, N, HW, a1, st))) return rc;
+            Tens at{a1, cin, H};
+            IgemmArgs g = conv_args(at, nullptr, N, 3, 1, 0);
+            set_w(g, r.c1w); g.bias = W(r.c1b);
+            g.out = h; g.ldo = r.cout; g.Cout = r.cout;
+            if (!cfg.use_scale_shift_norm) { g.fbias = film; g.fbias_ld = film_total; }    // h + emb_out (unet.py:196)
+            if ((rc = igemm_p(g, st))) return rc;
+        }
+        ar.release(mk);
     }
     rc = gn_fold(h, nullptr, r.cout, r.cout, N, HW, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr,
                  film_total, st, ar, &A2, &B2);
@@ -431,12 +449,18 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         VD_REQUIRE(x1 == nullptr, "identity skip over a concatenated input");
     }
     float* o = ar.get<float>((size_t)N * HW * r.cout);
-    if (!ar.dry) {
-        Tens ht{h, r.cout, H};
-        IgemmArgs g = conv_args(ht, nullptr, N, 3, 1, 0);
-        set_w(g, r.c2w); g.bias = W(r.c2b); g.affA = A2; g.affB = B2; g.act = 1;
-        g.res = skip; g.res_ld = r.cout; g.out = o; g.ldo = r.cout; g.Cout = r.cout;
-        if ((rc = igemm_p(g, st))) return rc;
+    {
+        const size_t mk = ar.mark();
+        float* a2 = ar.get<float>((size_t)N * HW * r.cout);
+        if (!ar.dry) {
+            if ((rc = affine_act(h, nullptr, r.cout, r.cout, A2, B2, N, HW, a2, st))) return rc;
+            Tens ht{a2, r.cout, H};
+            IgemmArgs g = conv_args(ht, nullptr, N, 3, 1, 0);
+            set_w(g, r.c2w); g.bias = W(r.c2b);
+            g.res = skip; g.res_ld = r.cout; g.out = o; g.ldo = r.cout; g.Cout = r.cout;
+            if ((rc = igemm_p(g, st))) return rc;
+        }
+        ar.release(mk);
     }
     *out = Tens{o, r.cout, H};
     return 0;
@@ -597,7 +621,7 @@ int vd_engine::ensure_ws(int B, int T) {
     FwdIn fi{}; fi.B = B; fi.T = T;
     int rc = forward(fi, nullptr, dry);
     if (rc) return rc;
-    const size_t need = dry.used + (size_t)B * T * 3 * cfg.image_size * cfg.image_size * sizeof(float) + 4096;
+    const size_t need = dry.peak + (size_t)B * T * 3 * cfg.image_size * cfg.image_size * sizeof(float) + 4096;
     if (need > ws_cap) {
         if (ws) VD_HIP(hipFree(ws));
         ws = nullptr; ws_cap = 0;
@@ -750,7 +774,7 @@ int vd_workspace_bytes(vd_engine* e, int B, int T, long long* bytes) {
     FwdIn fi{}; fi.B = B; fi.T = T;
     int rc = e->forward(fi, nullptr, dry);
     if (rc) return rc;
-    *bytes = (long long)dry.used;
+    *bytes = (long long)dry.peak;
     return 0;
 }
 

@@ -128,6 +128,39 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------ y = silu(x*A[n][c] + B[n][c]) over a virtual concat
+// GroupNorm(+FiLM)+SiLU materialised once for the 3x3 convs.  The conv kernels can apply the same affine + SiLU in their
+// operand load, but every block that touches a pixel then repeats it (Cout/64 column blocks x the halo overlap: 2.5x to
+// 12x), and on gfx950 VALU work does not hide behind fp32 MFMAs (tools/mfma_peak.hip): one HBM-bound pass is cheaper.
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ src0, const float* __restrict__ src1,
+                                                         int C0_4, int C4, const float* __restrict__ affA,
+                                                         const float* __restrict__ affB, int HW, size_t total4, int act,
+                                                         float* __restrict__ y) {
+    const int C1_4 = C4 - C0_4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / (unsigned)C4;
+        const int c4 = (int)(i - pix * C4);
+        const size_t n = pix / (unsigned)HW;
+        const f32x4 v = c4 < C0_4 ? reinterpret_cast<const f32x4*>(src0)[pix * C0_4 + c4]
+                                  : reinterpret_cast<const f32x4*>(src1)[pix * C1_4 + (c4 - C0_4)];
+        const f32x4 A = reinterpret_cast<const f32x4*>(affA)[n * C4 + c4];
+        const f32x4 B = reinterpret_cast<const f32x4*>(affB)[n * C4 + c4];
+        f32x4 r = v * A + B;
+        if (act) { r.x = silu_f(r.x); r.y = silu_f(r.y); r.z = silu_f(r.z); r.w = silu_f(r.w); }
+        reinterpret_cast<f32x4*>(y)[i] = r;
+    }
+}
+
+int launch_affine_act(const float* src0, const float* src1, int C0, int C, const float* affA, const float* affB, int nfr,
+                      int HW, int act, float* y, hipStream_t s) {
+    VD_REQUIRE(C % 4 == 0 && C0 % 4 == 0 && (src1 != nullptr || C0 == C), "affine_act: channel counts");
+    const size_t total4 = (size_t)nfr * HW * C / 4;
+    const int grid = (int)std::min<size_t>((total4 + 255) / 256, 16384);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid), dim3(256), 0, s, src0, src1, C0 / 4, C / 4, affA, affB, HW, total4, act, y);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y,
                         hipStream_t s) {
     const size_t total4 = (size_t)nfr * HW * C / 4;

@@ -103,6 +103,9 @@ int gn_stats_split(int nfr, int HW, int C);
 int launch_gn_affine(const double* part, int split, double count, const float* gamma, const float* beta,
                      const float* film, int film_ld, int nfr, int C, float* affA, float* affB, hipStream_t s);
 // y = x*A[n][c] + B[n][c]  (materialised normalisation for the attention residual, unet.py:474,538)
+// y[n][p][0..C) = silu?(concat(src0, src1)[n][p][c] * A[n][c] + B[n][c])
+int launch_affine_act(const float* src0, const float* src1, int C0, int C, const float* affA, const float* affB, int nfr,
+                      int HW, int act, float* y, hipStream_t s);
 int launch_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y,
                         hipStream_t s);
 // Temporal GroupNorm: stats over (T x C/32) for every (b, pixel); writes the normalised tensor.
