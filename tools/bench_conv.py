@@ -53,6 +53,11 @@ def main():
         res = torch.rand(nfr, Ho, Ho, Cout, device="cuda", generator=g) if pro and k == 3 else None
 
         wf = ww = None
+        if k == 3 and stride == 1 and Cout % 64 == 0 and Cin % 32 == 0 and not os.environ.get("VD_NO_WINO"):
+            # the engine's form of these layers: GroupNorm+SiLU and the skip concat are materialised by one elementwise
+            # pass (norm.hip affine_act_kernel), the Winograd kernel reads one plain tensor
+            x0 = torch.rand(nfr, H, H, Cin, device="cuda", generator=g) - 0.5
+            x1, C0, A, B, pro = None, Cin, None, None, 0
         if k == 1:
             A = B = None                 # linear layers of the engine use SiLU-only prologues (time_embed, FiLM)
         if stride == 1 and not os.environ.get("VD_NO_HALO"):

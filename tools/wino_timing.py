@@ -17,21 +17,19 @@ L.vd_debug_wino_stamps.restype = ctypes.c_int
 L.vd_debug_wino_stamps.argtypes = [ctypes.c_void_p]
 for nfr, C0, C1, Cout, H, pro in SHAPES:
     Cin = C0 + C1
-    x0 = torch.rand(nfr, H, H, C0, device="cuda") - 0.5
-    x1 = torch.rand(nfr, H, H, C1, device="cuda") - 0.5 if C1 else None
+    x0 = torch.rand(nfr, H, H, Cin, device="cuda") - 0.5
     ww = torch.rand(16 * Cout * Cin, device="cuda") * 0.05
     b = torch.rand(Cout, device="cuda")
-    A = torch.rand(nfr, Cin, device="cuda") + 0.5
-    B = torch.rand(nfr, Cin, device="cuda") - 0.5
     res = torch.rand(nfr, H, H, Cout, device="cuda")
     out = torch.empty(nfr, H, H, Cout, device="cuda")
     st = (ctypes.c_ulonglong * 8)()
     for _ in range(3):
-        _lib.check(L.vd_op_conv(_lib.ptr(x0), _lib.ptr(x1), C0, Cin, nfr, H, H, 0, 1, 1, 3, None, None, _lib.ptr(ww), _lib.ptr(b),
-                                _lib.ptr(A), _lib.ptr(B), pro, _lib.ptr(res), None, 0, _lib.ptr(out), Cout, _lib.current_stream()))
+        _lib.check(L.vd_op_conv(_lib.ptr(x0), None, Cin, Cin, nfr, H, H, 0, 1, 1, 3, None, None, _lib.ptr(ww), _lib.ptr(b),
+                                None, None, 0, _lib.ptr(res), None, 0, _lib.ptr(out), Cout, _lib.current_stream()))
         torch.cuda.synchronize()
     assert L.vd_debug_wino_stamps(st) == 0
     t = list(st)
     nch = Cin // 16
-    print(f"Cin {Cin:4d} Cout {Cout:4d} H {H:2d}: prologue {t[1]-t[0]:7d}  loop {t[2]-t[1]:8d} ({(t[2]-t[1])/nch:7.0f}/chunk, ideal 8192)"
-          f"  epilogue {t[3]-t[2]:7d}  total {t[3]-t[0]:8d}", flush=True)
+    print(f"Cin {Cin:4d} Cout {Cout:4d} H {H:2d}: prologue {t[1]-t[0]:6d}  loop {t[2]-t[1]:8d} ({(t[2]-t[1])/nch:6.0f}/chunk, ideal 8192)"
+          f"  epilogue {t[3]-t[2]:6d} = addr+res loads {t[4]-t[2]} + barrier {t[5]-t[4]} + Z write {t[6]-t[5]} + barrier {t[7]-t[6]}"
+          f" + Z read/store {t[3]-t[7]}   total {t[3]-t[0]:8d}", flush=True)

@@ -31,13 +31,11 @@ struct WinoGeom {
 };
 
 #ifdef VD_WINO_TIMING
-// kernel-experiment builds only (tools/wino_timing.py): shader-clock stamps of the first and the last block, wave 0
+// kernel-experiment builds only (tools/wino_timing.py): shader-clock stamps of block 0, wave 0
 __device__ unsigned long long g_wino_stamp[8];
 #define WINO_STAMP(i)                                                                                                  \
     do {                                                                                                               \
         if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_wino_stamp[i] = __builtin_readcyclecounter();    \
-        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1)                             \
-            g_wino_stamp[4 + i] = __builtin_readcyclecounter();                                                        \
     } while (0)
 extern "C" int vd_debug_wino_stamps(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_stamp), sizeof(g_wino_stamp));
@@ -49,11 +47,14 @@ extern "C" int vd_debug_wino_stamps(unsigned long long* host_out) {
 #define VD_WINO_SKIP 0     // kernel-experiment builds: bit 0 no patch staging, 1 no fragment transform, 2 no weight loads,
 #endif                     // 3 no barrier, 4 no patch loads, 5 no fragment reads (results are then wrong; timing only)
 
-__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
-__device__ __forceinline__ void pin1(float& v) { asm volatile("" : "+v"(v)); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// PRO: operand prologue (affine + SiLU) compiled in/out; TF4: four 8x8 frames per block (else one frame, 16x16 pixels).
-template <bool PRO, bool TF4>
+// TF4: four 8x8 frames per block (else one frame, 16x16 pixels).  The input is plain activations of ONE tensor: the
+// engine materialises GroupNorm+SiLU (and the skip concat) first (norm.hip affine_act_kernel), because on gfx950 VALU
+// work does not hide behind fp32 MFMAs (tools/mfma_peak.hip: every VALU instruction beside v_mfma_f32_32x32x2_f32 costs
+// its 4 cycles; SALU, LDS and memory issue are free) -- so the loop below is written to contain as few VALU
+// instructions as possible: 16 packed ops per MFMA group for the fragment transform and nothing else.
+template <bool TF4>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoGeom g) {
     constexpr int TTL = TF4 ? 2 : 3, TT = 1 << TTL, P = 2 * TT + 2;   // tiles per dim per frame, patch width
     constexpr int NX = TF4 ? 7 : 6;            // patch float4 per thread
@@ -71,134 +72,113 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
     const int f0 = bx * (TF4 ? 4 : 1);
     const int ox0 = bxx * 2 * TT, oy0 = byy * 2 * TT;               // output-pixel origin of the block
     const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
-    const int C1 = a.Cin - a.C0;
     const int nchunk = a.Cin / WKC, ncoblk = a.Cout >> 5;
     const int cob0 = blockIdx.y * 2;                                 // BN = 64 = 2 cout blocks
 
-    // ---- patch staging.  TF4: wave f stages frame f (one affine pair per thread); else the block's one frame.
-    // thread -> patch pixels sp0 + SS*e of its frame slot, channel quad lq
+    // ---- patch staging.  TF4: wave f stages frame f; else the block's one frame.  Thread -> patch pixels sp0 + SS*e of
+    // its frame slot, channel quad lq.  The source is read through a buffer descriptor: elements of the zero padding
+    // (and of frames past the end) get an out-of-range offset and the load itself returns zeros -- no select.
     const int lq = tid & 3;
     const int sf = TF4 ? wi : 0;
     const int sp0 = (TF4 ? lane : tid) >> 2;
-    const int n_st = min(f0 + sf, a.nfr - 1);
-    int so[NX];                                                       // source pixel index (clamped)
-    unsigned zmask = 0;                                               // bit e: element is zero padding
+    unsigned xo[NX];                                                  // byte offset of (pixel, channel lq*4) in the source
 #pragma unroll
     for (int e = 0; e < NX; ++e) {
         const int pl = sp0 + SS * e;
         const int py = pl / P, px = pl - py * P;
         const int ly = oy0 + py - 1, lx = ox0 + px - 1;
         const bool in = pl < P * P && f0 + sf < a.nfr && ly >= 0 && ly < Hl && lx >= 0 && lx < Wl;
-        so[e] = in ? (n_st * a.Hs + (ly >> a.ups)) * a.Ws + (lx >> a.ups) : 0;
-        if (!in) zmask |= 1u << e;
+        xo[e] = in ? (unsigned)(((f0 + sf) * a.Hs + (ly >> a.ups)) * a.Ws + (lx >> a.ups)) * (unsigned)(a.Cin * 4) + lq * 16u
+                   : 0x80000000u;
     }
+    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
     const int xw = (sf * FS + sp0) * WLD + lq * 4;                   // LDS float offset of element 0
-    f32x4 rx[NX], affa, affb;
+    f32x4 rx[NX];
     auto x_load = [&](int chunk) {
-        const int c = chunk * WKC;                                    // uniform: scalar base + 32-bit lane offsets
-        const bool second = c >= a.C0;
-        const char* base = reinterpret_cast<const char*>(second ? a.src1 + (c - a.C0) : a.src0 + c);
-        const int ld = second ? C1 : a.C0;
 #pragma unroll
         for (int e = 0; e < NX; ++e)
-            rx[e] = *reinterpret_cast<const f32x4*>(base + (unsigned)(so[e] * ld + lq * 4) * 4u);
-        if constexpr (PRO) {
-            const unsigned ao = (unsigned)(n_st * a.Cin + lq * 4) * 4u;
-            affa = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.affA + c) + ao);
-            affb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.affB + c) + ao);
-        }
+            rx[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xo[e], chunk * (WKC * 4), 0));
     };
-    // whole elements (prologue of the block) ...
-    auto x_store = [&](float* Xd) {
+    auto x_store = [&](int buf, int e0, int e1) {                     // the buffers are padded to NX*SS pixels: no range branch
 #pragma unroll
-        for (int e = 0; e < NX; ++e) {
-            f32x4 v = rx[e];                           // no pixel-range branch: the buffers are padded to NX*SS pixels
-            if constexpr (PRO) {
-                v = v * affa + affb;
-                v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
-            }
-            if ((zmask >> e) & 1) v = f32x4{0.f, 0.f, 0.f, 0.f};      // zero padding AFTER norm + activation
-            *reinterpret_cast<f32x4*>(Xd + xw + e * SS * WLD) = v;
-        }
-    };
-    // ... and ONE component of one element, the unit of staging work placed in an MFMA gap of the main loop (issue
-    // cost ~44 cycles of the 56 a 64-cycle MFMA leaves: fma 4, mul 4, exp 8, add 4, rcp 8, mul 4, select 4, + hazards).
-    // pin() on the way in and out nails the arithmetic to this point of the program: pure VALU work is otherwise
-    // hoisted to where its inputs are born (guide 5.7 item 3).
-    f32x4 sv;
-    auto x_piece = [&](float* Xd, int e, int c) {
-        if constexpr (PRO) {
-            float x = rx[e][c];
-            pin1(x);
-            x = silu_f(x * affa[c] + affb[c]);
-            if ((zmask >> e) & 1) x = 0.f;
-            pin1(x);
-            sv[c] = x;
-            if (c == 3) *reinterpret_cast<f32x4*>(Xd + xw + e * SS * WLD) = sv;
-        } else if (c == 0) {                           // pre-activated input (the engine's path): select + store only
-            f32x4 v = rx[e];
-            pin(v);
-            if ((zmask >> e) & 1) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(Xd + xw + e * SS * WLD) = v;
-        }
+        for (int e = 0; e < NX; ++e)
+            if (e >= e0 && e < e1) *reinterpret_cast<f32x4*>(smem + xw + buf * XBUF + e * SS * WLD) = rx[e];
     };
 
     // ---- A fragments: lane (tile m*32+lr, k-half lh); row wi of B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].
     // Row 2 is taken negated (d1 - d2; pack_conv3_wino negates U's row 2 to match) so that every row is
-    // d[r0] + sg * d[r1]: one fma per value
+    // d[r0] + sg * d[r1]: one (packed) fma per value pair
     const int r0 = wi == 0 ? 0 : 1, r1 = wi == 3 ? 3 : 2;
     const float sg = wi == 1 ? 1.f : -1.f;
-    int xb[2];                                                      // LDS float offset of the tile's patch origin
+    int xb[2];                                                      // LDS float offset of the tile's patch origin ...
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int t = m * 32 + lr;
         const int tx = t & (TT - 1), ty = (t >> TTL) & (TT - 1), f = t >> (2 * TTL);
         xb[m] = (f * FS + 2 * ty * P + 2 * tx) * WLD + lh * 4;
     }
-    const int rowo0 = r0 * P * WLD, rowo1 = r1 * P * WLD;
-    f32x4 raw[2][8], frag[2][4];
-    auto a_read = [&](int slot, const float* X, int m, int kg) {
-        const float* p = X + xb[m] + kg * 8;
+    int ab[2][2];                                                    // ... + the two patch rows this wave combines
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { ab[m][0] = xb[m] + r0 * P * WLD; ab[m][1] = xb[m] + r1 * P * WLD; }
+    f32x4 raw[2][8];
+    f32x2 fragl[2][4], fragh[2][4];                                  // channel pairs (0,1) and (2,3) of the k-quad
+    const f32x2 sg2 = {sg, sg};
+    // buf: which LDS patch buffer (compile-time after the 2x unroll of the chunk loop, so every address below is one
+    // of four lane-invariant VGPRs plus an instruction offset)
+    auto a_read = [&](int slot, int buf, int m, int kg) {
+        const float* p0 = smem + ab[m][0] + buf * XBUF + kg * 8;
+        const float* p1 = smem + ab[m][1] + buf * XBUF + kg * 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            raw[slot][j] = *reinterpret_cast<const f32x4*>(p + rowo0 + j * WLD);
-            raw[slot][4 + j] = *reinterpret_cast<const f32x4*>(p + rowo1 + j * WLD);
+            raw[slot][j] = *reinterpret_cast<const f32x4*>(p0 + j * WLD);
+            raw[slot][4 + j] = *reinterpret_cast<const f32x4*>(p1 + j * WLD);
         }
     };
-    auto a_transform = [&](int slot) {          // raw[slot] -> frag[slot]
-        f32x4 t[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = raw[slot][4 + j] * sg + raw[slot][j];
-        frag[slot][0] = t[0] - t[2]; frag[slot][1] = t[1] + t[2]; frag[slot][2] = t[2] - t[1]; frag[slot][3] = t[1] - t[3];
+    // raw[slot] -> frag[slot]: t_j = d[r1][j]*sg + d[r0][j], then the column combination of B: 8 packed fma + 8 packed
+    // add for 32 MFMAs' worth of A operands.  Written as asm because hipcc scalarises the <4 x float> form (each value
+    // is consumed by one MFMA as a scalar) and only partly re-packs it; the halves are independent, one block each.
+    // The blocks sit a whole MFMA group ahead of the first reader of their results (below), so no VALU->MFMA operand
+    // hazard can arise that the assembler-level hazard pass does not see.
+    auto half_transform = [&](f32x2& f0, f32x2& f1, f32x2& f2, f32x2& f3, f32x2 a0, f32x2 a1, f32x2 a2, f32x2 a3, f32x2 b0,
+                              f32x2 b1, f32x2 b2, f32x2 b3) {
+        asm volatile(
+            "v_pk_fma_f32 %4, %8, %12, %4\n\t"
+            "v_pk_fma_f32 %5, %9, %12, %5\n\t"
+            "v_pk_fma_f32 %6, %10, %12, %6\n\t"
+            "v_pk_fma_f32 %7, %11, %12, %7\n\t"
+            "v_pk_add_f32 %0, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %1, %5, %6\n\t"
+            "v_pk_add_f32 %2, %6, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %3, %5, %7 neg_lo:[0,1] neg_hi:[0,1]"
+            : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+            : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(sg2));
     };
-    // the same in six pieces (4 + 4 + 4 + 4 + 8 + 8 VALU): 0..3 row sums, 4..5 the fragments
-    f32x4 tcol[4];
-    auto a_piece = [&](int slot, int i) {
-        if (i < 4) {
-            pin(raw[slot][i]); pin(raw[slot][4 + i]);
-            tcol[i] = raw[slot][4 + i] * sg + raw[slot][i];
-            pin(tcol[i]);
-        } else if (i == 4) {
-            frag[slot][0] = tcol[0] - tcol[2]; frag[slot][1] = tcol[1] + tcol[2];
-            pin(frag[slot][0]); pin(frag[slot][1]);
-        } else {
-            frag[slot][2] = tcol[2] - tcol[1]; frag[slot][3] = tcol[1] - tcol[3];
-            pin(frag[slot][2]); pin(frag[slot][3]);
-        }
+    auto lo2 = [](const f32x4& v) { return f32x2{v.x, v.y}; };
+    auto hi2 = [](const f32x4& v) { return f32x2{v.z, v.w}; };
+    auto a_transform = [&](int s_) {
+        half_transform(fragl[s_][0], fragl[s_][1], fragl[s_][2], fragl[s_][3], lo2(raw[s_][0]), lo2(raw[s_][1]), lo2(raw[s_][2]),
+                       lo2(raw[s_][3]), lo2(raw[s_][4]), lo2(raw[s_][5]), lo2(raw[s_][6]), lo2(raw[s_][7]));
+        half_transform(fragh[s_][0], fragh[s_][1], fragh[s_][2], fragh[s_][3], hi2(raw[s_][0]), hi2(raw[s_][1]), hi2(raw[s_][2]),
+                       hi2(raw[s_][3]), hi2(raw[s_][4]), hi2(raw[s_][5]), hi2(raw[s_][6]), hi2(raw[s_][7]));
     };
 
-    // ---- B fragments: U[chunk][xi = 4*wi + j][cob][kg][lane][4]: scalar base per (chunk, j, n) + lane offset
-    const int cobn[2] = {cob0, min(cob0 + 1, ncoblk - 1)};
-    const unsigned ulane = lane * 16u;
+    // ---- B fragments: U[chunk][xi = 4*wi + j][cob][kg][lane][4] through a buffer descriptor: one lane offset per
+    // (j, n), everything else (chunk, wave row, k-group) in the scalar offset -- no address arithmetic in the loop
+    const auto usrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wwino), 0, 16 * a.Cout * a.Cin * 4, 0x00020000);
+    const int ustride = 16 * ncoblk * 2048, uwave = wi * 4 * ncoblk * 2048;
+    unsigned bo[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bo[j][n] = (unsigned)(j * ncoblk + min(cob0 + n, ncoblk - 1)) * 2048u + lane * 16u;
     f32x4 bfr[2][4][2];
     auto b_load = [&](int slot, int chunk, int kg) {
+        const int so = chunk * ustride + uwave + kg * 1024;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const float* ub = a.wwino + ((((size_t)chunk * 16 + wi * 4 + j) * ncoblk + cobn[n]) * 2 + kg) * 256;
-                bfr[slot][j][n] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ub) + ulane);
-            }
+            for (int n = 0; n < 2; ++n)
+                bfr[slot][j][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(usrc, bo[j][n], so, 0));
     };
 
     f32x16 acc[2][4][2];                                            // [m][j][n]
@@ -213,25 +193,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
 
     // ---- software pipeline over the 4 MFMA groups (kg, m) = (0,0) (0,1) (1,0) (1,1) of each chunk; with one wave per
     // SIMD nothing else hides a stall, so every operand is requested >= 2 groups (>= 4096 matrix-pipe cycles) ahead:
-    //   patch rows (HBM)      x_load(c+2)   before group 2 of chunk c   -> staged to LDS in groups 0,1 of chunk c+1
+    //   patch rows (HBM)      x_load(c+2)   before group 2 of chunk c   -> written to LDS in groups 0,1 of chunk c+1
     //   weights (L2)          b_load        two groups before use
     //   A fragments (LDS)     a_read        two groups before use, transformed one group before use
     // The one barrier per chunk sits between groups 1 and 2: the next patch is complete and nobody reads the current
     // one any more, so groups 2,3 already fetch the next chunk's first fragments.
     x_load(0);
     b_load(0, 0, 0);
-    x_store(smem);
+    x_store(0, 0, NX);
     x_load(min(1, nchunk - 1));
     __syncthreads();
-    a_read(0, smem, 0, 0);
-    a_read(1, smem, 1, 0);
+    a_read(0, 0, 0, 0);
+    a_read(1, 0, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
     a_transform(0);
     WINO_STAMP(1);
 
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
+    // one chunk: buf = the patch buffer it reads (the other one is being filled)
+    auto chunk_body = [&](int chunk, int buf) {
         const int n1 = min(chunk + 1, nchunk - 1), n2 = min(chunk + 2, nchunk - 1);
-        const float* Xc = smem + (chunk & 1) * XBUF;
-        float* Xn = smem + ((chunk + 1) & 1) * XBUF;
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
             const int kg = gi >> 1, m = gi & 1;
@@ -242,36 +222,40 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
                 if (!(VD_WINO_SKIP & 16)) x_load(n2);
             }
             if (!(VD_WINO_SKIP & 32)) {
-                if (gi < 2) a_read(gi & 1, Xc, gi & 1, 1);         // group gi+2 of this chunk
-                else a_read(gi & 1, Xn, gi & 1, 0);                // group gi-2 of the next chunk
+                if (gi < 2) a_read(gi & 1, buf, gi & 1, 1);        // group gi+2 of this chunk
+                else a_read(gi & 1, buf ^ 1, gi & 1, 0);           // group gi-2 of the next chunk
             }
             __builtin_amdgcn_sched_barrier(0);
-            // this group's 32 MFMAs, each followed by one hand-placed piece of VALU work and a full scheduling barrier:
-            // with one wave per SIMD nothing else fills the matrix pipe, so the next group's fragment transform (even
-            // gaps 2..12) and, in groups 0,1, half of the next chunk's patch staging (odd gaps) sit in the MFMA shadows
-            constexpr int XH = (NX + 1) / 2;                        // patch elements staged in group 0; the rest in group 1
+            // the NEXT group's fragment transform (one VALU burst: VALU work does not overlap fp32 MFMAs, and every
+            // MFMA<->VALU switch costs ~8 cycles more), (groups 0,1) half of the next patch's LDS writes, then this
+            // group's 32 MFMAs; the barriers keep the requests above from sinking towards their consumers
+            if (!(VD_WINO_SKIP & 2)) a_transform((gi + 1) & 1);
+            if (!(VD_WINO_SKIP & 1)) {
+                if (gi == 0) x_store(buf ^ 1, 0, (NX + 1) / 2);
+                if (gi == 1) x_store(buf ^ 1, (NX + 1) / 2, NX);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
                 const int e = k >> 3, j = (k >> 1) & 3, n = k & 1;
-                acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[gi & 1][j][e], bfr[kg][j][n][e], acc[m][j][n], 0, 0, 0);
-                if ((k & 1) == 0 && k >= 2 && k <= 12 && !(VD_WINO_SKIP & 2)) a_piece((gi + 1) & 1, (k - 2) >> 1);
-                if ((k & 1) == 1 && gi < 2) {
-                    const int i = k >> 1;                           // 0..15: component i&3 of element i>>2 of this half
-                    const int el = (gi == 0 ? 0 : XH) + (i >> 2);
-                    if (el < (gi == 0 ? XH : NX) && !(VD_WINO_SKIP & 1)) x_piece(Xn, el, i & 3);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                const float av = e < 2 ? fragl[gi & 1][j][e] : fragh[gi & 1][j][e - 2];
+                acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfr[kg][j][n][e], acc[m][j][n], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    for (int chunk = 0; chunk < nchunk; chunk += 2) {               // nchunk is even (conv_wino_supported)
+        chunk_body(chunk, 0);
+        chunk_body(chunk + 1, 1);
     }
     WINO_STAMP(2);
 
     // ---- output transform.  A^T = [[1,1,1,0],[0,1,-1,-1]].  Wave-local: Z[q] = sum_j M[wi][j] A[j][q]; the sum over
-    // i crosses waves through LDS; wave (p, q) then owns output pixel (p, q) of every tile.
+    // i crosses waves through LDS; wave (p, q) then owns output pixel (p, q) of every tile.  Everything below is
+    // branch-free: rows of frames past the end get an out-of-range buffer offset (loads return 0, stores are dropped).
     const int p = wi >> 1, q = wi & 1;
     const int co0 = blockIdx.y * 64 + lr;
-    int opix[2][16];
-    unsigned okm[2] = {0, 0};
+    unsigned oo[2][16];                                              // byte offset of (pixel, cout co0) in out / res
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -279,23 +263,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
             const int t = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;        // C/D row = tile
             const int tx = t & (TT - 1), ty = (t >> TTL) & (TT - 1), f = t >> (2 * TTL);
             const int nf = f0 + f;
-            if (nf < a.nfr) okm[m] |= 1u << r;
-            opix[m][r] = (min(nf, a.nfr - 1) * Hl + oy0 + 2 * ty + p) * Wl + ox0 + 2 * tx + q;
+            const unsigned o = (unsigned)(((nf * Hl + oy0 + 2 * ty + p) * Wl + ox0 + 2 * tx + q) * a.ldo + co0) * 4u;
+            oo[m][r] = nf < a.nfr ? o : 0x80000000u;
         }
-    // the residual rows are requested before the exchange so their latency hides behind it
+    const int obytes = a.nfr * Hl * Wl * a.ldo * 4;
+    const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
+    // the residual rows (same layout as the output: res_ld == ldo) and the bias are requested before the exchange so
+    // their latency hides behind it
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
     f32x16 rv[2][2];
-    if (a.res) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    rv[m][n][r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.res) +
-                                                                  (unsigned)(opix[m][r] * a.res_ld + co0 + n * 32) * 4u);
-    }
+            for (int r = 0; r < 16; ++r) rv[m][n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], n * 128, 0));
+    float bv[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) bv[n] = a.bias ? a.bias[co0 + n * 32] : 0.f;
+    WINO_STAMP(4);
     __syncthreads();                                                 // every wave is done with the patch buffers
-    // Z exchange layout in LDS: [i 4][q 2][m 2][n 2][reg16/4][lane 64][4]  (128 KB)
+    WINO_STAMP(5);
+    // Z exchange layout in LDS: [plane = 2i + q][m 2][n 2][reg16/4][lane 64][4]  (8 planes of 16 KB)
     float* Zs = smem;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -311,8 +300,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
                 *reinterpret_cast<f32x4*>(d1) = f32x4{z1[4 * c4], z1[4 * c4 + 1], z1[4 * c4 + 2], z1[4 * c4 + 3]};
             }
         }
+    WINO_STAMP(6);
     __syncthreads();
-    // wave (p, q): Y[p][q] = sum_i A^T[p][i] Z[i][q]; p = 0: Z0+Z1+Z2, p = 1: Z1-Z2-Z3
+    WINO_STAMP(7);
+    // wave (p, q): Y[p][q] = sum_i A^T[p][i] Z[i][q] = Z[p] + sgn * (Z[p+1] + Z[p+2]), sgn = +1 (p = 0) / -1 (p = 1);
+    // Z[p + k][q] is plane wi + 2k
+    const float sgn = p ? -1.f : 1.f;
+    const float* zw = Zs + wi * 4096 + lane * 4;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -320,26 +314,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
             f32x16 y;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                auto zl = [&](int i) {
-                    return *reinterpret_cast<const f32x4*>(Zs + (((((i * 2 + q) * 2 + m) * 2 + n) * 4 + c4) * 64 + lane) * 4);
-                };
-                const f32x4 v = p == 0 ? zl(0) + zl(1) + zl(2) : zl(1) - zl(2) - zl(3);
+                const float* zp = zw + ((m * 2 + n) * 4 + c4) * 256;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(zp) +
+                                (*reinterpret_cast<const f32x4*>(zp + 2 * 4096) + *reinterpret_cast<const f32x4*>(zp + 4 * 4096)) * sgn;
                 y[4 * c4] = v.x; y[4 * c4 + 1] = v.y; y[4 * c4 + 2] = v.z; y[4 * c4 + 3] = v.w;
             }
-            const int co = co0 + n * 32;
-            const float bv = a.bias ? a.bias[co] : 0.f;
-            if (a.res) y += rv[m][n];
+            y += rv[m][n];
             if (a.fbias) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int t = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    y[r] += a.fbias[(size_t)min(f0 + (t >> (2 * TTL)), a.nfr - 1) * a.fbias_ld + co];
+                    y[r] += a.fbias[(size_t)min(f0 + (t >> (2 * TTL)), a.nfr - 1) * a.fbias_ld + co0 + n * 32];
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((okm[m] >> r) & 1)
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(a.out) + (unsigned)(opix[m][r] * a.ldo + co) * 4u) = y[r] + bv;
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[r] + bv[n]), osrc, oo[m][r], n * 128, 0);
         }
     WINO_STAMP(3);
 }
@@ -349,10 +338,10 @@ static bool wino_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 bool conv_wino_supported(const IgemmArgs& a) {
     const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
     return a.wwino != nullptr && a.ksz == 3 && a.stride == 1 && a.pad == 1 && Hl == Wl && wino_pow2(Hl) && Hl >= 8 &&
-           a.Cout % 64 == 0 && a.Cin % WKC == 0 && a.C0 % WKC == 0 && (a.affA != nullptr) == (a.act != 0) &&
-           // 32-bit byte offsets into the sources / residual / output
-           (size_t)a.nfr * a.Hs * a.Ws * std::max(a.C0, a.Cin - a.C0) < (1u << 30) && (size_t)a.nfr * a.Cin < (1u << 30) &&
-           (size_t)a.nfr * Hl * Wl * std::max(a.ldo, a.res ? a.res_ld : 0) < (1u << 30);
+           a.Cout % 64 == 0 && a.Cin % (2 * WKC) == 0 && a.src1 == nullptr && a.C0 == a.Cin && a.affA == nullptr && a.act == 0 &&
+           // 32-bit byte offsets into the source (bit 31 marks the padding) / residual / output
+           (size_t)a.nfr * a.Hs * a.Ws * a.Cin < (1u << 29) &&
+           (size_t)a.nfr * Hl * Wl * a.ldo < (1u << 29) && (a.res == nullptr || a.res_ld == a.ldo);
 }
 
 int launch_conv_wino(const IgemmArgs& a, hipStream_t s) {
@@ -364,23 +353,15 @@ int launch_conv_wino(const IgemmArgs& a, hipStream_t s) {
     const size_t lds = std::max((size_t)2 * (g.TF == 4 ? 7 : 6) * 64 * WLD * sizeof(float), (size_t)4 * 2 * 2 * 2 * 4 * 64 * 4 * sizeof(float));
     static bool attr = false;
     if (!attr) {
-        const void* fns[4] = {reinterpret_cast<const void*>(&conv3x3_wino_kernel<true, true>),
-                              reinterpret_cast<const void*>(&conv3x3_wino_kernel<true, false>),
-                              reinterpret_cast<const void*>(&conv3x3_wino_kernel<false, true>),
-                              reinterpret_cast<const void*>(&conv3x3_wino_kernel<false, false>)};
+        const void* fns[2] = {reinterpret_cast<const void*>(&conv3x3_wino_kernel<true>),
+                              reinterpret_cast<const void*>(&conv3x3_wino_kernel<false>)};
         for (const void* f : fns) VD_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     const int fgroups = (a.nfr + g.TF - 1) / g.TF;
     dim3 grid(g.tiles_x * g.tiles_y * fgroups, a.Cout / 64);
-    const bool tf4 = g.TF == 4;
-    if (a.affA) {
-        if (tf4) hipLaunchKernelGGL((conv3x3_wino_kernel<true, true>), grid, dim3(256), lds, s, a, g);
-        else hipLaunchKernelGGL((conv3x3_wino_kernel<true, false>), grid, dim3(256), lds, s, a, g);
-    } else {
-        if (tf4) hipLaunchKernelGGL((conv3x3_wino_kernel<false, true>), grid, dim3(256), lds, s, a, g);
-        else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false>), grid, dim3(256), lds, s, a, g);
-    }
+    if (g.TF == 4) hipLaunchKernelGGL((conv3x3_wino_kernel<true>), grid, dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((conv3x3_wino_kernel<false>), grid, dim3(256), lds, s, a, g);
     VD_HIP(hipGetLastError());
     return 0;
 }
