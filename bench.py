@@ -206,6 +206,12 @@ def main():
                             launches_per_step=c["launches"], avg_launch_us=round(1e3 * c["ms"] / c["launches"], 1),
                             alg_gflop_per_launch=round(c["gflop"] / c["launches"], 3),
                             alg_mb_per_launch=round(c["mb"] / c["launches"], 2))
+            if name == "conv3x3_wino_kernel":
+                # `achieved` counts the ALGORITHMIC flops of a direct 3x3 convolution (2*M*Cout*Cin*9); Winograd
+                # F(2x2,3x3) executes 16/36 of them on the matrix pipe, so frac can exceed 1: the share of the MFMA
+                # peak the kernel actually keeps busy is achieved / 2.25
+                roofline["mfma_executed_tflops"] = round(achieved / 2.25, 2)
+                roofline["mfma_executed_frac"] = round(achieved / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4)
     vdist.barrier()
 
     if rank != 0:

@@ -131,7 +131,9 @@ const char* vd_profile_class_name(int i);
  * act: SiLU on the operand; res: residual in the epilogue; fbias: per-frame bias [nfr][fbias_ld]. */
 /* w_packed: [tap][Cout][Cin] (generic kernel; may be NULL when w_frag covers the shape);
  * w_frag: MFMA-fragment-major weights from vd_pack_conv3_frag / vd_pack_linear_frag, or NULL;
- * w_wino: Winograd-transformed 3x3 weights from vd_pack_conv3_wino, or NULL (preferred when given and supported). */
+ * w_wino: Winograd-transformed 3x3 weights from vd_pack_conv3_wino, or NULL (preferred when given and supported:
+ *         one plain source tensor -- no concat, no affine/act prologue -- stride 1, square power-of-two >= 8x8,
+ *         Cout % 64 == 0, Cin % 32 == 0). */
 int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, int ups, int stride,
                int pad, int ksz, const float* w_packed, const float* w_frag, const float* w_wino, const float* bias,
                const float* affA, const float* affB, int act, const float* res, const float* fbias, int fbias_ld,
@@ -139,8 +141,8 @@ int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, i
 /* Host repack OIHW (O, I multiples of 32) -> [tap][I/32][O/32][kgroup 4][lane 64][4]: lane 32h+r of k-group kg holds
  * w[co = 32*blk + r][ci = 32*chunk + 8*kg + 4*h + e]; one coalesced 1 KiB load per wave per MFMA k-group. */
 int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I);
-/* Winograd F(2x2,3x3) image of a 3x3 weight: U = G g G^T per (cout, cin), 16*O*I floats in
- * [I/16][16][O/32][2][64][4]; pass as w_wino (3x3 stride-1, >= 8x8, O % 64 == 0, I % 16 == 0). */
+/* Winograd F(2x2,3x3) image of a 3x3 weight: U = G g G^T per (cout, cin) with row 2 negated (the kernel negates row 2
+ * of B^T as well), 16*O*I floats in [I/16][16][O/32][2][64][4]; pass as w_wino. */
 int vd_pack_conv3_wino(const float* host_oihw, float* host_out, int O, int I);
 /* Same for an nn.Linear / 1x1-conv weight [N][K] (N, K multiples of 32) -> [K/32][N/32][4][64][4]; pass the result as
  * w_frag with ksz = 1. */
@@ -150,6 +152,10 @@ int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, 
                   const float* beta, const float* film, int film_ld, float* affA, float* affB, void* stream);
 int vd_op_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y,
                        void* stream);
+/* y[n][p][0..C) = SiLU?(concat(src0, src1)[n][p][c] * A[n][c] + B[n][c]): GroupNorm(+FiLM)+SiLU and the skip concat
+ * materialised once as the input of a 3x3 conv (in_layers / out_layers of ResBlock, unet.py:150-199). */
+int vd_op_affine_act(const float* src0, const float* src1, int C0, int C, const float* affA, const float* affB, int nfr,
+                     int HW, int act, float* y, void* stream);
 int vd_op_gn_temporal(const float* x, const float* gamma, const float* beta, int B, int T, int HW, int C, float* y,
                       void* stream);
 int vd_op_attn_spatial(const float* qkv, int nfr, int L, int C, int heads, float* out, void* stream);

@@ -111,8 +111,9 @@ def test_conv3x3_plain(N, Cin, Cout, H):
 
 @pytest.mark.parametrize("N,C0,C1,Cout,H", [(3, 64, 32, 96, 16), (3, 64, 32, 128, 16), (5, 32, 32, 64, 8), (2, 96, 0, 192, 32)])
 def test_conv3x3_fused_norm_film_silu_residual_concat(N, C0, C1, Cout, H):
-    """ResBlock operand path (unet.py:185-198): conv(silu(x*A+B)) + bias + skip, input = cat([h, skip]).
-    Cout % 64 == 0 runs the Winograd kernel (8x8: four frames per block, 5 frames -> ragged last block)."""
+    """ResBlock operand path fused into the conv's operand load (unet.py:185-198): conv(silu(x*A+B)) + bias + skip,
+    input = cat([h, skip]).  Runs on the direct kernels (the Winograd kernel takes one plain tensor; see
+    test_conv3x3_winograd_after_activation_pass for the engine's form of the same block)."""
     h, s = rnd(N, C0, H, H), (rnd(N, C1, H, H, seed=1) if C1 else None)
     A, B = rnd(N, C0 + C1, seed=2) + 1.5, rnd(N, C0 + C1, seed=3)
     w, b, res = rnd(Cout, C0 + C1, 3, 3, scale=0.06), rnd(Cout, scale=0.1), rnd(N, Cout, H, H, seed=4)
@@ -120,6 +121,47 @@ def test_conv3x3_fused_norm_film_silu_residual_concat(N, C0, C1, Cout, H):
     ref = F.conv2d(F.silu(x * A[:, :, None, None] + B[:, :, None, None]), w, b, padding=1) + res
     close(run_conv(h, s, w, b, affA=A, affB=B, act=1, res=res), ref, **TOL)
     close(run_conv(h, s, w, b, affA=A, affB=B, act=1, res=res, wino=False), ref, **TOL)
+
+
+def affine_act(x0, x1, A, B, act=1):
+    """vd_op_affine_act on NCHW cpu tensors -> NCHW cpu tensor with C0+C1 channels."""
+    N, C0, H, W = x0.shape
+    C = C0 + (x1.shape[1] if x1 is not None else 0)
+    y = torch.empty(N, H, W, C, device="cuda")
+    bufs = [dev(nhwc(x0)), dev(nhwc(x1)) if x1 is not None else None, dev(A), dev(B)]
+    _lib.check(_lib.lib().vd_op_affine_act(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), C0, C, _lib.ptr(bufs[2]), _lib.ptr(bufs[3]),
+                                           N, H * W, act, _lib.ptr(y), _lib.current_stream()))
+    torch.cuda.synchronize()
+    return y.permute(0, 3, 1, 2).cpu()
+
+
+@pytest.mark.parametrize("N,C0,C1,H", [(3, 64, 32, 16), (2, 32, 0, 8), (5, 128, 64, 4)])
+def test_affine_act_pass(N, C0, C1, H):
+    """GroupNorm(+FiLM) affine + SiLU over the virtual concat, written once (the 3x3 convs' input in the engine)."""
+    h, s = rnd(N, C0, H, H), (rnd(N, C1, H, H, seed=1) if C1 else None)
+    A, B = rnd(N, C0 + C1, seed=2) + 1.5, rnd(N, C0 + C1, seed=3)
+    x = torch.cat([h, s], 1) if C1 else h
+    lin = x * A[:, :, None, None] + B[:, :, None, None]
+    close(affine_act(h, s, A, B, act=1), F.silu(lin), atol=2e-6, rtol=2e-6)
+    close(affine_act(h, s, A, B, act=0), lin, atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,H", [(3, 64, 32, 128, 16), (5, 32, 32, 64, 8), (2, 96, 0, 192, 32), (9, 64, 0, 64, 8),
+                                            (1, 32, 32, 128, 64)])
+def test_conv3x3_winograd_after_activation_pass(N, C0, C1, Cout, H):
+    """The engine's ResBlock convs: activation pass (affine + SiLU + concat) then the Winograd kernel on the plain
+    tensor with bias + residual in its output transform (8x8: four frames per block; 5 and 9 frames -> ragged last
+    block whose rows are dropped by the buffer range check)."""
+    h, s = rnd(N, C0, H, H), (rnd(N, C1, H, H, seed=1) if C1 else None)
+    A, B = rnd(N, C0 + C1, seed=2) + 1.5, rnd(N, C0 + C1, seed=3)
+    w, b, res = rnd(Cout, C0 + C1, 3, 3, scale=0.06), rnd(Cout, scale=0.1), rnd(N, Cout, H, H, seed=4)
+    x = torch.cat([h, s], 1) if C1 else h
+    ref = F.conv2d(F.silu(x * A[:, :, None, None] + B[:, :, None, None]), w, b, padding=1) + res
+    act = affine_act(h, s, A, B)
+    close(run_conv(act, None, w, b, res=res), ref, **TOL)                      # Winograd
+    close(run_conv(act, None, w, b, res=res, wino=False), ref, **TOL)          # direct kernel on the same input
+    fb = rnd(N, Cout, seed=5)
+    close(run_conv(act, None, w, b, res=res, fbias=fb), ref + fb[:, :, None, None], **TOL)   # + per-frame bias (no FiLM)
 
 
 def test_conv3x3_upsample_fused():

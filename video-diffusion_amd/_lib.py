@@ -27,9 +27,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -fno-slp-vectorize: packed-f32 VALU (v_pk_fma_f32 ...) beside MFMAs is slower than the scalar pair it replaces
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-fno-slp-vectorize",
            *[os.path.join(_CSRC, s) for s in SOURCES], "-o", SO_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
@@ -90,6 +88,7 @@ SIGNATURES = {
     "vd_pack_linear_frag": (_I, [_P, _P, _I, _I]),
     "vd_op_gn_fold": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "vd_op_affine_apply": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "vd_op_affine_act": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "vd_op_gn_temporal": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "vd_op_attn_spatial": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "vd_op_attn_temporal": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -85,7 +85,7 @@ static const char* kProfNames[PC_COUNT] = {"igemm_kernel<128,128>", "igemm_kerne
                                            "attn_temporal", "out_conv", "elementwise", "posterior",
                                            "conv3x3_frag_kernel<128,128>", "conv3x3_frag_kernel<128,64>",
                                            "conv3x3_frag_kernel<64,128>", "conv3x3_frag_kernel<64,64>", "conv3x3_wino_kernel"};
-struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
+struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; char tag[56]; };
 struct Profiler {
     bool on = false;
     std::vector<ProfRec> recs;
@@ -94,9 +94,10 @@ static Profiler g_prof;
 
 struct ProfScope {
     hipStream_t st; bool live;
-    ProfScope(int cls, double flops, double bytes, hipStream_t s) : st(s), live(g_prof.on) {
+    ProfScope(int cls, double flops, double bytes, hipStream_t s, const char* tag = "") : st(s), live(g_prof.on) {
         if (!live) return;
-        ProfRec r{cls, flops, bytes, nullptr, nullptr};
+        ProfRec r{cls, flops, bytes, nullptr, nullptr, {0}};
+        snprintf(r.tag, sizeof(r.tag), "%s", tag);
         (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
         (void)hipEventRecord(r.a, st);
         g_prof.recs.push_back(r);
@@ -110,7 +111,10 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     const double bytes = 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout);
     const int cls = conv_wino_supported(g) ? (int)PC_CONV_WINO
                                            : igemm_tile_class(g.M, g.Cout) + (conv_halo_supported(g) ? (int)PC_CONV_128x128 : 0);
-    ProfScope ps(cls, 2.0 * g.M * g.Cout * cin * taps, bytes, st);
+    char tag[56];
+    snprintf(tag, sizeof(tag), "M=%d N=%d K=%d k%d s%d%s%s%s", g.M, g.Cout, g.Cin, g.ksz, g.stride, g.ups ? " ups" : "",
+             g.affA ? " pro" : (g.act ? " act" : ""), g.res ? " res" : "");
+    ProfScope ps(cls, 2.0 * g.M * g.Cout * cin * taps, bytes, st, tag);
     return launch_igemm(g, st);
 }
 
@@ -909,6 +913,9 @@ int vd_profile_end(double* out, int cap) {
         float ms = 0.f;
         VD_HIP(hipEventElapsedTime(&ms, r.a, r.b));
         out[r.cls * 4 + 0] += 1.0; out[r.cls * 4 + 1] += ms; out[r.cls * 4 + 2] += r.flops; out[r.cls * 4 + 3] += r.bytes;
+        if (getenv("VD_PROF_DUMP"))                    // per-launch listing for kernel work (tools/)
+            fprintf(stderr, "[vd_prof] %-28s %-40s %8.1f us %7.1f TFLOP/s\n", kProfNames[r.cls], r.tag, ms * 1e3,
+                    ms > 0 ? r.flops / ms / 1e9 : 0.0);
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
     g_prof.recs.clear();
@@ -944,6 +951,11 @@ int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, 
     (void)hipStreamSynchronize(st);
     (void)hipFree(part);
     return rc;
+}
+
+int vd_op_affine_act(const float* src0, const float* src1, int C0, int C, const float* affA, const float* affB, int nfr,
+                     int HW, int act, float* y, void* stream) {
+    return launch_affine_act(src0, src1, C0, C, affA, affB, nfr, HW, act, y, static_cast<hipStream_t>(stream));
 }
 
 int vd_op_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y, void* stream) {

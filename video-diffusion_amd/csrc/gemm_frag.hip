@@ -14,11 +14,14 @@ namespace vd {
 
 constexpr int GLD = 36;
 
-template <int BM, int BN>
+// On gfx950 VALU instructions do not overlap fp32 MFMAs of the same wave (tools/mfma_peak.hip), while memory and scalar
+// issue is free: all addressing therefore goes through buffer descriptors (lane offsets computed once, per-chunk
+// offsets scalar, out-of-range rows handled by the range check), and the SiLU prologue is compiled out when unused.
+template <int BM, int BN, bool ACT>
 __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
     constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];          // [2][BM][GLD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -26,52 +29,68 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
     const int nchunk = a.Cin >> 5, ncoblk = a.Cout >> 5;
     const int C1 = a.Cin - a.C0;
 
-    size_t arow[AR];
+    // A rows: byte offsets into either source (rows past M: duplicates of the last row, dropped at the store)
+    const auto asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.M * a.C0 * 4, 0x00020000);
+    const auto asrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1 ? a.src1 : a.src0), 0,
+                                                         a.src1 ? a.M * C1 * 4 : 0, 0x00020000);
+    unsigned ao0[AR], ao1[AR];
 #pragma unroll
-    for (int j = 0; j < AR; ++j) arow[j] = (size_t)min(m0 + lrow + 32 * j, a.M - 1);   // rows past M: duplicates, masked at store
-
-    int cob[NI];
+    for (int j = 0; j < AR; ++j) {
+        const unsigned row = (unsigned)min(m0 + lrow + 32 * j, a.M - 1);
+        ao0[j] = row * (unsigned)(a.C0 * 4) + lq * 16u;
+        ao1[j] = row * (unsigned)(C1 * 4) + lq * 16u;
+    }
+    // B fragments [K/32][N/32][kgroup 4][lane 64][4]: lane offset per column block, (chunk, k-group) scalar
+    const auto bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, a.Cin * a.Cout * 4, 0x00020000);
+    unsigned bo[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) cob[j] = min(blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1);
-    const float* wl = a.wfrag + lane * 4;
+    for (int j = 0; j < NI; ++j) bo[j] = (unsigned)min((int)blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1) * 4096u + lane * 16u;
 
     f32x4 ra[AR], bfr[4][NI], afr[2][MI];      // weight ring of 4 = k-groups per chunk: slot == kg, compile-time
     auto a_prefetch = [&](int chunk) {
-        const int c = chunk * 32 + lq * 4;
-        const float* base; int cc, ld;
-        if (c < a.C0) { base = a.src0; cc = c; ld = a.C0; } else { base = a.src1; cc = c - a.C0; ld = C1; }
+        const int c = chunk * 32;
+        if (c < a.C0) {
 #pragma unroll
-        for (int j = 0; j < AR; ++j) ra[j] = *reinterpret_cast<const f32x4*>(base + arow[j] * ld + cc);
+            for (int j = 0; j < AR; ++j)
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc0, ao0[j], c * 4, 0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < AR; ++j)
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc1, ao1[j], (c - a.C0) * 4, 0));
+        }
     };
     auto a_store = [&](float* Ad) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             f32x4 v = ra[j];
-            if (a.act) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            if constexpr (ACT) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
             *reinterpret_cast<f32x4*>(Ad + (lrow + 32 * j) * GLD + lq * 4) = v;
         }
     };
     auto b_load = [&](int slot, int chunk, int kg) {
-        const float* p = wl + ((size_t)chunk * ncoblk) * 1024 + kg * 256;
+        const int so = chunk * ncoblk * 4096 + kg * 1024;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[slot][j] = *reinterpret_cast<const f32x4*>(p + (size_t)cob[j] * 1024);
+        for (int j = 0; j < NI; ++j) bfr[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j], so, 0));
     };
 
+    // output / residual element (row m, column co): byte offset, or out of range for rows past M
+    const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.ldo * 4, 0x00020000);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0,
+                                                        a.res ? a.M * a.res_ld * 4 : 0, 0x00020000);
     // accumulators start at bias + residual: the residual tile streams in under the first A-tile staging
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const int co = min(n0 + wn * (BN / 2) + j * 32 + lr, a.Cout - 1);
-        const float bv = a.bias ? a.bias[co] : 0.f;
+        const int co = n0 + wn * (BN / 2) + j * 32 + lr;
+        const float bv = a.bias && co < a.Cout ? a.bias[co] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
-            if (a.res) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[i][j][r] += a.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), a.M - 1) * a.res_ld + co];
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const unsigned off = m < a.M && co < a.Cout ? (unsigned)(m * a.res_ld + co) * 4u : 0x80000000u;
+                acc[i][j][r] = bv + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
             }
         }
     }
@@ -116,14 +135,15 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int co = n0 + wn * (BN / 2) + j * 32 + lr;
-        if (co >= a.Cout) continue;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < a.M) a.out[(size_t)m * a.ldo + co] = acc[i][j][r];
+                const unsigned off = m < a.M && co < a.Cout ? (unsigned)(m * a.ldo + co) * 4u : 0x80000000u;
+                const float val = acc[i][j][r];          // (bit_cast straight from a vector-element lvalue reads element 0)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), osrc, off, 0, 0);
             }
         }
     }
@@ -131,14 +151,17 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
 
 bool gemm_frag_supported(const IgemmArgs& a) {
     return a.wfrag != nullptr && a.ksz == 1 && a.stride == 1 && a.pad == 0 && a.ups == 0 && a.Cout % 32 == 0 &&
-           a.affA == nullptr && a.fbias == nullptr;
+           a.affA == nullptr && a.fbias == nullptr &&
+           // 32-bit byte offsets (bit 31 marks out-of-range rows)
+           (size_t)a.M * std::max(std::max(a.C0, a.Cin - a.C0), std::max(a.ldo, a.res ? a.res_ld : 0)) < (1u << 29);
 }
 
 template <int BM, int BN>
 static int launch_gf(const IgemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * BM * GLD * sizeof(float);
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_frag_kernel<BM, BN>), grid, dim3(256), lds, s, a);
+    if (a.act) hipLaunchKernelGGL((gemm_frag_kernel<BM, BN, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((gemm_frag_kernel<BM, BN, false>), grid, dim3(256), lds, s, a);
     VD_HIP(hipGetLastError());
     return 0;
 }
