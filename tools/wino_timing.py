@@ -28,6 +28,14 @@ for nfr, C0, C1, Cout, H, pro in SHAPES:
                                 None, None, 0, _lib.ptr(res), None, 0, _lib.ptr(out), Cout, _lib.current_stream()))
         torch.cuda.synchronize()
     assert L.vd_debug_wino_stamps(st) == 0
+    if hasattr(L, "vd_debug_wino_segments"):
+        sg = (ctypes.c_ulonglong * 32)()
+        L.vd_debug_wino_segments.restype = ctypes.c_int
+        L.vd_debug_wino_segments.argtypes = [ctypes.c_void_p]
+        assert L.vd_debug_wino_segments(sg) == 0
+        nch = Cin // 16
+        for w in range(4):
+            print(f"   wave {w} per chunk: " + "  ".join(f"g{i}: issue+mfma {sg[8*w+2*i]/nch:6.0f} post {sg[8*w+2*i+1]/nch:5.0f}" for i in range(4)))
     t = list(st)
     nch = Cin // 16
     print(f"Cin {Cin:4d} Cout {Cout:4d} H {H:2d}: prologue {t[1]-t[0]:6d}  loop {t[2]-t[1]:8d} ({(t[2]-t[1])/nch:6.0f}/chunk, ideal 8192)"

@@ -43,6 +43,22 @@ extern "C" int vd_debug_wino_stamps(unsigned long long* host_out) {
 #else
 #define WINO_STAMP(i)
 #endif
+#if defined(VD_WINO_TIMING) && VD_WINO_TIMING == 2
+// per-group split of the main loop (block 0, wave 0): [issue + 32 MFMAs] and [transform + patch writes] of groups 0..3
+__device__ unsigned long long g_wino_seg[32];          // [wave][8], a block in the middle of the grid
+extern "C" int vd_debug_wino_segments(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_seg), sizeof(g_wino_seg));
+}
+#define WINO_SEG_DECL unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, segt_ = 0
+#define WINO_SEG_START segt_ = __builtin_readcyclecounter()
+#define WINO_SEG(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); seg_[i] += now_ - segt_; segt_ = now_; } while (0)
+#define WINO_SEG_FLUSH do { if ((threadIdx.x & 63) == 0 && blockIdx.x == gridDim.x / 2 + 3 && blockIdx.y == 0) for (int i_ = 0; i_ < 8; ++i_) g_wino_seg[(threadIdx.x >> 6) * 8 + i_] = seg_[i_]; } while (0)
+#else
+#define WINO_SEG_DECL
+#define WINO_SEG_START
+#define WINO_SEG(i)
+#define WINO_SEG_FLUSH
+#endif
 #ifndef VD_WINO_SKIP
 #define VD_WINO_SKIP 0     // kernel-experiment builds: bit 0 no patch staging, 1 no fragment transform, 2 no weight loads,
 #endif                     // 3 no barrier, 4 no patch loads, 5 no fragment reads (results are then wrong; timing only)
@@ -93,16 +109,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
     }
     const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
     const int xw = (sf * FS + sp0) * WLD + lq * 4;                   // LDS float offset of element 0
-    f32x4 rx[NX];
-    auto x_load = [&](int chunk) {
+    f32x4 rx[2][NX];                                                  // two sets: a patch is requested 4 MFMA groups ahead
+    auto x_load = [&](int set, int chunk) {
 #pragma unroll
         for (int e = 0; e < NX; ++e)
-            rx[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xo[e], chunk * (WKC * 4), 0));
+            rx[set][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xo[e], chunk * (WKC * 4), 0));
     };
-    auto x_store = [&](int buf, int e0, int e1) {                     // the buffers are padded to NX*SS pixels: no range branch
+    auto x_load_one = [&](int set, int chunk, int e) {
+        rx[set][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xo[e], chunk * (WKC * 4), 0));
+    };
+    auto x_store = [&](int set, int buf, int e0, int e1) {            // the buffers are padded to NX*SS pixels: no range branch
 #pragma unroll
         for (int e = 0; e < NX; ++e)
-            if (e >= e0 && e < e1) *reinterpret_cast<f32x4*>(smem + xw + buf * XBUF + e * SS * WLD) = rx[e];
+            if (e >= e0 && e < e1) *reinterpret_cast<f32x4*>(smem + xw + buf * XBUF + e * SS * WLD) = rx[set][e];
     };
 
     // ---- A fragments: lane (tile m*32+lr, k-half lh); row wi of B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].
@@ -120,25 +139,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
     int ab[2][2];                                                    // ... + the two patch rows this wave combines
 #pragma unroll
     for (int m = 0; m < 2; ++m) { ab[m][0] = xb[m] + r0 * P * WLD; ab[m][1] = xb[m] + r1 * P * WLD; }
-    f32x4 raw[2][8];
+    f32x4 raw[8];
     f32x2 fragl[2][4], fragh[2][4];                                  // channel pairs (0,1) and (2,3) of the k-quad
     const f32x2 sg2 = {sg, sg};
     // buf: which LDS patch buffer (compile-time after the 2x unroll of the chunk loop, so every address below is one
     // of four lane-invariant VGPRs plus an instruction offset)
-    auto a_read = [&](int slot, int buf, int m, int kg) {
+    auto a_read = [&](int buf, int m, int kg) {
         const float* p0 = smem + ab[m][0] + buf * XBUF + kg * 8;
         const float* p1 = smem + ab[m][1] + buf * XBUF + kg * 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            raw[slot][j] = *reinterpret_cast<const f32x4*>(p0 + j * WLD);
-            raw[slot][4 + j] = *reinterpret_cast<const f32x4*>(p1 + j * WLD);
+            raw[j] = *reinterpret_cast<const f32x4*>(p0 + j * WLD);
+            raw[4 + j] = *reinterpret_cast<const f32x4*>(p1 + j * WLD);
         }
     };
-    // raw[slot] -> frag[slot]: t_j = d[r1][j]*sg + d[r0][j], then the column combination of B: 8 packed fma + 8 packed
-    // add for 32 MFMAs' worth of A operands.  Written as asm because hipcc scalarises the <4 x float> form (each value
-    // is consumed by one MFMA as a scalar) and only partly re-packs it; the halves are independent, one block each.
-    // The blocks sit a whole MFMA group ahead of the first reader of their results (below), so no VALU->MFMA operand
-    // hazard can arise that the assembler-level hazard pass does not see.
+    auto a_read_one = [&](int buf, int m, int kg, int i) {           // i = 0..7: patch row r0 / r1, column j
+        raw[i] = *reinterpret_cast<const f32x4*>(smem + ab[m][i >> 2] + buf * XBUF + kg * 8 + (i & 3) * WLD);
+    };
+    // raw -> frag[slot]: t_j = d[r1][j]*sg + d[r0][j], then the column combination of B: 8 packed fma + 8 packed add for
+    // 32 MFMAs' worth of A operands.  Written as asm because hipcc scalarises the <4 x float> form (each value is consumed
+    // by one MFMA as a scalar) and only partly re-packs it; the two channel halves are independent, one block each.
+    // The results feed the next group's first MFMA directly: the closing s_nop covers the VALU-write -> MFMA-read wait
+    // states that hipcc does not pad for asm.
     auto half_transform = [&](f32x2& f0, f32x2& f1, f32x2& f2, f32x2& f3, f32x2 a0, f32x2 a1, f32x2 a2, f32x2 a3, f32x2 b0,
                               f32x2 b1, f32x2 b2, f32x2 b3) {
         asm volatile(
@@ -149,17 +171,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
             "v_pk_add_f32 %0, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"
             "v_pk_add_f32 %1, %5, %6\n\t"
             "v_pk_add_f32 %2, %6, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"
-            "v_pk_add_f32 %3, %5, %7 neg_lo:[0,1] neg_hi:[0,1]"
+            "v_pk_add_f32 %3, %5, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "s_nop 1"
             : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
             : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(sg2));
     };
     auto lo2 = [](const f32x4& v) { return f32x2{v.x, v.y}; };
     auto hi2 = [](const f32x4& v) { return f32x2{v.z, v.w}; };
     auto a_transform = [&](int s_) {
-        half_transform(fragl[s_][0], fragl[s_][1], fragl[s_][2], fragl[s_][3], lo2(raw[s_][0]), lo2(raw[s_][1]), lo2(raw[s_][2]),
-                       lo2(raw[s_][3]), lo2(raw[s_][4]), lo2(raw[s_][5]), lo2(raw[s_][6]), lo2(raw[s_][7]));
-        half_transform(fragh[s_][0], fragh[s_][1], fragh[s_][2], fragh[s_][3], hi2(raw[s_][0]), hi2(raw[s_][1]), hi2(raw[s_][2]),
-                       hi2(raw[s_][3]), hi2(raw[s_][4]), hi2(raw[s_][5]), hi2(raw[s_][6]), hi2(raw[s_][7]));
+        half_transform(fragl[s_][0], fragl[s_][1], fragl[s_][2], fragl[s_][3], lo2(raw[0]), lo2(raw[1]), lo2(raw[2]), lo2(raw[3]),
+                       lo2(raw[4]), lo2(raw[5]), lo2(raw[6]), lo2(raw[7]));
+        half_transform(fragh[s_][0], fragh[s_][1], fragh[s_][2], fragh[s_][3], hi2(raw[0]), hi2(raw[1]), hi2(raw[2]), hi2(raw[3]),
+                       hi2(raw[4]), hi2(raw[5]), hi2(raw[6]), hi2(raw[7]));
     };
 
     // ---- B fragments: U[chunk][xi = 4*wi + j][cob][kg][lane][4] through a buffer descriptor: one lane offset per
@@ -181,6 +204,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
                 bfr[slot][j][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(usrc, bo[j][n], so, 0));
     };
 
+    auto b_load_one = [&](int slot, int chunk, int kg, int i) {      // i = 0..7: (j, n)
+        bfr[slot][i >> 1][i & 1] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(usrc, bo[i >> 1][i & 1], chunk * ustride + uwave + kg * 1024, 0));
+    };
+
     f32x16 acc[2][4][2];                                            // [m][j][n]
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -191,63 +219,77 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][j][n][r] = 0.f;
 
-    // ---- software pipeline over the 4 MFMA groups (kg, m) = (0,0) (0,1) (1,0) (1,1) of each chunk; with one wave per
-    // SIMD nothing else hides a stall, so every operand is requested >= 2 groups (>= 4096 matrix-pipe cycles) ahead:
-    //   patch rows (HBM)      x_load(c+2)   before group 2 of chunk c   -> written to LDS in groups 0,1 of chunk c+1
-    //   weights (L2)          b_load        two groups before use
-    //   A fragments (LDS)     a_read        two groups before use, transformed one group before use
-    // The one barrier per chunk sits between groups 1 and 2: the next patch is complete and nobody reads the current
-    // one any more, so groups 2,3 already fetch the next chunk's first fragments.
-    x_load(0);
+    // ---- software pipeline over the 4 MFMA groups (kg, m) = (0,0) (0,1) (1,0) (1,1) of each chunk.  With one wave per
+    // SIMD nothing else hides a stall, so every operand is requested well ahead of its use:
+    //   patch rows (HBM)      chunk c+2's in groups 1 and 3 of chunk c  -> written to LDS in groups 0,1 of chunk c+1
+    //   weights (L2)          one group ahead, issued in the group before that
+    //   A fragments (LDS)     read behind the previous group's first MFMAs, transformed right after its last
+    // The one barrier per chunk sits before group 3: the next patch is complete and nobody reads the current one any
+    // more, so group 3 already fetches the next chunk's first fragments.
+    x_load(0, 0);
     b_load(0, 0, 0);
-    x_store(0, 0, NX);
-    x_load(min(1, nchunk - 1));
+    x_store(0, 0, 0, NX);
+    x_load(1, min(1, nchunk - 1));
     __syncthreads();
-    a_read(0, 0, 0, 0);
-    a_read(1, 0, 1, 0);
+    a_read(0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     a_transform(0);
     WINO_STAMP(1);
 
-    // one chunk: buf = the patch buffer it reads (the other one is being filled)
+    WINO_SEG_DECL;
+    WINO_SEG_START;
+    // one chunk: buf = the patch buffer it reads = the register set that is free to receive the patch after next.
+    // Requests are issued ONE per MFMA slot, never in bursts: the four waves run in lockstep, and 4 x 14 one-KiB loads
+    // issued together overflow the CU's memory-instruction queue -- the last wave then stalls ~1000 cycles at issue and
+    // the others wait for it at the barrier (tools/wino_timing.py, VD_WINO_TIMING=2).
     auto chunk_body = [&](int chunk, int buf) {
         const int n1 = min(chunk + 1, nchunk - 1), n2 = min(chunk + 2, nchunk - 1);
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
             const int kg = gi >> 1, m = gi & 1;
-            if (gi == 0 && !(VD_WINO_SKIP & 4)) b_load(1, chunk, 1);
-            if (gi == 2) {
-                if (!(VD_WINO_SKIP & 8)) __syncthreads();
-                if (!(VD_WINO_SKIP & 4)) b_load(0, n1, 0);
-                if (!(VD_WINO_SKIP & 16)) x_load(n2);
-            }
-            if (!(VD_WINO_SKIP & 32)) {
-                if (gi < 2) a_read(gi & 1, buf, gi & 1, 1);        // group gi+2 of this chunk
-                else a_read(gi & 1, buf ^ 1, gi & 1, 0);           // group gi-2 of the next chunk
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // the NEXT group's fragment transform (one VALU burst: VALU work does not overlap fp32 MFMAs, and every
-            // MFMA<->VALU switch costs ~8 cycles more), (groups 0,1) half of the next patch's LDS writes, then this
-            // group's 32 MFMAs; the barriers keep the requests above from sinking towards their consumers
-            if (!(VD_WINO_SKIP & 2)) a_transform((gi + 1) & 1);
-            if (!(VD_WINO_SKIP & 1)) {
-                if (gi == 0) x_store(buf ^ 1, 0, (NX + 1) / 2);
-                if (gi == 1) x_store(buf ^ 1, (NX + 1) / 2, NX);
-            }
+            if (gi == 3 && !(VD_WINO_SKIP & 8)) __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
                 const int e = k >> 3, j = (k >> 1) & 3, n = k & 1;
                 const float av = e < 2 ? fragl[gi & 1][j][e] : fragh[gi & 1][j][e - 2];
                 acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfr[kg][j][n][e], acc[m][j][n], 0, 0, 0);
+                bool fence = false;
+                if (k < 8 && !(VD_WINO_SKIP & 32)) {                // fragments of the NEXT group, behind MFMAs 0..7
+                    if (gi < 3) a_read_one(buf, (gi + 1) & 1, (gi + 1) >> 1, k);
+                    else a_read_one(buf ^ 1, 0, 0, k);
+                    fence = true;
+                }
+                if (k >= 8 && k < 24 && (k & 1) == 0) {             // one global request behind every other MFMA 8..22
+                    const int i = (k - 8) >> 1;                     // 0..7
+                    // weights: slot kg^1 is free once the previous group is done with it
+                    if (gi == 0 && !(VD_WINO_SKIP & 4)) { b_load_one(1, chunk, 1, i); fence = true; }
+                    if (gi == 2 && !(VD_WINO_SKIP & 4)) { b_load_one(0, n1, 0, i); fence = true; }
+                    // patch after next: first half of its rows in group 1, the rest in group 3
+                    if (gi == 1 && i < (NX + 1) / 2 && !(VD_WINO_SKIP & 16)) { x_load_one(buf, n2, i); fence = true; }
+                    if (gi == 3 && i < NX / 2 && !(VD_WINO_SKIP & 16)) { x_load_one(buf, n2, (NX + 1) / 2 + i); fence = true; }
+                }
+                if (fence) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            WINO_SEG(2 * gi);
+            // after the MFMAs (which cover the LDS latency of the fragment reads): the next group's fragment transform in
+            // one VALU burst -- VALU work does not overlap fp32 MFMAs and every MFMA<->VALU switch costs ~8 cycles -- and
+            // (groups 0,1) half of the next patch's LDS writes
+            if (!(VD_WINO_SKIP & 2)) a_transform((gi + 1) & 1);
+            if (!(VD_WINO_SKIP & 1)) {
+                if (gi == 0) x_store(buf ^ 1, buf ^ 1, 0, (NX + 1) / 2);
+                if (gi == 1) x_store(buf ^ 1, buf ^ 1, (NX + 1) / 2, NX);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            WINO_SEG(2 * gi + 1);
         }
     };
     for (int chunk = 0; chunk < nchunk; chunk += 2) {               // nchunk is even (conv_wino_supported)
         chunk_body(chunk, 0);
         chunk_body(chunk + 1, 1);
     }
+    WINO_SEG_FLUSH;
     WINO_STAMP(2);
 
     // ---- output transform.  A^T = [[1,1,1,0],[0,1,-1,-1]].  Wave-local: Z[q] = sum_j M[wi][j] A[j][q]; the sum over
