@@ -310,16 +310,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
         }
     const int obytes = a.nfr * Hl * Wl * a.ldo * 4;
     const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
-    // the residual rows (same layout as the output: res_ld == ldo) and the bias are requested before the exchange so
-    // their latency hides behind it
+    // the residual rows (same layout as the output: res_ld == ldo) are requested a quarter at a time between the pieces
+    // of the exchange: their latency hides behind it, and 4 waves x 64 requests in one burst would overflow the CU's
+    // memory-instruction queue (same effect as in the main loop)
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
     f32x16 rv[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rv[m][n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], n * 128, 0));
     float bv[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) bv[n] = a.bias ? a.bias[co0 + n * 32] : 0.f;
@@ -332,6 +327,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rv[m][n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], n * 128, 0));
             const f32x16 z0 = acc[m][0][n] + acc[m][1][n] + acc[m][2][n];
             const f32x16 z1 = acc[m][1][n] - acc[m][2][n] - acc[m][3][n];
 #pragma unroll
@@ -341,6 +339,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
                 *reinterpret_cast<f32x4*>(d0) = f32x4{z0[4 * c4], z0[4 * c4 + 1], z0[4 * c4 + 2], z0[4 * c4 + 3]};
                 *reinterpret_cast<f32x4*>(d1) = f32x4{z1[4 * c4], z1[4 * c4 + 1], z1[4 * c4 + 2], z1[4 * c4 + 3]};
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     WINO_STAMP(6);
     __syncthreads();
