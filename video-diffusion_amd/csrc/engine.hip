@@ -57,7 +57,7 @@ static const int CH_MULT_256[] = {1, 1, 2, 2, 4, 4};
 static const int CH_MULT_128[] = {1, 1, 2, 3, 4};
 static const int CH_MULT_64[] = {1, 2, 3, 4};
 static const int CH_MULT_32[] = {1, 2, 2, 2};
-constexpr int STEM_CPAD = 32;
+constexpr int STEM_KPAD = 64;          // im2col width of the 5-channel 3x3 stem (45 real columns)
 
 struct Arena {
     char* base = nullptr;
@@ -186,7 +186,7 @@ struct vd_engine {
         for (long long s : shape) { p.shape[i++] = s; p.numel *= (size_t)s; }
         p.kind = kind;
         p.packed = p.numel;
-        if (kind == PK_STEM) p.packed = (size_t)9 * p.shape[0] * STEM_CPAD;
+        if (kind == PK_STEM) p.packed = (size_t)p.shape[0] * STEM_KPAD;
         if (kind == PK_CONV3W) p.packed = (size_t)16 * p.shape[0] * p.shape[1];
         params.push_back(p);
         pidx[name] = (int)params.size() - 1;
@@ -534,7 +534,7 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
 int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
     const int B = in.B, T = in.T, N = B * T, S = cfg.image_size, mc = cfg.num_channels;
     int rc;
-    float* x8 = ar.get<float>((size_t)N * S * S * STEM_CPAD);
+    float* x8 = ar.get<float>((size_t)N * S * S * STEM_KPAD);       // im2col of the network input
     float* tfr = ar.get<float>(N);
     float* amask = ar.get<float>(N);
     float* tsin = ar.get<float>((size_t)N * mc);
@@ -546,7 +546,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
     float* femb = cfg.use_frame_encoding ? ar.get<float>((size_t)N * pos_ch) : nullptr;
     if (!ar.dry) {
         VD_REQUIRE(d_freq_time && n_freq_time == mc / 2, "vd_set_freqs not called (time frequencies)");
-        AssembleArgs aa{in.x, in.obs_src, in.obs, in.lat, in.km, in.t_model, in.obs_mode, B, T, S, S, STEM_CPAD, x8, tfr, amask};
+        AssembleArgs aa{in.x, in.obs_src, in.obs, in.lat, in.km, in.t_model, in.obs_mode, B, T, S, S, STEM_KPAD, x8, tfr, amask};
         if ((rc = launch_assemble(aa, st))) return rc;
         if ((rc = launch_sinus_embed(tfr, N, mc, d_freq_time, tsin, st))) return rc;
         if ((rc = linear(tsin, N, mc, 0, 0, E, W(p_te0w), W(p_te0b), 0, nullptr, e1, st))) return rc;
@@ -562,7 +562,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
         }
     }
     std::vector<Tens> hs;
-    Tens h{x8, STEM_CPAD, S};
+    Tens h{x8, STEM_KPAD, S};
     auto run = [&](const std::vector<Layer>& blk, Tens in0, const Tens* in1, Tens* outp) -> int {
         Tens cur = in0;
         const Tens* second = in1;
@@ -572,6 +572,11 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
                 if ((rc = res_block(res[L.idx], cur, second, N, film, nullptr, st, ar, &nxt))) return rc;
             } else if (L.type == 2) {
                 if ((rc = attn_block(attn[L.idx], cur, B, T, te, in.fidx, amask, st, ar, &nxt))) return rc;
+            } else if (L.type == 0) {                                 // stem: im2col (assemble_kernel) x [64][mc] GEMM
+                const ConvP& c = convs[L.idx];
+                float* o = ar.get<float>((size_t)N * S * S * c.c);
+                if (!ar.dry && (rc = linear(cur.p, N * S * S, STEM_KPAD, 0, 0, c.c, W(c.w), W(c.b), 0, nullptr, o, st))) return rc;
+                nxt = Tens{o, c.c, S};
             } else {
                 const ConvP& c = convs[L.idx];
                 const int stride = L.type == 3 ? 2 : 1, ups = L.type == 4 ? 1 : 0;
@@ -579,7 +584,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
                 float* o = ar.get<float>((size_t)g.M * c.c);
                 if (!ar.dry) {
                     set_w(g, c.w); g.bias = W(c.b); g.out = o; g.ldo = c.c; g.Cout = c.c;
-                    if ((rc = igemm_p(g, st, L.type == 0 ? 5 : 0))) return rc;
+                    if ((rc = igemm_p(g, st))) return rc;
                 }
                 nxt = Tens{o, c.c, g.Ho};
             }
@@ -706,13 +711,21 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
         tmp.resize(p.numel);
         pack_conv3_frag(host, tmp.data(), (int)p.shape[0], (int)p.shape[1]);
         src = tmp.data();
-    } else if (p.kind == PK_CONV3 || p.kind == PK_OUTCONV || p.kind == PK_STEM) {
+    } else if (p.kind == PK_STEM) {                    // OIHW -> [O][k = tap*I + i] (zero padded) -> fragment-major linear
         const int O = (int)p.shape[0], I = (int)p.shape[1];
-        const int Ip = p.kind == PK_STEM ? STEM_CPAD : I;
-        tmp.assign((size_t)9 * O * Ip, 0.f);
+        std::vector<float> lin((size_t)O * STEM_KPAD, 0.f);
         for (int o = 0; o < O; ++o)
             for (int i = 0; i < I; ++i)
-                for (int t = 0; t < 9; ++t) tmp[((size_t)t * O + o) * Ip + i] = host[((size_t)o * I + i) * 9 + t];
+                for (int t = 0; t < 9; ++t) lin[(size_t)o * STEM_KPAD + t * I + i] = host[((size_t)o * I + i) * 9 + t];
+        tmp.resize((size_t)O * STEM_KPAD);
+        pack_linear_frag(lin.data(), tmp.data(), O, STEM_KPAD, O, 0);
+        src = tmp.data();
+    } else if (p.kind == PK_CONV3 || p.kind == PK_OUTCONV) {
+        const int O = (int)p.shape[0], I = (int)p.shape[1];
+        tmp.assign((size_t)9 * O * I, 0.f);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int t = 0; t < 9; ++t) tmp[((size_t)t * O + o) * I + i] = host[((size_t)o * I + i) * 9 + t];
         src = tmp.data();
     } else if (p.kind == PK_POSENC) {
         const int C = (int)p.shape[1], HW = (int)(p.shape[2] * p.shape[3]);

@@ -14,11 +14,22 @@ namespace vd {
 
 constexpr int GLD = 36;
 
+#ifdef VD_GEMM_TIMING
+// kernel-experiment builds only (tools/gemm_timing.py): shader-clock stamps of one mid-grid block, wave 0
+__device__ unsigned long long g_gemm_stamp[4];
+#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) g_gemm_stamp[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int vd_debug_gemm_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamp), sizeof(g_gemm_stamp));
+}
+#else
+#define GEMM_STAMP(i)
+#endif
+
 // On gfx950 VALU instructions do not overlap fp32 MFMAs of the same wave (tools/mfma_peak.hip), while memory and scalar
 // issue is free: all addressing therefore goes through buffer descriptors (lane offsets computed once, per-chunk
 // offsets scalar, out-of-range rows handled by the range check), and the SiLU prologue is compiled out when unused.
 template <int BM, int BN, bool ACT>
-__global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(256, 3) void gemm_frag_kernel(IgemmArgs a) {
     constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];          // [2][BM][GLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -28,6 +39,7 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
     const int lrow = tid >> 3, lq = tid & 7;
     const int nchunk = a.Cin >> 5, ncoblk = a.Cout >> 5;
     const int C1 = a.Cin - a.C0;
+    GEMM_STAMP(0);
 
     // A rows: byte offsets into either source (rows past M: duplicates of the last row, dropped at the store)
     const auto asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.M * a.C0 * 4, 0x00020000);
@@ -73,27 +85,34 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
         for (int j = 0; j < NI; ++j) bfr[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j], so, 0));
     };
 
-    // output / residual element (row m, column co): byte offset, or out of range for rows past M
+    // output / residual element (row, column): lane part of the byte offset per (row group i, column block j) + a scalar
+    // per accumulator row r -- ONE VALU add per access.  Rows past M fall off the end of the descriptor, columns past
+    // Cout are parked beyond 2^31: the range check drops both.  (Epilogue VALU matters: beside the other blocks' MFMAs
+    // every VALU instruction of this wave waits for a free ALU slot, tools/gemm_timing.py.)
     const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.ldo * 4, 0x00020000);
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0,
-                                                        a.res ? a.M * a.res_ld * 4 : 0, 0x00020000);
-    // accumulators start at bias + residual: the residual tile streams in under the first A-tile staging
-    f32x16 acc[MI][NI];
+                                                        a.res ? a.M * a.ldo * 4 : 0, 0x00020000);
+    unsigned vb[MI][NI];
+    float bv[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int co = n0 + wn * (BN / 2) + j * 32 + lr;
-        const float bv = a.bias && co < a.Cout ? a.bias[co] : 0.f;
+        bv[j] = a.bias && co < a.Cout ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
+        for (int i = 0; i < MI; ++i)
+            vb[i][j] = co < a.Cout ? (unsigned)((m0 + wm * (BM / 2) + i * 32 + 4 * lh) * a.ldo + co) * 4u : 0x80000000u;
+    }
+    // accumulators start at bias + residual: the residual tile streams in under the first A-tile staging
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                const unsigned off = m < a.M && co < a.Cout ? (unsigned)(m * a.res_ld + co) * 4u : 0x80000000u;
-                acc[i][j][r] = bv + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+                const int srow = ((r & 3) + 8 * (r >> 2)) * a.ldo * 4;                       // scalar
+                acc[i][j][r] = bv[j] + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vb[i][j] + srow, 0, 0));
             }
-        }
-    }
 
     a_prefetch(0);
     b_load(0, 0, 0);
@@ -102,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
     __syncthreads();
 
     const int aoff = (wm * (BM / 2) + lr) * GLD + lh * 4;
+    GEMM_STAMP(1);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const int nxt = min(chunk + 1, nchunk - 1);           // last chunk: redundant prefetch instead of a branch
         const float* Acur = smem + (chunk & 1) * BM * GLD + aoff;
@@ -131,29 +151,38 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(IgemmArgs a) {
         }
         __syncthreads();
     }
+    GEMM_STAMP(2);
 
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int co = n0 + wn * (BN / 2) + j * 32 + lr;
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
-#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            unsigned vbe = vb[i][j];
+            asm volatile("" : "+v"(vbe));                // opaque: the 64 offsets are re-added here, not kept live
+#pragma unroll                                           // across the K loop (64 VGPRs -> spills at 3 blocks per CU)
             for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                const unsigned off = m < a.M && co < a.Cout ? (unsigned)(m * a.ldo + co) * 4u : 0x80000000u;
+                const int srow = ((r & 3) + 8 * (r >> 2)) * a.ldo * 4;
                 const float val = acc[i][j][r];          // (bit_cast straight from a vector-element lvalue reads element 0)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), osrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), osrc, vbe + srow, 0, 0);
             }
         }
-    }
+    GEMM_STAMP(3);
 }
+
+#ifdef VD_GEMM_TIMING
+extern "C" int vd_debug_gemm_occupancy(void) {
+    int n = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_frag_kernel<128, 128, false>, 256, (size_t)2 * 128 * GLD * sizeof(float));
+    return n;
+}
+#endif
 
 bool gemm_frag_supported(const IgemmArgs& a) {
     return a.wfrag != nullptr && a.ksz == 1 && a.stride == 1 && a.pad == 0 && a.ups == 0 && a.Cout % 32 == 0 &&
            a.affA == nullptr && a.fbias == nullptr &&
            // 32-bit byte offsets (bit 31 marks out-of-range rows)
-           (size_t)a.M * std::max(std::max(a.C0, a.Cin - a.C0), std::max(a.ldo, a.res ? a.res_ld : 0)) < (1u << 29);
+           (a.res == nullptr || a.res_ld == a.ldo) &&
+           (size_t)a.M * std::max(std::max(a.C0, a.Cin - a.C0), a.ldo) < (1u << 28);
 }
 
 template <int BM, int BN>

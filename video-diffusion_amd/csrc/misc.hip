@@ -4,8 +4,11 @@
 namespace vd {
 
 // ------------------------------------------------------------------ network input (CondMargVideoModel.forward,
-// unet.py:951-983,991-1013): 5 channels [x*lat + obs_src*obs + x*(1-any), obs, kinda_marg], NCHW -> NHWC,
-// zero padded to Cpad so the stem convolution runs on the MFMA kernel; per-frame timesteps; attention mask.
+// unet.py:951-983,991-1013): 5 channels [x*lat + obs_src*obs + x*(1-any), obs, kinda_marg]; per-frame timesteps;
+// attention mask.  The 5-channel 3x3 stem (input_blocks.0.0) has K = 45: far too thin for the implicit-GEMM conv
+// kernels (13 TFLOP/s with the channels padded to 32), so the input is written directly as its im2col matrix
+// [B*T*H*W][Kpad = 64], k = tap*5 + channel (zeros for taps outside the image and for k >= 45), and the stem runs as a
+// plain K = 64 GEMM on gemm_frag_kernel.
 __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
     const int n = blockIdx.y;
     const int HW = a.H * a.W;
@@ -17,25 +20,33 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
         a.t_frames[n] = tobs * om + t * (1.f - om);
         a.amask[n] = any;
     }
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    float* o = a.x_nhwc + ((size_t)n * HW + p) * a.Cpad;
-    float v[8];
+    // thread -> (pixel, tap): 16 pixels x 9 taps (+7 idle lanes' worth) per 256 threads would waste lanes; use one thread
+    // per (pixel, tap) with 9 taps in consecutive threads: blockIdx.x covers 28 pixels (252 threads active)
+    const int tp = threadIdx.x / 9, tap = threadIdx.x - tp * 9;
+    const int p = blockIdx.x * 28 + tp;
+    if (tp >= 28 || p >= HW) return;
+    const int y = p / a.W + tap / 3 - 1, x = p % a.W + tap % 3 - 1;
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+        const int q = y * a.W + x;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float xv = a.x[((size_t)n * 3 + c) * HW + p];
-        const float ov = a.obs_src[((size_t)n * 3 + c) * HW + p];
-        v[c] = xv * lm + ov * om + xv * (1.f - any);
+        for (int c = 0; c < 3; ++c) {
+            const float xv = a.x[((size_t)n * 3 + c) * HW + q];
+            const float ov = a.obs_src[((size_t)n * 3 + c) * HW + q];
+            v[c] = xv * lm + ov * om + xv * (1.f - any);
+        }
+        v[3] = om; v[4] = km;
     }
-    v[3] = om; v[4] = km; v[5] = v[6] = v[7] = 0.f;
-    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], 0.f, 0.f, 0.f};
-    for (int c = 8; c < a.Cpad; c += 4) *reinterpret_cast<f32x4*>(o + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* o = a.x_cols + ((size_t)n * HW + p) * a.Kpad + tap * 5;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) o[c] = v[c];
+    if (tap == 8)
+        for (int k = 45; k < a.Kpad; ++k) o[k - 40] = 0.f;            // o + 5 = column 45
 }
 
 int launch_assemble(const AssembleArgs& a, hipStream_t s) {
-    VD_REQUIRE(a.Cpad % 8 == 0 && a.Cpad >= 8, "padded input channels");
-    hipLaunchKernelGGL(assemble_kernel, dim3((a.H * a.W + 255) / 256, a.B * a.T), dim3(256), 0, s, a);
+    VD_REQUIRE(a.Kpad % 32 == 0 && a.Kpad >= 64, "padded im2col width");
+    hipLaunchKernelGGL(assemble_kernel, dim3((a.H * a.W + 27) / 28, a.B * a.T), dim3(256), 0, s, a);
     VD_HIP(hipGetLastError());
     return 0;
 }

@@ -118,8 +118,8 @@ struct AssembleArgs {
     const float* obs_mask, *lat_mask, *km_mask;   // [B*T]
     const float* t_model;// [B] value handed to the network (already mapped / rescaled)
     int obs_t_mode;      // 0: 'x_0' (obs frames see t=0), 1: 'x_t', 2: 'x_t_minus_1'
-    int B, T, H, W, Cpad;
-    float* x_nhwc;       // [B*T][H][W][Cpad]  (5 real channels + zero pad)
+    int B, T, H, W, Kpad;
+    float* x_cols;       // [B*T*H*W][Kpad]: im2col of the 5-channel input for the 3x3 stem, k = tap*5 + channel
     float* t_frames;     // [B*T]
     float* amask;        // [B*T] anything mask
 };
