@@ -138,6 +138,18 @@ int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, i
                int pad, int ksz, const float* w_packed, const float* w_frag, const float* w_wino, const float* bias,
                const float* affA, const float* affB, int act, const float* res, const float* fbias, int fbias_ld,
                float* out, int Cout, void* stream);
+/* vd_op_conv whose epilogue also writes the GroupNorm partial sums of its OUTPUT (Winograd shapes only, -1 otherwise):
+ * gn_part[nfr][split][Cout][2] doubles = per (frame, block of the frame, channel) [sum, sum of squares], with
+ * split = vd_conv_stats_split(output height).  vd_op_gn_affine folds one or two such tables (the halves of a channel
+ * concat; tables from vd_op_conv_stats or from a statistics pass have the same layout) into the (A, B) pair of
+ * vd_op_gn_fold, so the consumer's GroupNorm (unet.py:185-198) never reads the tensor for its statistics. */
+int vd_conv_stats_split(int Hout);
+int vd_op_conv_stats(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const float* w_wino, const float* bias,
+                     const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
+                     void* stream);
+int vd_op_gn_affine(const double* part0, int split0, int C0, const double* part1, int split1, int C, int nfr, int HW,
+                    const float* gamma, const float* beta, const float* film, int film_ld, float* affA, float* affB,
+                    void* stream);
 /* Host repack OIHW (O, I multiples of 32) -> [tap][I/32][O/32][kgroup 4][lane 64][4]: lane 32h+r of k-group kg holds
  * w[co = 32*blk + r][ci = 32*chunk + 8*kg + 4*h + e]; one coalesced 1 KiB load per wave per MFMA k-group. */
 int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I);

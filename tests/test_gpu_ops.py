@@ -164,6 +164,47 @@ def test_conv3x3_winograd_after_activation_pass(N, C0, C1, Cout, H):
     close(run_conv(act, None, w, b, res=res, fbias=fb), ref + fb[:, :, None, None], **TOL)   # + per-frame bias (no FiLM)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,C1", [(3, 64, 128, 32, 0), (5, 32, 64, 8, 0), (2, 96, 192, 16, 64), (6, 64, 64, 8, 32)])
+def test_conv3x3_winograd_groupnorm_partials(N, Cin, Cout, H, C1):
+    """GroupNorm statistics of the conv OUTPUT from its own epilogue (per frame, block, channel partial sums) folded
+    by vd_op_gn_affine -- alone and as the first half of a channel concat whose second half went through the ordinary
+    statistics pass -- against vd_op_gn_fold reading the tensors (unet.py:185-198: the next GroupNorm + FiLM)."""
+    L = _lib.lib()
+    x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, scale=0.06), rnd(Cout, scale=0.1)
+    res = rnd(N, Cout, H, H, seed=4)
+    xd, wd, bd, rd = dev(nhwc(x)), dev(pack_wino(w)), dev(b), dev(nhwc(res))
+    out = torch.empty(N, H, H, Cout, device="cuda")
+    split = L.vd_conv_stats_split(H)
+    part = torch.full((N, split, Cout, 2), float("nan"), dtype=torch.float64, device="cuda")
+    _lib.check(L.vd_op_conv_stats(_lib.ptr(xd), Cin, N, H, H, 0, _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), None, 0, _lib.ptr(out),
+                                  Cout, _lib.ptr(part), _lib.current_stream()))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, w, b, padding=1) + res
+    close(out.permute(0, 3, 1, 2).cpu(), ref, **TOL)
+    # the table against sums over the stored tensor
+    o64 = out.double()
+    tot = part.sum(1).cpu()
+    close(tot[..., 0], o64.sum((1, 2)).cpu(), atol=1e-3, rtol=1e-5)
+    close(tot[..., 1], (o64 * o64).sum((1, 2)).cpu(), atol=1e-3, rtol=1e-5)
+    # folded affine: fused table (+ a second source through the statistics pass) == statistics pass over everything
+    C = Cout + C1
+    gamma, beta, film = dev(rnd(C, seed=6) + 1.0), dev(rnd(C, seed=7)), dev(rnd(N, 2 * C, seed=8))
+    s1 = dev(nhwc(rnd(N, C1, H, H, seed=9))) if C1 else None
+    A0, B0, A1, B1 = (torch.empty(N, C, device="cuda") for _ in range(4))
+    _lib.check(L.vd_op_gn_fold(_lib.ptr(out), _lib.ptr(s1), Cout, C, N, H * H, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(film), 2 * C,
+                               _lib.ptr(A0), _lib.ptr(B0), _lib.current_stream()))
+    part1, split1 = None, 0
+    if C1:                       # second table: per-channel sums of s1 in one block per frame (same layout, split 1)
+        s64 = s1.double()
+        part1 = torch.stack([s64.sum((1, 2)), (s64 * s64).sum((1, 2))], -1).reshape(N, 1, C1, 2).contiguous()
+        split1 = 1
+    _lib.check(L.vd_op_gn_affine(_lib.ptr(part), split, Cout, _lib.ptr(part1), split1, C, N, H * H, _lib.ptr(gamma), _lib.ptr(beta),
+                                 _lib.ptr(film), 2 * C, _lib.ptr(A1), _lib.ptr(B1), _lib.current_stream()))
+    torch.cuda.synchronize()
+    close(A1.cpu(), A0.cpu(), atol=2e-6, rtol=2e-6)
+    close(B1.cpu(), B0.cpu(), atol=2e-6, rtol=2e-6)
+
+
 def test_conv3x3_upsample_fused():
     """Upsample (unet.py:63-72): nearest x2 read through the gather, zero padding at the UPSAMPLED border."""
     x, w, b = rnd(2, 64, 8, 8), rnd(64, 64, 3, 3, scale=0.07), rnd(64, scale=0.1)

@@ -83,6 +83,9 @@ SIGNATURES = {
     "vd_profile_classes": (_I, []),
     "vd_profile_class_name": (ctypes.c_char_p, [_I]),
     "vd_op_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P]),
+    "vd_conv_stats_split": (_I, [_I]),
+    "vd_op_conv_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
+    "vd_op_gn_affine": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "vd_pack_conv3_wino": (_I, [_P, _P, _I, _I]),
     "vd_pack_conv3_frag": (_I, [_P, _P, _I, _I]),
     "vd_pack_linear_frag": (_I, [_P, _P, _I, _I]),

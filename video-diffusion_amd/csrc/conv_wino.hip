@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
     // Z[p + k][q] is plane wi + 2k
     const float sgn = p ? -1.f : 1.f;
     const float* zw = Zs + wi * 4096 + lane * 4;
+    float gsum[TF4 ? 4 : 1][2][2] = {};
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -368,9 +369,51 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
                     y[r] += a.fbias[(size_t)min(f0 + (t >> (2 * TTL)), a.nfr - 1) * a.fbias_ld + co0 + n * 32];
                 }
             }
+            y += bv[n];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[r] + bv[n]), osrc, oo[m][r], n * 128, 0);
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)y[r]), osrc, oo[m][r], n * 128, 0);
+            if (a.stats) {                                           // GroupNorm partial sums of what was just stored
+#pragma unroll
+                for (int h = 0; h < (TF4 ? 2 : 1); ++h) {            // TF4: rows 0..7 / 8..15 are two frames
+                    float s = 0.f, ss = 0.f;
+#pragma unroll
+                    for (int r = h * (TF4 ? 8 : 0); r < (TF4 ? 8 * h + 8 : 16); ++r) { s += y[r]; ss += y[r] * y[r]; }
+                    const int fs = TF4 ? 2 * m + h : 0;              // frame slot of the block
+                    gsum[fs][n][0] += s; gsum[fs][n][1] += ss;
+                }
+            }
         }
+    if (a.stats) {
+        // per lane: [frame slot][n][sum, sumsq] over its 16 or 32 rows (fp32 over <= 32 values), then doubles: 8 partials
+        // per (frame, channel) -- 4 waves (the 4 pixels of a tile) x 2 k-halves -- meet in LDS and one thread per
+        // (frame, channel) adds them in a fixed order and writes the block's entry of the partial table
+        constexpr int NFS = TF4 ? 4 : 1;
+        __syncthreads();                                             // the Z planes are dead
+        double* red = reinterpret_cast<double*>(smem);               // [wave 4][lh 2][fs][n 2][lr 32][2]
+#pragma unroll
+        for (int fs = 0; fs < NFS; ++fs)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                double* d = red + (((((wi * 2 + lh) * NFS + fs) * 2 + n) * 32 + lr) * 2);
+                d[0] = (double)gsum[fs][n][0]; d[1] = (double)gsum[fs][n][1];
+            }
+        __syncthreads();
+        if (tid < NFS * 64) {
+            const int fs = tid >> 6, n = (tid >> 5) & 1, c = tid & 31;
+            double s = 0.0, ss = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double* d = red + ((((k * NFS + fs) * 2 + n) * 32 + c) * 2);
+                s += d[0]; ss += d[1];
+            }
+            const int nf = f0 + fs;
+            const int sp = TF4 ? 0 : byy * g.tiles_x + bxx;
+            if (nf < a.nfr) {
+                double* o = a.stats + (((size_t)nf * a.stats_split + sp) * a.Cout + blockIdx.y * 64 + n * 32 + c) * 2;
+                o[0] = s; o[1] = ss;
+            }
+        }
+    }
     WINO_STAMP(3);
 }
 
@@ -385,8 +428,11 @@ bool conv_wino_supported(const IgemmArgs& a) {
            (size_t)a.nfr * Hl * Wl * a.ldo < (1u << 29) && (a.res == nullptr || a.res_ld == a.ldo);
 }
 
+int conv_wino_stats_split(int Hout) { return Hout >= 16 ? (Hout / 16) * (Hout / 16) : 1; }
+
 int launch_conv_wino(const IgemmArgs& a, hipStream_t s) {
     const int Hl = a.Hs << a.ups;
+    VD_REQUIRE(a.stats == nullptr || a.stats_split == conv_wino_stats_split(Hl), "GroupNorm partial table: split");
     WinoGeom g;
     const int TT = Hl >= 16 ? 8 : 4;                   // tiles per dim per frame in a block
     g.TF = 64 / (TT * TT);                             // 1 or 4 frames

@@ -51,7 +51,9 @@ struct AttP { int normw, normb, qkvw, qkvb, projw, projb; };
 struct AttnP { int C; AttP sp, tp; RpeP rq, rk, rv; };
 struct ConvP { int w, b, c; };
 struct Layer { int type; int idx; };      // 0 stem, 1 res, 2 attn, 3 down, 4 up
-struct Tens { float* p; int C, H; };
+// An activation tensor [N][H][H][C]; part/split: its GroupNorm partial sums [N][split][C][2] when the producing
+// convolution's epilogue wrote them (conv_wino.hip), else null and the consumer's GroupNorm runs the statistics pass.
+struct Tens { float* p; int C, H; double* part = nullptr; int split = 0; };
 
 static const int CH_MULT_256[] = {1, 1, 2, 2, 4, 4};
 static const int CH_MULT_128[] = {1, 1, 2, 3, 4};
@@ -114,6 +116,7 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     char tag[56];
     snprintf(tag, sizeof(tag), "M=%d N=%d K=%d k%d s%d%s%s%s", g.M, g.Cout, g.Cin, g.ksz, g.stride, g.ups ? " ups" : "",
              g.affA ? " pro" : (g.act ? " act" : ""), g.res ? " res" : "");
+    VD_REQUIRE(g.stats == nullptr || conv_wino_supported(g), "GroupNorm partial sums requested from a kernel that has no such epilogue");
     ProfScope ps(cls, 2.0 * g.M * g.Cout * cin * taps, bytes, st, tag);
     return launch_igemm(g, st);
 }
@@ -200,7 +203,7 @@ struct vd_engine {
                   hipStream_t st, Arena& ar, Tens* out);
     int attn_block(const AttnP& a, Tens x, int B, int T, const float* te_all, const int64_t* fidx, const float* amask,
                    hipStream_t st, Arena& ar, Tens* out);
-    int gn_fold(const float* s0, const float* s1, int C0, int C, int N, int HW, int gw, int gb, const float* film,
+    int gn_fold(const Tens& x0, const Tens* x1, int N, int gw, int gb, const float* film,
                 int film_ld, hipStream_t st, Arena& ar, float** A, float** B);
     int linear(const float* a, int M, int K, int pw, int pb, int Nout, const float* wptr, const float* bptr, int act,
                const float* res, float* out, hipStream_t st);
@@ -388,17 +391,36 @@ int vd_engine::linear(const float* a, int M, int K, int, int, int Nout, const fl
     return igemm_p(g, st);
 }
 
-int vd_engine::gn_fold(const float* s0, const float* s1, int C0, int C, int N, int HW, int gw, int gb,
+int vd_engine::gn_fold(const Tens& x0, const Tens* x1, int N, int gw, int gb,
                        const float* film, int film_ld, hipStream_t st, Arena& ar, float** A, float** Bp) {
-    const int split = gn_stats_split(N, HW, C);
-    double* part = ar.get<double>((size_t)N * split * C * 2);
+    const int HW = x0.H * x0.H, C = x0.C + (x1 ? x1->C : 0);
+    // per-channel partial sums of each source: the table its producer wrote, or one statistics pass over it
+    const Tens* src[2] = {&x0, x1};
+    const double* part[2] = {nullptr, nullptr};
+    int split[2] = {0, 0};
+    for (int i = 0; i < 2; ++i) {
+        if (!src[i]) continue;
+        if (src[i]->part) { part[i] = src[i]->part; split[i] = src[i]->split; continue; }
+        split[i] = gn_stats_split(N, HW, src[i]->C);
+        double* pt = ar.get<double>((size_t)N * split[i] * src[i]->C * 2);
+        part[i] = pt;
+        if (ar.dry) continue;
+        ProfScope ps(PC_GN_STATS, 0.0, 4.0 * N * HW * src[i]->C, st);
+        int rc = launch_gn_stats(src[i]->p, nullptr, src[i]->C, src[i]->C, N, HW, pt, split[i], st);
+        if (rc) return rc;
+    }
     *A = ar.get<float>((size_t)N * C);
     *Bp = ar.get<float>((size_t)N * C);
     if (ar.dry) return 0;
-    ProfScope ps(PC_GN_STATS, 0.0, 4.0 * N * HW * C, st);
-    int rc = launch_gn_stats(s0, s1, C0, C, N, HW, part, split, st);
-    if (rc) return rc;
-    return launch_gn_affine(part, split, (double)HW * (C / 32), W(gw), W(gb), film, film_ld, N, C, *A, *Bp, st);
+    return launch_gn_affine(part[0], split[0], x0.C, part[1], split[1], (double)HW * (C / 32), W(gw), W(gb), film, film_ld, N,
+                            C, *A, *Bp, st);
+}
+
+// the epilogue of the Winograd conv (the kernel every PK_CONV3W weight runs on) writes the GroupNorm partial sums of
+// its output: allocate the table and hand it to the launch
+static double* stats_table(Arena& ar, int N, int Hout, int Cout, int* split) {
+    *split = conv_wino_stats_split(Hout);
+    return ar.get<double>((size_t)N * *split * Cout * 2);
 }
 
 static IgemmArgs conv_args(Tens x0, const Tens* x1, int N, int ksz, int stride, int ups) {
@@ -419,9 +441,13 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     VD_REQUIRE(cin == r.cin, "ResBlock input channels");
     const float* s1 = x1 ? x1->p : nullptr;
     float *A1, *B1, *A2, *B2;
-    int rc = gn_fold(x0.p, s1, x0.C, cin, N, HW, r.gn1w, r.gn1b, nullptr, 0, st, ar, &A1, &B1);
+    int rc = gn_fold(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, st, ar, &A1, &B1);
     if (rc) return rc;
     float* h = ar.get<float>((size_t)N * HW * r.cout);
+    Tens ht{h, r.cout, H};
+    if (params[r.c1w].kind == PK_CONV3W) ht.part = stats_table(ar, N, H, r.cout, &ht.split);
+    Tens ot{nullptr, r.cout, H};
+    if (params[r.c2w].kind == PK_CONV3W) ot.part = stats_table(ar, N, H, r.cout, &ot.split);
     const float* film = film_all + r.film_off;
     {   // SiLU(GroupNorm(concat(x0, x1))) once, into a transient; the conv then reads plain activations (norm.hip)
         const size_t mk = ar.mark();
@@ -431,14 +457,13 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
             Tens at{a1, cin, H};
             IgemmArgs g = conv_args(at, nullptr, N, 3, 1, 0);
             set_w(g, r.c1w); g.bias = W(r.c1b);
-            g.out = h; g.ldo = r.cout; g.Cout = r.cout;
+            g.out = h; g.ldo = r.cout; g.Cout = r.cout; g.stats = ht.part; g.stats_split = ht.split;
             if (!cfg.use_scale_shift_norm) { g.fbias = film; g.fbias_ld = film_total; }    // h + emb_out (unet.py:196)
             if ((rc = igemm_p(g, st))) return rc;
         }
         ar.release(mk);
     }
-    rc = gn_fold(h, nullptr, r.cout, r.cout, N, HW, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr,
-                 film_total, st, ar, &A2, &B2);
+    rc = gn_fold(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, st, ar, &A2, &B2);
     if (rc) return rc;
     const float* skip = x0.p;
     if (r.skw >= 0) {
@@ -458,15 +483,17 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         float* a2 = ar.get<float>((size_t)N * HW * r.cout);
         if (!ar.dry) {
             if ((rc = affine_act(h, nullptr, r.cout, r.cout, A2, B2, N, HW, a2, st))) return rc;
-            Tens ht{a2, r.cout, H};
-            IgemmArgs g = conv_args(ht, nullptr, N, 3, 1, 0);
+            Tens at{a2, r.cout, H};
+            IgemmArgs g = conv_args(at, nullptr, N, 3, 1, 0);
             set_w(g, r.c2w); g.bias = W(r.c2b);
             g.res = skip; g.res_ld = r.cout; g.out = o; g.ldo = r.cout; g.Cout = r.cout;
+            g.stats = ot.part; g.stats_split = ot.split;
             if ((rc = igemm_p(g, st))) return rc;
         }
         ar.release(mk);
     }
-    *out = Tens{o, r.cout, H};
+    ot.p = o;
+    *out = ot;
     return 0;
 }
 
@@ -512,7 +539,7 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
     }
     // ---- spatial attention over the HW pixels of each frame               (unet.py:258-267)
     float *A, *Bf;
-    if ((rc = gn_fold(xt, nullptr, C, C, N, HW, a.sp.normw, a.sp.normb, nullptr, 0, st, ar, &A, &Bf))) return rc;
+    if ((rc = gn_fold(Tens{xt, C, H}, nullptr, N, a.sp.normw, a.sp.normb, nullptr, 0, st, ar, &A, &Bf))) return rc;
     float* xn2 = ar.get<float>(tok * C);
     float* qkv2 = ar.get<float>(tok * 3 * C);
     float* o2 = ar.get<float>(tok * C);
@@ -582,11 +609,13 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
                 const int stride = L.type == 3 ? 2 : 1, ups = L.type == 4 ? 1 : 0;
                 IgemmArgs g = conv_args(cur, nullptr, N, 3, stride, ups);
                 float* o = ar.get<float>((size_t)g.M * c.c);
+                nxt = Tens{o, c.c, g.Ho};
+                if (params[c.w].kind == PK_CONV3W) nxt.part = stats_table(ar, N, g.Ho, c.c, &nxt.split);
                 if (!ar.dry) {
                     set_w(g, c.w); g.bias = W(c.b); g.out = o; g.ldo = c.c; g.Cout = c.c;
+                    g.stats = nxt.part; g.stats_split = nxt.split;
                     if ((rc = igemm_p(g, st))) return rc;
                 }
-                nxt = Tens{o, c.c, g.Ho};
             }
             cur = nxt;
             second = nullptr;
@@ -615,7 +644,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
         if ((rc = run(output_blocks[i], h, &skip, &h))) return rc;      // cat([h, hs.pop()]) read in place
     }
     float *A, *Bf;
-    if ((rc = gn_fold(h.p, nullptr, h.C, h.C, N, S * S, p_outgw, p_outgb, nullptr, 0, st, ar, &A, &Bf))) return rc;
+    if ((rc = gn_fold(h, nullptr, N, p_outgw, p_outgb, nullptr, 0, st, ar, &A, &Bf))) return rc;
     if (!ar.dry) {
         VD_REQUIRE(h.H == S && h.C == final_ch, "output head shape");
         { ProfScope ps(PC_OUT_CONV, 2.0 * N * S * S * h.C * 27.0, 4.0 * N * S * S * (h.C + 3.0), st);
@@ -953,6 +982,29 @@ int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, i
     return launch_igemm(g, static_cast<hipStream_t>(stream));
 }
 
+int vd_conv_stats_split(int Hout) { return conv_wino_stats_split(Hout); }
+
+int vd_op_conv_stats(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const float* w_wino, const float* bias,
+                     const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
+                     void* stream) {
+    IgemmArgs g{};
+    g.src0 = src0; g.C0 = Cin; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws; g.ups = ups;
+    g.stride = 1; g.pad = 1; g.ksz = 3;
+    g.Ho = Hs << ups; g.Wo = Ws << ups;
+    g.wwino = w_wino; g.bias = bias; g.res = res; g.res_ld = Cout; g.fbias = fbias; g.fbias_ld = fbias_ld;
+    g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
+    g.stats = gn_part; g.stats_split = conv_wino_stats_split(g.Ho);
+    VD_REQUIRE(conv_wino_supported(g), "vd_op_conv_stats: shape not covered by the Winograd kernel");
+    return launch_igemm(g, static_cast<hipStream_t>(stream));
+}
+
+int vd_op_gn_affine(const double* part0, int split0, int C0, const double* part1, int split1, int C, int nfr, int HW,
+                    const float* gamma, const float* beta, const float* film, int film_ld, float* affA, float* affB,
+                    void* stream) {
+    return launch_gn_affine(part0, split0, C0, part1, split1, (double)HW * (C / 32), gamma, beta, film, film_ld, nfr, C, affA,
+                            affB, static_cast<hipStream_t>(stream));
+}
+
 int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, int HW, const float* gamma,
                   const float* beta, const float* film, int film_ld, float* affA, float* affB, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -960,7 +1012,7 @@ int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, 
     double* part;
     VD_HIP(hipMalloc(reinterpret_cast<void**>(&part), (size_t)nfr * split * C * 2 * sizeof(double)));
     int rc = launch_gn_stats(src0, src1, C0, C, nfr, HW, part, split, st);
-    if (!rc) rc = launch_gn_affine(part, split, (double)HW * (C / 32), gamma, beta, film, film_ld, nfr, C, affA, affB, st);
+    if (!rc) rc = launch_gn_affine(part, split, C, nullptr, 0, (double)HW * (C / 32), gamma, beta, film, film_ld, nfr, C, affA, affB, st);
     (void)hipStreamSynchronize(st);
     (void)hipFree(part);
     return rc;

@@ -64,9 +64,12 @@ int launch_gn_stats(const float* src0, const float* src1, int C0, int C, int nfr
 
 // ------------------------------------------------------------------ group statistics -> per-(frame,channel) affine
 //   y = ((x-mean)*rstd*gamma + beta) * (1+scale) + shift  =  x*A + B
-// One block per frame: 8 lanes per group reduce the (split x C/32) fp64 partials with shuffles, then all
-// 256 threads fold mean/rstd/gamma/beta and the FiLM pair into A, B.
-__global__ __launch_bounds__(256) void gn_final_affine_kernel(const double* __restrict__ part, int split, double count,
+// The per-channel partial sums come from up to two tables (the two halves of a virtual concat: channels [0, C0) from
+// part0 with split0 entries per frame, [C0, C) from part1 with split1), each written either by gn_stats_partial or by
+// the epilogue of the convolution that produced the tensor (conv_wino.hip).  One block per frame: 8 lanes per group
+// reduce the fp64 partials with shuffles, then all 256 threads fold mean/rstd/gamma/beta and the FiLM pair into A, B.
+__global__ __launch_bounds__(256) void gn_final_affine_kernel(const double* __restrict__ part0, int split0, int C0,
+                                                              const double* __restrict__ part1, int split1, double count,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
                                                               const float* __restrict__ film, int film_ld, int C,
@@ -74,12 +77,14 @@ __global__ __launch_bounds__(256) void gn_final_affine_kernel(const double* __re
     __shared__ float mr[64];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int g = tid >> 3, l = tid & 7;
-    const int cg = C / 32;
+    const int cg = C / 32, C1 = C - C0;
     double s = 0, ss = 0;
-    for (int k = l; k < split * cg; k += 8) {
-        const int sp = k / cg, c = k - sp * cg;
-        const double* p = part + (((size_t)n * split + sp) * C + g * cg + c) * 2;
-        s += p[0]; ss += p[1];
+    for (int ci = l; ci < cg; ci += 8) {
+        const int c = g * cg + ci;
+        const bool second = c >= C0;
+        const int split = second ? split1 : split0, ld = second ? C1 : C0, cc = second ? c - C0 : c;
+        const double* p = (second ? part1 : part0) + ((size_t)n * split * ld + cc) * 2;
+        for (int sp = 0; sp < split; ++sp) { s += p[(size_t)sp * ld * 2]; ss += p[(size_t)sp * ld * 2 + 1]; }
     }
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 8); ss += __shfl_xor(ss, o, 8); }
@@ -106,26 +111,14 @@ __global__ __launch_bounds__(256) void gn_final_affine_kernel(const double* __re
     }
 }
 
-int launch_gn_affine(const double* part, int split, double count, const float* gamma, const float* beta,
-                     const float* film, int film_ld, int nfr, int C, float* affA, float* affB, hipStream_t s) {
-    hipLaunchKernelGGL(gn_final_affine_kernel, dim3(nfr), dim3(256), 0, s, part, split, count, gamma, beta, film, film_ld,
-                       C, affA, affB);
+int launch_gn_affine(const double* part0, int split0, int C0, const double* part1, int split1, double count,
+                     const float* gamma, const float* beta, const float* film, int film_ld, int nfr, int C, float* affA,
+                     float* affB, hipStream_t s) {
+    VD_REQUIRE(part0 && (C0 == C || part1), "GroupNorm partial tables");
+    hipLaunchKernelGGL(gn_final_affine_kernel, dim3(nfr), dim3(256), 0, s, part0, split0, C0, part1, split1, count, gamma,
+                       beta, film, film_ld, C, affA, affB);
     VD_HIP(hipGetLastError());
     return 0;
-}
-
-// ------------------------------------------------------------------ y = x*A[n][c] + B[n][c]
-__global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ x, const float* __restrict__ affA,
-                                                           const float* __restrict__ affB, size_t per_frame4, int C4,
-                                                           size_t total4, float* __restrict__ y) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const size_t n = i / per_frame4;
-        const int c4 = (int)(i % C4);
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-        const f32x4 A = reinterpret_cast<const f32x4*>(affA)[n * C4 + c4];
-        const f32x4 B = reinterpret_cast<const f32x4*>(affB)[n * C4 + c4];
-        reinterpret_cast<f32x4*>(y)[i] = v * A + B;
-    }
 }
 
 // ------------------------------------------------------------------ y = silu(x*A[n][c] + B[n][c]) over a virtual concat
@@ -159,6 +152,20 @@ int launch_affine_act(const float* src0, const float* src1, int C0, int C, const
     hipLaunchKernelGGL(affine_act_kernel, dim3(grid), dim3(256), 0, s, src0, src1, C0 / 4, C / 4, affA, affB, HW, total4, act, y);
     VD_HIP(hipGetLastError());
     return 0;
+}
+
+// ------------------------------------------------------------------ y = x*A[n][c] + B[n][c]
+__global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ x, const float* __restrict__ affA,
+                                                           const float* __restrict__ affB, size_t per_frame4, int C4,
+                                                           size_t total4, float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t n = i / per_frame4;
+        const int c4 = (int)(i % C4);
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 A = reinterpret_cast<const f32x4*>(affA)[n * C4 + c4];
+        const f32x4 B = reinterpret_cast<const f32x4*>(affB)[n * C4 + c4];
+        reinterpret_cast<f32x4*>(y)[i] = v * A + B;
+    }
 }
 
 int launch_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y,

@@ -55,6 +55,11 @@ struct IgemmArgs {
     float* out;          // [M][ldo]
     int ldo;
     int Cout, M;
+    // GroupNorm statistics of the OUTPUT, produced by the epilogue (conv_wino.hip only): per (frame, block-of-frame,
+    // channel) [sum, sum of squares] as doubles, the layout gn_stats_partial writes -> the consumer's GroupNorm needs no
+    // pass over the tensor.  stats_split = blocks per frame (conv_wino_stats_split).  Null: not produced.
+    double* stats;
+    int stats_split;
 };
 
 struct AttnSpatialArgs {
@@ -88,6 +93,7 @@ void pack_linear_frag(const float* w, float* out_base, int rows, int K, int n_to
 void pack_conv3_frag(const float* oihw, float* out, int O, int I);
 // Winograd F(2x2,3x3) path (conv_wino.hip): 2.25x fewer MFMAs than the direct 3x3 kernels
 bool conv_wino_supported(const IgemmArgs& a);
+int conv_wino_stats_split(int Hout);          // blocks per frame = partial sums per (frame, channel)
 int launch_conv_wino(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino(const float* oihw, float* out, int O, int I);      // out: 16*O*I floats
 int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s);
@@ -100,8 +106,9 @@ int launch_gn_stats(const float* src0, const float* src1, int C0, int C, int nfr
 int gn_stats_split(int nfr, int HW, int C);
 // affA/affB[n][c] = fold(mean, rstd, gamma, beta, FiLM scale/shift).  film: [nfr][film_ld], scale at +0, shift at +C.
 // count = elements per group (HW * C/32)
-int launch_gn_affine(const double* part, int split, double count, const float* gamma, const float* beta,
-                     const float* film, int film_ld, int nfr, int C, float* affA, float* affB, hipStream_t s);
+int launch_gn_affine(const double* part0, int split0, int C0, const double* part1, int split1, double count,
+                     const float* gamma, const float* beta, const float* film, int film_ld, int nfr, int C, float* affA,
+                     float* affB, hipStream_t s);
 // y = x*A[n][c] + B[n][c]  (materialised normalisation for the attention residual, unet.py:474,538)
 // y[n][p][0..C) = silu?(concat(src0, src1)[n][p][c] * A[n][c] + B[n][c])
 int launch_affine_act(const float* src0, const float* src1, int C0, int C, const float* affA, const float* affB, int nfr,
