@@ -22,7 +22,7 @@ for M, K, N, res in SHAPES:
     b = torch.rand(N, device="cuda")
     r = torch.rand(M, N, device="cuda") if res else None
     out = torch.empty(M, N, device="cuda")
-    st = (ctypes.c_ulonglong * 4)()
+    st = (ctypes.c_ulonglong * 6)()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for it in range(3):
         if it == 2:
@@ -36,4 +36,5 @@ for M, K, N, res in SHAPES:
     nch = K // 32
     us = ev[0].elapsed_time(ev[1]) * 1e3
     print(f"M {M:6d} K {K:4d} N {N:4d}: {us:7.1f} us {2.0*M*N*K/us/1e6:6.1f} TFLOP/s | prologue {t[1]-t[0]:6d}  loop {t[2]-t[1]:7d} "
-          f"({(t[2]-t[1])/nch:6.0f}/chunk; 64 MFMA = 4096/wave)  epilogue {t[3]-t[2]:6d}  total {t[3]-t[0]:7d}", flush=True)
+          f"({(t[2]-t[1])/nch:6.0f}/chunk; 64 MFMA = 4096/wave)  epilogue {t[3]-t[2]:6d}  total {t[3]-t[0]:7d} | kernel "
+          f"block lasted {(t[5]-t[4])/100:.1f} us -> shader clock {(t[3]-t[0])/max(t[5]-t[4],1)*0.1:.2f} GHz", flush=True)

@@ -16,8 +16,11 @@ constexpr int GLD = 36;
 
 #ifdef VD_GEMM_TIMING
 // kernel-experiment builds only (tools/gemm_timing.py): shader-clock stamps of one mid-grid block, wave 0
-__device__ unsigned long long g_gemm_stamp[4];
-#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) g_gemm_stamp[i] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long g_gemm_stamp[6];      // [4], [5]: constant-rate (100 MHz) clock at stamps 0 and 3
+#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) {                  \
+        g_gemm_stamp[i] = __builtin_readcyclecounter();                                                             \
+        if (i == 0) g_gemm_stamp[4] = __builtin_amdgcn_s_memrealtime();                                             \
+        if (i == 3) g_gemm_stamp[5] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 extern "C" int vd_debug_gemm_stamps(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamp), sizeof(g_gemm_stamp));
 }
