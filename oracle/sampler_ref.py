@@ -86,3 +86,36 @@ class SamplerRef:
             else:
                 x = self.ddim_sample(x, t, kw, noises[i], eta=eta)["sample"]
         return x
+
+    def full_loop(self, batch, schedule_factory, obs_length, vertical_steps, observed_frames, noise_fn):
+        """scripts/video_sample_full.py:50-323 (non-adaptive branch) -- the vertical + horizontal sampler:
+        vertical phase = per window, the first `vertical_steps` timesteps in a row from the window's current frames
+        (observed frames from x_0, :88-200); horizontal phase = per remaining timestep, the whole schedule again with
+        one p_sample per window at that timestep and `observed_frames` as given (:202-315).
+        `schedule_factory()` yields (obs_idx, latent_idx) lists; `noise_fn(shape)` is the next randn_like draw."""
+        B = batch.shape[0]
+        samples = torch.zeros_like(batch)
+        samples[:, :obs_length] = batch[:, :obs_length]
+
+        def window(obs_idx, lat_idx):
+            x0 = torch.cat([samples[:, obs_idx], samples[:, lat_idx]], dim=1).clone()
+            om = torch.zeros_like(x0[:, :, :1, :1, :1])
+            om[:, :len(obs_idx)] = 1
+            return x0, dict(x0=x0, obs_mask=om, latent_mask=1 - om, kinda_marg_mask=torch.zeros_like(om),
+                            frame_indices=torch.tensor(list(obs_idx) + list(lat_idx)).repeat(B, 1))
+
+        steps = list(range(self.num_timesteps))[::-1]
+        if vertical_steps > 0:
+            for obs_idx, lat_idx in schedule_factory():
+                x0, kw = window(obs_idx, lat_idx)
+                local = x0.clone()
+                for ts in steps[:vertical_steps]:
+                    local = self.p_sample(local, torch.tensor([ts] * B), kw, noise_fn(local.shape))["sample"]
+                samples[:, lat_idx] = local[:, -len(lat_idx):]
+        for ts in steps[vertical_steps:]:
+            for obs_idx, lat_idx in schedule_factory():
+                x0, kw = window(obs_idx, lat_idx)
+                kw = dict(kw, observed_frames=observed_frames, x_t_minus_1=x0)
+                local = self.p_sample(x0, torch.tensor([ts] * B), kw, noise_fn(x0.shape))["sample"]
+                samples[:, lat_idx] = local[:, -len(lat_idx):]
+        return samples

@@ -154,3 +154,34 @@ def test_engine_reports_errors_not_crashes():
     # compute entry points refuse to run without weights (no silent fallback)
     assert L.vd_unet_forward(model._handle, 2, 4, None, None, None, None, None, None, None, 0, None, None) == -1
     assert b"weights not set" in L.vd_last_error()
+
+
+def test_eval_dir_naming_matches_reference(tmp_path):
+    """improved_diffusion/test_util.py:65-132 naming rules against strings produced by the reference
+    (tools/gen_golden_full.py): results/<subpath>/<stem>[_ddim][_respace<X>] and the run identifier."""
+    from argparse import Namespace
+
+    from helpers import load_json
+    from video_diffusion_amd import test_util as tu
+    cases = load_json("eval_paths.json")
+    assert len(cases) >= 30
+    for c in cases:
+        a = Namespace(**c["args"])
+        if c["kind"] == "model_results_path":
+            assert str(tu.get_model_results_path(a, postfix=c["postfix"])) == c["expect"], c
+        else:
+            assert tu.get_eval_run_identifier(a, postfix=c["postfix"]) == c["expect"], c
+    # '*latest' checkpoints get their training step appended (read from the file)
+    ck = tmp_path / "my-checkpoints" / "run1" / "ema_latest.pt"
+    ck.parent.mkdir(parents=True)
+    import torch
+    torch.save({"step": 4321, "state_dict": {}, "config": {}}, ck)
+    a = Namespace(use_ddim=True, timestep_respacing="ddim50", eval_dir=None, checkpoint_path=str(ck))
+    assert str(tu.get_model_results_path(a)) == "results/run1/ema_latest_4321_ddim_respaceddim50"
+    # the lock sits next to the file and is released afterwards
+    f = tmp_path / "model_config.json"
+    with tu.Protect(f):
+        assert (tmp_path / "model_config.json.lock").exists()
+        f.write_text("{}")
+    with tu.Protect(f, timeout=0.5):
+        pass

@@ -22,7 +22,7 @@ for nfr, C0, C1, Cout, H, pro in SHAPES:
     b = torch.rand(Cout, device="cuda")
     res = torch.rand(nfr, H, H, Cout, device="cuda")
     out = torch.empty(nfr, H, H, Cout, device="cuda")
-    st = (ctypes.c_ulonglong * 8)()
+    st = (ctypes.c_ulonglong * 10)()
     for _ in range(3):
         _lib.check(L.vd_op_conv(_lib.ptr(x0), None, Cin, Cin, nfr, H, H, 0, 1, 1, 3, None, None, _lib.ptr(ww), _lib.ptr(b),
                                 None, None, 0, _lib.ptr(res), None, 0, _lib.ptr(out), Cout, _lib.current_stream()))
@@ -40,4 +40,5 @@ for nfr, C0, C1, Cout, H, pro in SHAPES:
     nch = Cin // 16
     print(f"Cin {Cin:4d} Cout {Cout:4d} H {H:2d}: prologue {t[1]-t[0]:6d}  loop {t[2]-t[1]:8d} ({(t[2]-t[1])/nch:6.0f}/chunk, ideal 8192)"
           f"  epilogue {t[3]-t[2]:6d} = addr+res loads {t[4]-t[2]} + barrier {t[5]-t[4]} + Z write {t[6]-t[5]} + barrier {t[7]-t[6]}"
-          f" + Z read/store {t[3]-t[7]}   total {t[3]-t[0]:8d}", flush=True)
+          f" + Z read/store {t[3]-t[7]}   total {t[3]-t[0]:8d} = {(t[9]-t[8])/100:.1f} us -> shader clock "
+          f"{(t[3]-t[0])/max(t[9]-t[8],1)*0.1:.2f} GHz", flush=True)

@@ -32,10 +32,14 @@ struct WinoGeom {
 
 #ifdef VD_WINO_TIMING
 // kernel-experiment builds only (tools/wino_timing.py): shader-clock stamps of block 0, wave 0
-__device__ unsigned long long g_wino_stamp[8];
+__device__ unsigned long long g_wino_stamp[10];         // [8], [9]: constant-rate (100 MHz) clock at stamps 0 and 3
 #define WINO_STAMP(i)                                                                                                  \
     do {                                                                                                               \
-        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_wino_stamp[i] = __builtin_readcyclecounter();    \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {                                                  \
+            g_wino_stamp[i] = __builtin_readcyclecounter();                                                            \
+            if (i == 0) g_wino_stamp[8] = __builtin_amdgcn_s_memrealtime();                                            \
+            if (i == 3) g_wino_stamp[9] = __builtin_amdgcn_s_memrealtime();                                            \
+        }                                                                                                              \
     } while (0)
 extern "C" int vd_debug_wino_stamps(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_stamp), sizeof(g_wino_stamp));
