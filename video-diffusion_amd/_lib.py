@@ -23,19 +23,30 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> in-tree libvdamd.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 -> in-tree libvdamd.so (cross-compiles without a GPU).
+    One process per GPU may get here at once (torchrun): the build is serialised by a lock file and written under a
+    per-process name, so a rank either builds or waits and then finds the library fresh."""
     if not force and not _stale():
         return SO_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           *[os.path.join(_CSRC, s) for s in SOURCES], "-o", SO_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(SO_PATH + ".tmp", SO_PATH)
-    return SO_PATH
+    import fcntl
+    with open(SO_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return SO_PATH
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = f"{SO_PATH}.{os.getpid()}.tmp"
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                   *[os.path.join(_CSRC, s) for s in SOURCES], "-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+            os.replace(tmp, SO_PATH)
+            return SO_PATH
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 class VdConfig(ctypes.Structure):

@@ -110,14 +110,15 @@ struct ProfScope {
 static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     const double taps = (double)g.ksz * g.ksz, cin = cin_alg ? cin_alg : g.Cin;
     const double in_pix = (double)g.nfr * g.Hs * g.Ws;
-    const double bytes = 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout);
+    const double nz = g.zcount > 1 ? g.zcount : 1;
+    const double bytes = nz * 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout);
     const int cls = conv_wino_supported(g) ? (int)PC_CONV_WINO
                                            : igemm_tile_class(g.M, g.Cout) + (conv_halo_supported(g) ? (int)PC_CONV_128x128 : 0);
     char tag[56];
     snprintf(tag, sizeof(tag), "M=%d N=%d K=%d k%d s%d%s%s%s", g.M, g.Cout, g.Cin, g.ksz, g.stride, g.ups ? " ups" : "",
              g.affA ? " pro" : (g.act ? " act" : ""), g.res ? " res" : "");
     VD_REQUIRE(g.stats == nullptr || conv_wino_supported(g), "GroupNorm partial sums requested from a kernel that has no such epilogue");
-    ProfScope ps(cls, 2.0 * g.M * g.Cout * cin * taps, bytes, st, tag);
+    ProfScope ps(cls, nz * 2.0 * g.M * g.Cout * cin * taps, bytes, st, tag);
     return launch_igemm(g, st);
 }
 
@@ -506,11 +507,13 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
     // ---- temporal attention over the T frames of each (batch, pixel)      (unet.py:246-255)
     float* xn = ar.get<float>(tok * C);
     float* qkv = ar.get<float>(tok * 3 * C);
-    float* R[3] = {nullptr, nullptr, nullptr};
-    const RpeP* rp[3] = {&a.rk, &a.rq, &a.rv};
+    // relative-position terms in memory order q, k, v: the three nets of a block have identical shapes and sit at a
+    // constant stride in the packed weights, so each of their two layers is ONE launch (blockIdx.y / .z = net)
+    const RpeP* rp[3] = {&a.rq, &a.rk, &a.rv};
     const size_t rrows = (size_t)B * T * T;
-    float* Ehid = cfg.use_rpe_net ? ar.get<float>(rrows * C) : nullptr;
-    for (int i = 0; i < 3; ++i) R[i] = ar.get<float>(rrows * C);
+    float* Ehid = cfg.use_rpe_net ? ar.get<float>(3 * rrows * C) : nullptr;
+    float* Rall = ar.get<float>(3 * rrows * C);
+    float* R[3] = {Rall + rrows * C, Rall, Rall + 2 * rrows * C};          // k, q, v as the attention kernel takes them
     float* o = ar.get<float>(tok * C);
     float* xt = ar.get<float>(tok * C);
     if (!ar.dry) {
@@ -518,15 +521,23 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
           rc = launch_gn_temporal(x.p, W(a.tp.normw), W(a.tp.normb), B, T, HW, C, xn, st); }
         if (rc) return rc;
         if ((rc = linear(xn, (int)tok, C, 0, 0, 3 * C, W(a.tp.qkvw), W(a.tp.qkvb), 0, nullptr, qkv, st))) return rc;
-        for (int i = 0; i < 3; ++i) {
-            if (cfg.use_rpe_net) {
-                if ((rc = launch_rpe_hidden(te_all + rp[i]->te_off, te_total, W(rp[i]->dw), W(rp[i]->db), fidx, B, T, C,
-                                            Ehid, st))) return rc;
-                if ((rc = linear(Ehid, (int)rrows, C, 0, 0, C, W(rp[i]->ow), W(rp[i]->ob), 0, nullptr, R[i], st))) return rc;
-            } else {
-                if ((rc = launch_rpe_table(W(rp[i]->table), fidx, B, T, C, cfg.rp_alpha, cfg.rp_beta, cfg.rp_gamma, R[i], st)))
-                    return rc;
-            }
+        if (cfg.use_rpe_net) {
+            const int zs_dw = (int)(W(rp[1]->dw) - W(rp[0]->dw)), zs_db = (int)(W(rp[1]->db) - W(rp[0]->db));
+            const int zs_ow = (int)(W(rp[1]->ow) - W(rp[0]->ow)), zs_ob = (int)(W(rp[1]->ob) - W(rp[0]->ob));
+            VD_REQUIRE(W(rp[2]->dw) - W(rp[1]->dw) == zs_dw && W(rp[2]->db) - W(rp[1]->db) == zs_db &&
+                       W(rp[2]->ow) - W(rp[1]->ow) == zs_ow && W(rp[2]->ob) - W(rp[1]->ob) == zs_ob &&
+                       rp[1]->te_off - rp[0]->te_off == C && rp[2]->te_off - rp[1]->te_off == C, "RPE nets: constant stride");
+            if ((rc = launch_rpe_hidden(te_all + rp[0]->te_off, te_total, W(rp[0]->dw), W(rp[0]->db), fidx, B, T, C, Ehid, 3, C,
+                                        zs_dw, zs_db, rrows * C, st))) return rc;
+            IgemmArgs g{};
+            g.src0 = Ehid; g.C0 = C; g.Cin = C; g.nfr = (int)rrows; g.Hs = g.Ws = g.Ho = g.Wo = 1; g.stride = 1; g.ksz = 1;
+            g.wfrag = W(rp[0]->ow); g.bias = W(rp[0]->ob); g.out = Rall; g.ldo = C; g.Cout = C; g.M = (int)rrows;
+            g.zcount = 3; g.zs_a = g.zs_out = (int)(rrows * C); g.zs_w = zs_ow; g.zs_bias = zs_ob;
+            if ((rc = igemm_p(g, st))) return rc;
+        } else {
+            for (int i = 0; i < 3; ++i)
+                if ((rc = launch_rpe_table(W(rp[i]->table), fidx, B, T, C, cfg.rp_alpha, cfg.rp_beta, cfg.rp_gamma,
+                                           Rall + i * rrows * C, st))) return rc;
         }
         AttnTemporalArgs ta{qkv, R[0], R[1], R[2], amask, o, B, T, HW, C, cfg.num_heads,
                             cfg.allow_interactions_between_padding, scale};

@@ -43,6 +43,11 @@ __global__ __launch_bounds__(256, 3) void gemm_frag_kernel(IgemmArgs a) {
     const int nchunk = a.Cin >> 5, ncoblk = a.Cout >> 5;
     const int C1 = a.Cin - a.C0;
     GEMM_STAMP(0);
+    if (a.zcount > 1) {                          // batched problems of one shape
+        const int z = blockIdx.z;
+        a.src0 += (size_t)z * a.zs_a; a.wfrag += (size_t)z * a.zs_w; a.out += (size_t)z * a.zs_out;
+        if (a.bias) a.bias += (size_t)z * a.zs_bias;
+    }
 
     // A rows: byte offsets into either source (rows past M: duplicates of the last row, dropped at the store)
     const auto asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.M * a.C0 * 4, 0x00020000);
@@ -191,7 +196,7 @@ bool gemm_frag_supported(const IgemmArgs& a) {
 template <int BM, int BN>
 static int launch_gf(const IgemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * BM * GLD * sizeof(float);
-    dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.zcount > 1 ? a.zcount : 1);
     if (a.act) hipLaunchKernelGGL((gemm_frag_kernel<BM, BN, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((gemm_frag_kernel<BM, BN, false>), grid, dim3(256), lds, s, a);
     VD_HIP(hipGetLastError());

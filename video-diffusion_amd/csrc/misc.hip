@@ -93,7 +93,8 @@ int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hip
 __global__ __launch_bounds__(256) void rpe_hidden_kernel(const float* __restrict__ te, int te_ld,
                                                          const float* __restrict__ Wd, const float* __restrict__ bd,
                                                          const int64_t* __restrict__ fidx, int T, int C,
-                                                         float* __restrict__ E) {
+                                                         float* __restrict__ E, int zs_te, int zs_w, int zs_b, size_t zs_e) {
+    te += blockIdx.y * zs_te; Wd += blockIdx.y * zs_w; bd += blockIdx.y * zs_b; E += blockIdx.y * zs_e;
     const int row = blockIdx.x;                 // (b*T + t)*T + s
     const int s_ = row % T, bt = row / T, b = bt / T;
     const float d = (float)(fidx[bt] - fidx[b * T + s_]);
@@ -105,8 +106,9 @@ __global__ __launch_bounds__(256) void rpe_hidden_kernel(const float* __restrict
 }
 
 int launch_rpe_hidden(const float* te, int te_ld, const float* Wd, const float* bd, const int64_t* fidx, int B, int T,
-                      int C, float* E, hipStream_t s) {
-    hipLaunchKernelGGL(rpe_hidden_kernel, dim3(B * T * T), dim3(256), 0, s, te, te_ld, Wd, bd, fidx, T, C, E);
+                      int C, float* E, int nz, int zs_te, int zs_w, int zs_b, size_t zs_e, hipStream_t s) {
+    hipLaunchKernelGGL(rpe_hidden_kernel, dim3(B * T * T, nz), dim3(256), 0, s, te, te_ld, Wd, bd, fidx, T, C, E, zs_te, zs_w,
+                       zs_b, zs_e);
     VD_HIP(hipGetLastError());
     return 0;
 }

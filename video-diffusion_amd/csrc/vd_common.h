@@ -60,6 +60,10 @@ struct IgemmArgs {
     // pass over the tensor.  stats_split = blocks per frame (conv_wino_stats_split).  Null: not produced.
     double* stats;
     int stats_split;
+    // gemm_frag.hip only: zcount > 1 runs zcount independent problems of identical shape in one launch (blockIdx.z);
+    // problem z reads src0 + z*zs_a, wfrag + z*zs_w, bias + z*zs_bias and writes out + z*zs_out (element strides).
+    // The three RPE-net output layers of an attention block (unet.py:283-298) go out this way.
+    int zcount, zs_a, zs_w, zs_bias, zs_out;
 };
 
 struct AttnSpatialArgs {
@@ -134,8 +138,9 @@ int launch_assemble(const AssembleArgs& a, hipStream_t s);
 // out[n] = [cos(t*f) | sin(t*f)] with the frequency table built on the host (nn.py:89-107)
 int launch_sinus_embed(const float* t, int n, int dim, const float* freqs, float* out, hipStream_t s);
 // RPENet hidden: E[b,t,s,c] = silu(te[b*T+t][c] + Wd[c][:]*feat(d) + bd[c]), d = fi[b,t]-fi[b,s]  (unet.py:283-296)
+// nz nets at once (blockIdx.y): net z reads te + z*zs_te, Wd + z*zs_w, bd + z*zs_b and writes E + z*zs_e
 int launch_rpe_hidden(const float* te, int te_ld, const float* Wd, const float* bd, const int64_t* fidx, int B, int T,
-                      int C, float* E, hipStream_t s);
+                      int C, float* E, int nz, int zs_te, int zs_w, int zs_b, size_t zs_e, hipStream_t s);
 // bucket-table path (unet.py:330-347): R[b,t,s,:] = table[bucket(d)]
 int launch_rpe_table(const float* table, const int64_t* fidx, int B, int T, int C, float alpha, float beta,
                      float gamma, float* R, hipStream_t s);
