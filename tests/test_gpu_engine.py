@@ -348,3 +348,45 @@ def test_full_sampler_matches_reference_golden(monkeypatch, tag, vertical, obs_f
     close(got, ref, atol=3e-2, rtol=1e-2)                 # test_infer_video_autoreg_vs_oracle for the per-step bound)
     obs = int(rec["obs_length"])
     assert np.array_equal(got[:, :obs], rec["batch"][:, :obs]) and extra.shape == (1,)
+
+
+@pytest.mark.gpu
+def test_step_is_hipgraph_capturable_and_replays_bit_exact():
+    """BASELINE configs[4] runs the denoise step from a captured hipGraph: the engine allocates nothing and never
+    synchronises inside a step, addresses are stable, so two captured p_sample steps replay to the bits of the eager
+    launches (explicit noise; with in-kernel Philox the offset is a launch argument and would be frozen by capture)."""
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=64, num_res_blocks=1,
+                                                              rp_alpha=4, rp_beta=4, rp_gamma=4, timestep_respacing="ddim10")}
+    model, diff = engine(cfg)
+    c = _rand_window(2, 4, 32, 2, seed=5)
+    kw = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in c.items() if k != "x"}
+    kw["x_t_minus_1"] = kw["x0"]
+    x = c["x"].cuda()
+    g1, g2 = torch.Generator().manual_seed(1), torch.Generator().manual_seed(2)
+    n1, n2 = torch.randn(x.shape, generator=g1).cuda(), torch.randn(x.shape, generator=g2).cuda()
+    t9, t8 = torch.full((2,), 9, dtype=torch.int64, device="cuda"), torch.full((2,), 8, dtype=torch.int64, device="cuda")
+
+    def two_steps(inp):
+        a = diff._step(0, model, inp, t9, True, None, kw, 0.0, n1)[0]
+        return diff._step(0, model, a, t8, True, None, kw, 0.0, n2)[0]
+
+    eager = two_steps(x).clone()                                    # also warms up: workspace, kernel attributes
+    torch.cuda.synchronize()
+    static_in = x.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        two_steps(static_in)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=s):
+            out = two_steps(static_in)
+    torch.cuda.synchronize()
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    static_in.copy_(x * 0.5)                                        # new input, same graph
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, two_steps(x * 0.5))
