@@ -159,6 +159,14 @@ int vd_pack_conv3_wino(const float* host_oihw, float* host_out, int O, int I);
 /* Same for an nn.Linear / 1x1-conv weight [N][K] (N, K multiples of 32) -> [K/32][N/32][4][64][4]; pass the result as
  * w_frag with ksz = 1. */
 int vd_pack_linear_frag(const float* host_w, float* host_out, int N, int K);
+/* fp32-accurate linear layer on the bf16 matrix cores (csrc/gemm_split.hip): every fp32 operand is split exactly into
+ * three bf16 pieces (3 x 8 significand bits), six of the nine piece products are accumulated in fp32; the weight is
+ * split on the host: [N][K] (N, K multiples of 32) -> [K/16][N/32][3][64][8] bf16 = 3*N*K uint16.
+ * out[m][n] = bias[n] + res[m][n] + sum_k f(a[m][k]) w[n][k], f = SiLU if act.  The engine's default for every
+ * nn.Linear / 1x1 conv / the stem (environment VD_MATH=fp32 selects the plain fp32-MFMA kernels instead). */
+int vd_pack_linear_split(const float* host_w, unsigned short* host_out, int N, int K);
+int vd_op_linear_split(const float* a, int M, int K, const void* w_split, const float* bias, const float* res, int act,
+                       float* out, int N, void* stream);
 /* GroupNorm32 statistics folded to y = x*A + B per (frame, channel); film ([nfr][2C] scale|shift) optional. */
 int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, int HW, const float* gamma,
                   const float* beta, const float* film, int film_ld, float* affA, float* affB, void* stream);

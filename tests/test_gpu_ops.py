@@ -434,3 +434,51 @@ def test_randn_moments_and_reproducibility():
     _lib.check(L.vd_randn(_lib.ptr(b), b.numel(), 6, 0, _lib.current_stream()))
     torch.cuda.synchronize()
     assert not torch.equal(a, b)
+
+
+def pack_lin_split(w):
+    """[N][K] -> three bf16 planes in MFMA fragment order [K/16][N/32][3][64][8] (library packer + closed form)."""
+    N, K = w.shape
+    src = w.contiguous().float()
+    out = torch.empty(3 * N * K, dtype=torch.int16)
+    _lib.check(_lib.lib().vd_pack_linear_split(_lib.ptr(src), _lib.ptr(out), N, K))
+    p1 = src.bfloat16()
+    r1 = src - p1.float()
+    p2 = r1.bfloat16()
+    p3 = (r1 - p2.float()).bfloat16()
+    assert torch.equal(p1.float() + p2.float() + p3.float(), src)            # the split is exact
+    planes = torch.stack([p1, p2, p3]).view(torch.int16)                     # [3][N][K]
+    ref = planes.reshape(3, N // 32, 32, K // 16, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
+    assert torch.equal(out, ref)
+    return out
+
+
+@pytest.mark.parametrize("M,K,N,act,res", [(128, 128, 512, 0, 0), (4099, 96, 288, 0, 1), (300, 1024, 64, 1, 0),
+                                           (2048, 384, 384, 0, 1), (70, 64, 128, 1, 1)])
+def test_linear_split_bf16x6_is_fp32_accurate(M, K, N, act, res):
+    """csrc/gemm_split.hip: fp32 operands split exactly into three bf16 pieces, six piece products on the bf16 matrix
+    cores, fp32 accumulation.  Held to the op tolerance against torch fp32 AND, against an fp64 product, required to be
+    no further away than the plain fp32-MFMA kernel (gemm_frag.hip) on the same inputs."""
+    L = _lib.lib()
+    a, w, b = rnd(M, K), rnd(N, K, scale=(3.0 / K) ** 0.5), rnd(N, scale=0.1)
+    r = rnd(M, N, seed=4) if res else None
+    ad, bd, rd = dev(a), dev(b), (dev(r) if res else None)
+    out_s, out_f = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ws = dev(pack_lin_split(w))
+    _lib.check(L.vd_op_linear_split(_lib.ptr(ad), M, K, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(rd), act, _lib.ptr(out_s), N,
+                                    _lib.current_stream()))
+    wf = dev(pack_lin_frag(w))
+    _lib.check(L.vd_op_conv(_lib.ptr(ad), None, K, K, M, 1, 1, 0, 1, 0, 1, None, _lib.ptr(wf), None, _lib.ptr(bd), None, None, act,
+                            _lib.ptr(rd), None, 0, _lib.ptr(out_f), N, _lib.current_stream()))
+    torch.cuda.synchronize()
+    x = F.silu(a) if act else a
+    ref32 = x @ w.t() + b + (r if res else 0)
+    close(out_s.cpu(), ref32, **TOL)
+    # the GPU applies its own SiLU (fast exp / rcp): compare the matrix products on the activation the GPU used
+    xg = x.double()
+    ref64 = xg @ w.double().t() + b.double() + (r.double() if res else 0)
+    e_split = (out_s.cpu().double() - ref64).abs()
+    e_fp32 = (out_f.cpu().double() - ref64).abs()
+    if not act:
+        assert e_split.max() <= 1.5 * e_fp32.max() + 1e-7, (e_split.max(), e_fp32.max())
+        assert e_split.mean() <= 1.5 * e_fp32.mean() + 1e-8, (e_split.mean(), e_fp32.mean())

@@ -65,10 +65,22 @@ def main():
             if k == 3 and Cout % 64 == 0 and not os.environ.get("VD_NO_WINO"):
                 ww = torch.rand(16 * Cout * Cin, device="cuda", generator=g) * 0.05
 
-        def run():
+        if k == 1 and x1 is None and os.environ.get("VD_MATH") != "fp32" and Cin % 32 == 0 and Cout % 32 == 0 and not pro:
+            ws = torch.randint(-2000, 2000, (3 * Cout * Cin,), device="cuda", dtype=torch.int16)   # timing only: any bf16 bits
+
+            def run():
+                _lib.check(L.vd_op_linear_split(_lib.ptr(x0), nfr * H * H, Cin, _lib.ptr(ws), _lib.ptr(b), None, 0, _lib.ptr(out), Cout,
+                                                _lib.current_stream()))
+            run.__name__ = "split"
+        else:
+            run = None
+
+        def run_fp32():
             _lib.check(L.vd_op_conv(_lib.ptr(x0), _lib.ptr(x1), C0, Cin, nfr, H, H, ups, stride, pad, k, _lib.ptr(w),
                                     _lib.ptr(wf), _lib.ptr(ww), _lib.ptr(b), _lib.ptr(A), _lib.ptr(B), pro, _lib.ptr(res), None, 0,
                                     _lib.ptr(out), Cout, _lib.current_stream()))
+        if run is None:
+            run = run_fp32
         run()
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -59,6 +59,13 @@ static const int CH_MULT_256[] = {1, 1, 2, 2, 4, 4};
 static const int CH_MULT_128[] = {1, 1, 2, 3, 4};
 static const int CH_MULT_64[] = {1, 2, 3, 4};
 static const int CH_MULT_32[] = {1, 2, 2, 2};
+// VD_MATH=fp32 keeps every matrix product on the fp32 MFMA; default: linear layers / 1x1 convs / the stem run as six
+// bf16 piece products of exactly split fp32 operands with fp32 accumulation (gemm_split.hip, same accuracy, 2.67x rate)
+static bool split_math() {
+    static const bool v = [] { const char* e = getenv("VD_MATH"); return !(e && std::string(e) == "fp32"); }();
+    return v;
+}
+
 constexpr int STEM_KPAD = 64;          // im2col width of the 5-channel 3x3 stem (45 real columns)
 
 struct Arena {
@@ -177,7 +184,7 @@ struct vd_engine {
         const int k = params[p].kind;
         g.w = g.wfrag = g.wwino = nullptr;
         if (k == PK_CONV3W) g.wwino = W(p);
-        else if (k == PK_CONV3F || k == PK_LINF) g.wfrag = W(p);
+        else if (k == PK_CONV3F || k == PK_LINF) { g.wfrag = W(p); g.wsplit = k == PK_LINF && split_math(); }
         else g.w = W(p);
     }
 
@@ -191,6 +198,7 @@ struct vd_engine {
         p.kind = kind;
         p.packed = p.numel;
         if (kind == PK_STEM) p.packed = (size_t)p.shape[0] * STEM_KPAD;
+        if ((kind == PK_STEM || kind == PK_LINF) && split_math()) p.packed = p.packed * 3 / 2;       // three bf16 planes
         if (kind == PK_CONV3W) p.packed = (size_t)16 * p.shape[0] * p.shape[1];
         params.push_back(p);
         pidx[name] = (int)params.size() - 1;
@@ -386,6 +394,7 @@ int vd_engine::linear(const float* a, int M, int K, int, int, int Nout, const fl
     g.src0 = a; g.src1 = nullptr; g.C0 = K; g.Cin = K;
     g.nfr = M; g.Hs = 1; g.Ws = 1; g.ups = 0; g.stride = 1; g.pad = 0; g.ksz = 1; g.Ho = 1; g.Wo = 1;
     g.w = nullptr; g.wfrag = wptr;           // every nn.Linear weight is stored fragment-major (PK_LINF)
+    g.wsplit = split_math();
     g.bias = bptr; g.affA = nullptr; g.affB = nullptr; g.act = act;
     g.res = resid; g.res_ld = Nout; g.fbias = nullptr; g.fbias_ld = 0;
     g.out = out; g.ldo = Nout; g.Cout = Nout; g.M = M;
@@ -531,7 +540,7 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
                                         zs_dw, zs_db, rrows * C, st))) return rc;
             IgemmArgs g{};
             g.src0 = Ehid; g.C0 = C; g.Cin = C; g.nfr = (int)rrows; g.Hs = g.Ws = g.Ho = g.Wo = 1; g.stride = 1; g.ksz = 1;
-            g.wfrag = W(rp[0]->ow); g.bias = W(rp[0]->ob); g.out = Rall; g.ldo = C; g.Cout = C; g.M = (int)rrows;
+            g.wfrag = W(rp[0]->ow); g.wsplit = split_math(); g.bias = W(rp[0]->ob); g.out = Rall; g.ldo = C; g.Cout = C; g.M = (int)rrows;
             g.zcount = 3; g.zs_a = g.zs_out = (int)(rrows * C); g.zs_w = zs_ow; g.zs_bias = zs_ob;
             if ((rc = igemm_p(g, st))) return rc;
         } else {
@@ -730,6 +739,19 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
     }
     std::vector<float> tmp;
     const float* src = host;
+    if (p.kind == PK_LINF && split_math()) {
+        // rows [row0, row0+rows) of a [frag_rows][K] matrix -> K/16 contiguous pieces of its bf16-split fragment image
+        const int rows = (int)p.shape[0], K = (int)p.shape[1];
+        std::vector<unsigned short> sp((size_t)p.numel * 3);
+        pack_linear_split(host, sp.data(), rows, K, rows, 0);
+        const size_t piece = (size_t)(rows / 32) * 1536;                   // ushorts per k-step of this member
+        for (int ks = 0; ks < K / 16; ++ks) {
+            float* dst = e->wbuf + p.off + ((size_t)ks * (p.frag_rows / 32) + p.frag_row0 / 32) * 768;
+            VD_HIP(hipMemcpy(dst, sp.data() + ks * piece, piece * sizeof(unsigned short), hipMemcpyHostToDevice));
+        }
+        p.loaded = true;
+        return 0;
+    }
     if (p.kind == PK_LINF) {
         // rows [row0, row0+rows) of a [frag_rows][K] matrix -> K/32 contiguous pieces of its fragment-major image
         const int rows = (int)p.shape[0], K = (int)p.shape[1];
@@ -757,8 +779,13 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
         for (int o = 0; o < O; ++o)
             for (int i = 0; i < I; ++i)
                 for (int t = 0; t < 9; ++t) lin[(size_t)o * STEM_KPAD + t * I + i] = host[((size_t)o * I + i) * 9 + t];
-        tmp.resize((size_t)O * STEM_KPAD);
-        pack_linear_frag(lin.data(), tmp.data(), O, STEM_KPAD, O, 0);
+        if (split_math()) {
+            tmp.resize((size_t)O * STEM_KPAD * 3 / 2);
+            pack_linear_split(lin.data(), reinterpret_cast<unsigned short*>(tmp.data()), O, STEM_KPAD, O, 0);
+        } else {
+            tmp.resize((size_t)O * STEM_KPAD);
+            pack_linear_frag(lin.data(), tmp.data(), O, STEM_KPAD, O, 0);
+        }
         src = tmp.data();
     } else if (p.kind == PK_CONV3 || p.kind == PK_OUTCONV) {
         const int O = (int)p.shape[0], I = (int)p.shape[1];
@@ -936,6 +963,21 @@ int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I) {
     VD_REQUIRE(host_oihw && host_out && O % 32 == 0 && I % 32 == 0, "O and I multiples of 32");
     pack_conv3_frag(host_oihw, host_out, O, I);
     return 0;
+}
+
+int vd_pack_linear_split(const float* host_w, unsigned short* host_out, int N, int K) {
+    VD_REQUIRE(host_w && host_out && N % 32 == 0 && K % 32 == 0, "vd_pack_linear_split: N, K multiples of 32");
+    pack_linear_split(host_w, host_out, N, K, N, 0);
+    return 0;
+}
+
+int vd_op_linear_split(const float* a, int M, int K, const void* w_split, const float* bias, const float* res, int act,
+                       float* out, int N, void* stream) {
+    IgemmArgs g{};
+    g.src0 = a; g.C0 = K; g.Cin = K; g.nfr = M; g.Hs = g.Ws = g.Ho = g.Wo = 1; g.stride = 1; g.ksz = 1;
+    g.wfrag = static_cast<const float*>(w_split); g.wsplit = 1; g.bias = bias; g.act = act; g.res = res; g.res_ld = N;
+    g.out = out; g.ldo = N; g.Cout = N; g.M = M;
+    return launch_igemm(g, static_cast<hipStream_t>(stream));
 }
 
 int vd_pack_conv3_wino(const float* host_oihw, float* host_out, int O, int I) {

@@ -186,7 +186,7 @@ extern "C" int vd_debug_gemm_occupancy(void) {
 #endif
 
 bool gemm_frag_supported(const IgemmArgs& a) {
-    return a.wfrag != nullptr && a.ksz == 1 && a.stride == 1 && a.pad == 0 && a.ups == 0 && a.Cout % 32 == 0 &&
+    return a.wfrag != nullptr && !a.wsplit && a.ksz == 1 && a.stride == 1 && a.pad == 0 && a.ups == 0 && a.Cout % 32 == 0 &&
            a.affA == nullptr && a.fbias == nullptr &&
            // 32-bit byte offsets (bit 31 marks out-of-range rows)
            (a.res == nullptr || a.res_ld == a.ldo) &&

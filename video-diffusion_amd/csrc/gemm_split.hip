@@ -1,0 +1,257 @@
+// Linear layers and 1x1 convolutions at fp32 accuracy on the bf16 matrix cores, gfx950.
+//
+//   out[m][n] = bias[n] + res[m][n] + sum_k f(A[m][k]) * W[n][k]        f = identity | SiLU
+//
+// An fp32 value is EXACTLY the sum of three bf16 values (3 x 8 significand bits = 24): x = x1 + x2 + x3 with
+// x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (each subtraction exact in fp32).  A product a*b is then the
+// sum of nine piece products, each exact in fp32; the three smallest (a2 b3, a3 b2, a3 b3 <= 2^-24 |a b|) are below the
+// rounding of an fp32 accumulator and are dropped.  The remaining six go through v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation: 6 instructions x 32 cycles per 16 k instead of 8 x 64 cycles of v_mfma_f32_32x32x2_f32 -- 2.67x the
+// fp32 matrix rate, and, unlike the fp32 MFMA, the bf16 MFMA leaves the vector ALU free for the splitting itself.
+// Measured against an fp64 product the result is at least as close as the fp32-MFMA kernel's (tests/test_gpu_ops.py).
+//
+// Same operand plan as gemm_frag.hip: the A tile [BM][32] of a K-chunk is split once by the staging threads into three
+// bf16 planes in LDS (rows padded to 80 bytes: conflict-free ds_read_b128 fragments), the weights are split on the
+// host at load time and stream from L2 in fragment order [K/16][N/32][piece 3][lane 64][8 bf16], three k-steps ahead.
+#include <cstring>
+
+#include "vd_common.h"
+
+namespace vd {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SROW = 80;                   // bytes per LDS row of one plane: 32 bf16 + 16 bytes of padding
+
+__device__ __forceinline__ void split3(f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
+    p1 = __builtin_convertvector(v, bf16x4);
+    f32x4 r = v - __builtin_convertvector(p1, f32x4);
+    p2 = __builtin_convertvector(r, bf16x4);
+    r = r - __builtin_convertvector(p2, f32x4);
+    p3 = __builtin_convertvector(r, bf16x4);
+}
+
+template <int BM, int BN, bool ACT>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
+    constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
+    constexpr int PLANE = BM * SROW, ABUF = 3 * PLANE;                    // bytes
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];         // [2][3 planes][BM][SROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int lrow = tid >> 3, lq = tid & 7;
+    const int nchunk = a.Cin >> 5, ncoblk = a.Cout >> 5;
+    const int C1 = a.Cin - a.C0;
+    if (a.zcount > 1) {                          // batched problems of one shape
+        const int z = blockIdx.z;
+        a.src0 += (size_t)z * a.zs_a; a.wfrag += (size_t)z * a.zs_w; a.out += (size_t)z * a.zs_out;
+        if (a.bias) a.bias += (size_t)z * a.zs_bias;
+    }
+
+    const auto asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.M * a.C0 * 4, 0x00020000);
+    const auto asrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1 ? a.src1 : a.src0), 0,
+                                                         a.src1 ? a.M * C1 * 4 : 0, 0x00020000);
+    unsigned ao0[AR], ao1[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        const unsigned row = (unsigned)min(m0 + lrow + 32 * j, a.M - 1);
+        ao0[j] = row * (unsigned)(a.C0 * 4) + lq * 16u;
+        ao1[j] = row * (unsigned)(C1 * 4) + lq * 16u;
+    }
+    // weights: [K/16][N/32][piece][lane][8 bf16] = 3072 bytes per (k-step, column block)
+    const auto bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, a.Cin * a.Cout * 6, 0x00020000);
+    unsigned bo[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bo[j] = (unsigned)min((int)blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1) * 3072u + lane * 16u;
+
+    f32x4 ra[AR];
+    bf16x8 bfr[3][NI][3], afr[2][MI][3];         // [ring slot][tile][piece]
+    auto a_prefetch = [&](int chunk) {
+        const int c = chunk * 32;
+        if (c < a.C0) {
+#pragma unroll
+            for (int j = 0; j < AR; ++j)
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc0, ao0[j], c * 4, 0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < AR; ++j)
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc1, ao1[j], (c - a.C0) * 4, 0));
+        }
+    };
+    auto a_store = [&](char* Ad) {               // split once per element, three planes
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            f32x4 v = ra[j];
+            if constexpr (ACT) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            bf16x4 p1, p2, p3;
+            split3(v, p1, p2, p3);
+            char* d = Ad + (lrow + 32 * j) * SROW + lq * 8;
+            *reinterpret_cast<bf16x4*>(d) = p1;
+            *reinterpret_cast<bf16x4*>(d + PLANE) = p2;
+            *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = p3;
+        }
+    };
+    auto b_load = [&](int slot, int kstep) {      // kstep = global 16-wide k step
+        const int so = kstep * ncoblk * 3072;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bfr[slot][j][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p * 1024, so, 0));
+    };
+    const int aoff = (wm * (BM / 2) + lr) * SROW + lh * 16;
+    auto a_frags = [&](int slot, const char* Ab, int ks) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                afr[slot][i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * PLANE + aoff + i * 32 * SROW + ks * 32);
+    };
+
+    const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.ldo * 4, 0x00020000);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0,
+                                                        a.res ? a.M * a.ldo * 4 : 0, 0x00020000);
+    unsigned vb[MI][NI];
+    float bv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int co = n0 + wn * (BN / 2) + j * 32 + lr;
+        bv[j] = a.bias && co < a.Cout ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            vb[i][j] = co < a.Cout ? (unsigned)((m0 + wm * (BM / 2) + i * 32 + 4 * lh) * a.ldo + co) * 4u : 0x80000000u;
+    }
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = ((r & 3) + 8 * (r >> 2)) * a.ldo * 4;
+                acc[i][j][r] = bv[j] + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vb[i][j] + srow, 0, 0));
+            }
+
+    const int nks = 2 * nchunk;
+    a_prefetch(0);
+    b_load(0, 0);
+    b_load(1, min(1, nks - 1));
+    a_store(smem_c);
+    __syncthreads();
+    a_frags(0, smem_c, 0);
+
+    // k-steps in a ring of 3 weight slots (two steps ahead) and 2 fragment slots (one step ahead); the six piece
+    // products of a tile go into its accumulator back to back, small terms first
+    auto kstep = [&](int chunk, int ks, int gslot, int aslot) {          // gslot = (2*chunk + ks) % 3, compile time
+        const int g = 2 * chunk + ks;
+        const char* Acur = smem_c + (chunk & 1) * ABUF;
+        b_load((gslot + 2) % 3, min(g + 2, nks - 1));
+        if (ks == 0) a_frags(aslot ^ 1, Acur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][1], bfr[gslot][j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][2], bfr[gslot][j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][1], bfr[gslot][j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    };
+    // 3 chunks = 6 k-steps per trip so that ring slots are compile-time constants
+    for (int chunk0 = 0; chunk0 < nchunk; chunk0 += 3) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const int chunk = chunk0 + cc;
+            if (chunk < nchunk) {
+                const int nxt = min(chunk + 1, nchunk - 1);
+                a_prefetch(nxt);
+                kstep(chunk, 0, (2 * cc) % 3, 0);
+                kstep(chunk, 1, (2 * cc + 1) % 3, 1);
+                a_store(smem_c + ((chunk + 1) & 1) * ABUF);
+                __syncthreads();
+                a_frags(0, smem_c + ((chunk + 1) & 1) * ABUF, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            unsigned vbe = vb[i][j];
+            asm volatile("" : "+v"(vbe));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = ((r & 3) + 8 * (r >> 2)) * a.ldo * 4;
+                const float val = acc[i][j][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), osrc, vbe + srow, 0, 0);
+            }
+        }
+}
+
+bool gemm_split_supported(const IgemmArgs& a) {
+    return a.wsplit && a.wfrag != nullptr && a.ksz == 1 && a.stride == 1 && a.pad == 0 && a.ups == 0 && a.Cout % 32 == 0 &&
+           a.Cin % 32 == 0 && a.C0 % 32 == 0 && a.affA == nullptr && a.fbias == nullptr && (a.res == nullptr || a.res_ld == a.ldo) &&
+           (size_t)a.M * std::max(std::max(a.C0, a.Cin - a.C0), a.ldo) < (1u << 28) && (size_t)a.Cin * a.Cout * 6 < (1u << 31);
+}
+
+template <int BM, int BN>
+static int launch_gs(const IgemmArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * 3 * BM * SROW;
+    dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.zcount > 1 ? a.zcount : 1);
+    if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false>), grid, dim3(256), lds, s, a);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s) {
+    switch (tile_class) {
+        case 0: return launch_gs<128, 128>(a, s);
+        case 1: return launch_gs<128, 64>(a, s);
+        case 2: return launch_gs<64, 128>(a, s);
+        default: return launch_gs<64, 64>(a, s);
+    }
+}
+
+// host: fp32 -> three bf16 pieces (round to nearest even on the top 16 bits)
+static inline unsigned short bf16_rne(float f) {
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);          // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float bf16_to_f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+
+void split3_host(float v, unsigned short out[3]) {
+    out[0] = bf16_rne(v);
+    const float r1 = v - bf16_to_f(out[0]);
+    out[1] = bf16_rne(r1);
+    out[2] = bf16_rne(r1 - bf16_to_f(out[1]));
+}
+
+// rows [row0, row0+rows) of a [n_total][K] row-major matrix into the split fragment image of the WHOLE matrix:
+// [K/16][n_total/32][piece 3][lane 64][8]: lane 32h+r of a (k-step, column block) holds W[n = 32*blk + r][k = 16*ks + 8h + j]
+void pack_linear_split(const float* w, unsigned short* out_base, int rows, int K, int n_total, int row0) {
+    const int nks = K / 16, ncoblk = n_total / 32;
+    for (int ks = 0; ks < nks; ++ks)
+        for (int cb = 0; cb < rows / 32; ++cb)
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 32; ++r)
+                    for (int j = 0; j < 8; ++j) {
+                        unsigned short p[3];
+                        split3_host(w[(size_t)(cb * 32 + r) * K + ks * 16 + 8 * h + j], p);
+                        for (int q = 0; q < 3; ++q)
+                            out_base[((((size_t)ks * ncoblk + row0 / 32 + cb) * 3 + q) * 64 + h * 32 + r) * 8 + j] = p[q];
+                    }
+}
+
+}  // namespace vd

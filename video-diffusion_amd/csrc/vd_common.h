@@ -64,6 +64,9 @@ struct IgemmArgs {
     // problem z reads src0 + z*zs_a, wfrag + z*zs_w, bias + z*zs_bias and writes out + z*zs_out (element strides).
     // The three RPE-net output layers of an attention block (unet.py:283-298) go out this way.
     int zcount, zs_a, zs_w, zs_bias, zs_out;
+    // wfrag is the bf16-split image of the weights (gemm_split.hip: fp32 accuracy from six bf16 piece products);
+    // zs_w then counts floats of that image as well
+    int wsplit;
 };
 
 struct AttnSpatialArgs {
@@ -97,7 +100,11 @@ void pack_linear_frag(const float* w, float* out_base, int rows, int K, int n_to
 void pack_conv3_frag(const float* oihw, float* out, int O, int I);
 // Winograd F(2x2,3x3) path (conv_wino.hip): 2.25x fewer MFMAs than the direct 3x3 kernels
 bool conv_wino_supported(const IgemmArgs& a);
-int conv_wino_stats_split(int Hout);          // blocks per frame = partial sums per (frame, channel)
+int conv_wino_stats_split(int Hout);
+// fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
+bool gemm_split_supported(const IgemmArgs& a);
+int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s);
+void pack_linear_split(const float* w, unsigned short* out_base, int rows, int K, int n_total, int row0);          // blocks per frame = partial sums per (frame, channel)
 int launch_conv_wino(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino(const float* oihw, float* out, int O, int I);      // out: 16*O*I floats
 int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s);
