@@ -165,6 +165,14 @@ int vd_pack_linear_frag(const float* host_w, float* host_out, int N, int K);
  * out[m][n] = bias[n] + res[m][n] + sum_k f(a[m][k]) w[n][k], f = SiLU if act.  The engine's default for every
  * nn.Linear / 1x1 conv / the stem (environment VD_MATH=fp32 selects the plain fp32-MFMA kernels instead). */
 int vd_pack_linear_split(const float* host_w, unsigned short* host_out, int N, int K);
+/* The same arithmetic for the 3x3 convs (csrc/conv_wino_split.hip): Winograd F(2x2,3x3) whose element products run as
+ * six bf16 piece products of the exactly split fp32 operands.  Weights: OIHW -> U = G g G^T (row 2 negated) split into
+ * [I/16][16][O/32][3][64][8] bf16 = 48*O*I uint16.  One plain source tensor, stride 1, square power-of-two >= 8x8,
+ * O % 32 == 0, I % 32 == 0; gn_part as vd_op_conv_stats (or NULL). */
+int vd_pack_conv3_wino_split(const float* host_oihw, unsigned short* host_out, int O, int I);
+int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
+                          const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
+                          void* stream);
 int vd_op_linear_split(const float* a, int M, int K, const void* w_split, const float* bias, const float* res, int act,
                        float* out, int N, void* stream);
 /* GroupNorm32 statistics folded to y = x*A + B per (frame, channel); film ([nfr][2C] scale|shift) optional. */

@@ -482,3 +482,46 @@ def test_linear_split_bf16x6_is_fp32_accurate(M, K, N, act, res):
     if not act:
         assert e_split.max() <= 1.5 * e_fp32.max() + 1e-7, (e_split.max(), e_fp32.max())
         assert e_split.mean() <= 1.5 * e_fp32.mean() + 1e-8, (e_split.mean(), e_fp32.mean())
+
+
+def pack_wino_split(w):
+    O, I = w.shape[:2]
+    out = torch.empty(48 * O * I, dtype=torch.int16)
+    _lib.check(_lib.lib().vd_pack_conv3_wino_split(_lib.ptr(w.contiguous().float()), _lib.ptr(out), O, I))
+    return out
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,ups", [(3, 64, 128, 16, 0), (5, 32, 64, 8, 0), (2, 96, 160, 32, 0), (9, 64, 32, 8, 0),
+                                               (1, 128, 64, 64, 0), (2, 64, 64, 8, 1)])
+def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups):
+    """csrc/conv_wino_split.hip: Winograd F(2x2,3x3) with the element products as six bf16 piece products of exactly
+    split fp32 operands.  Held to the op tolerance against torch fp32, required to be no further from an fp64 conv than
+    the fp32-MFMA Winograd kernel, and its GroupNorm partial sums checked against the stored output."""
+    L = _lib.lib()
+    x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, scale=(3.0 / (9 * Cin)) ** 0.5), rnd(Cout, scale=0.1)
+    Ho = H << ups
+    res = rnd(N, Cout, Ho, Ho, seed=4)
+    fb = rnd(N, Cout, seed=5)
+    xd, bd, rd, fd = dev(nhwc(x)), dev(b), dev(nhwc(res)), dev(fb)
+    out_s = torch.empty(N, Ho, Ho, Cout, device="cuda")
+    split = L.vd_conv_stats_split(Ho)
+    part = torch.full((N, split, Cout, 2), float("nan"), dtype=torch.float64, device="cuda")
+    ws = dev(pack_wino_split(w))
+    _lib.check(L.vd_op_conv_wino_split(_lib.ptr(xd), Cin, N, H, H, ups, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(fd), Cout,
+                                       _lib.ptr(out_s), Cout, _lib.ptr(part), _lib.current_stream()))
+    torch.cuda.synchronize()
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    ref = F.conv2d(xin, w, b, padding=1) + res + fb[:, :, None, None]
+    got = out_s.permute(0, 3, 1, 2).cpu()
+    close(got, ref, **TOL)
+    ref64 = F.conv2d(xin.double(), w.double(), b.double(), padding=1) + res.double() + fb.double()[:, :, None, None]
+    e_split = (got.double() - ref64).abs()
+    if Cout % 64 == 0:                                              # the fp32-MFMA Winograd kernel on the same inputs
+        out_f = run_conv(x, None, w, b, ups=ups, res=res, fbias=fb)
+        e_fp32 = (out_f.double() - ref64).abs()
+        assert e_split.max() <= 1.5 * e_fp32.max() + 1e-7, (e_split.max(), e_fp32.max())
+        assert e_split.mean() <= 1.5 * e_fp32.mean() + 1e-8, (e_split.mean(), e_fp32.mean())
+    o64 = out_s.double()
+    tot = part.sum(1).cpu()
+    close(tot[..., 0], o64.sum((1, 2)).cpu(), atol=1e-3, rtol=1e-5)
+    close(tot[..., 1], (o64 * o64).sum((1, 2)).cpu(), atol=1e-3, rtol=1e-5)

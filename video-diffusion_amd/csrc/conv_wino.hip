@@ -425,7 +425,7 @@ static bool wino_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 bool conv_wino_supported(const IgemmArgs& a) {
     const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
-    return a.wwino != nullptr && a.ksz == 3 && a.stride == 1 && a.pad == 1 && Hl == Wl && wino_pow2(Hl) && Hl >= 8 &&
+    return a.wwino != nullptr && !a.wsplit && a.ksz == 3 && a.stride == 1 && a.pad == 1 && Hl == Wl && wino_pow2(Hl) && Hl >= 8 &&
            a.Cout % 64 == 0 && a.Cin % (2 * WKC) == 0 && a.src1 == nullptr && a.C0 == a.Cin && a.affA == nullptr && a.act == 0 &&
            // 32-bit byte offsets into the source (bit 31 marks the padding) / residual / output
            (size_t)a.nfr * a.Hs * a.Ws * a.Cin < (1u << 29) &&

@@ -66,6 +66,13 @@ static bool split_math() {
     return v;
 }
 
+// The 3x3 Winograd convs have the same option (conv_wino_split.hip); it is not yet faster than the fp32-MFMA kernel
+// (VALU- and LDS-bound, tools/winos_timing.py), so it is opt-in: VD_CONV_SPLIT=1.
+static bool split_conv() {
+    static const bool v = [] { const char* e = getenv("VD_CONV_SPLIT"); return e && std::string(e) == "1" && split_math(); }();
+    return v;
+}
+
 constexpr int STEM_KPAD = 64;          // im2col width of the 5-channel 3x3 stem (45 real columns)
 
 struct Arena {
@@ -119,12 +126,13 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     const double in_pix = (double)g.nfr * g.Hs * g.Ws;
     const double nz = g.zcount > 1 ? g.zcount : 1;
     const double bytes = nz * 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout);
-    const int cls = conv_wino_supported(g) ? (int)PC_CONV_WINO
+    const int cls = conv_wino_supported(g) || conv_wino_split_supported(g) ? (int)PC_CONV_WINO
                                            : igemm_tile_class(g.M, g.Cout) + (conv_halo_supported(g) ? (int)PC_CONV_128x128 : 0);
     char tag[56];
     snprintf(tag, sizeof(tag), "M=%d N=%d K=%d k%d s%d%s%s%s", g.M, g.Cout, g.Cin, g.ksz, g.stride, g.ups ? " ups" : "",
              g.affA ? " pro" : (g.act ? " act" : ""), g.res ? " res" : "");
-    VD_REQUIRE(g.stats == nullptr || conv_wino_supported(g), "GroupNorm partial sums requested from a kernel that has no such epilogue");
+    VD_REQUIRE(g.stats == nullptr || conv_wino_supported(g) || conv_wino_split_supported(g),
+               "GroupNorm partial sums requested from a kernel that has no such epilogue");
     ProfScope ps(cls, nz * 2.0 * g.M * g.Cout * cin * taps, bytes, st, tag);
     return launch_igemm(g, st);
 }
@@ -183,7 +191,7 @@ struct vd_engine {
     void set_w(vd::IgemmArgs& g, int p) const {
         const int k = params[p].kind;
         g.w = g.wfrag = g.wwino = nullptr;
-        if (k == PK_CONV3W) g.wwino = W(p);
+        if (k == PK_CONV3W) { g.wwino = W(p); g.wsplit = split_conv(); }
         else if (k == PK_CONV3F || k == PK_LINF) { g.wfrag = W(p); g.wsplit = k == PK_LINF && split_math(); }
         else g.w = W(p);
     }
@@ -199,7 +207,7 @@ struct vd_engine {
         p.packed = p.numel;
         if (kind == PK_STEM) p.packed = (size_t)p.shape[0] * STEM_KPAD;
         if ((kind == PK_STEM || kind == PK_LINF) && split_math()) p.packed = p.packed * 3 / 2;       // three bf16 planes
-        if (kind == PK_CONV3W) p.packed = (size_t)16 * p.shape[0] * p.shape[1];
+        if (kind == PK_CONV3W) p.packed = (size_t)16 * p.shape[0] * p.shape[1] * (split_conv() ? 3 : 2) / 2;
         params.push_back(p);
         pidx[name] = (int)params.size() - 1;
         return (int)params.size() - 1;
@@ -765,7 +773,11 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
         p.loaded = true;
         return 0;
     }
-    if (p.kind == PK_CONV3W) {
+    if (p.kind == PK_CONV3W && split_conv()) {
+        tmp.resize(p.packed);
+        pack_conv3_wino_split(host, reinterpret_cast<unsigned short*>(tmp.data()), (int)p.shape[0], (int)p.shape[1]);
+        src = tmp.data();
+    } else if (p.kind == PK_CONV3W) {
         tmp.resize(p.packed);
         pack_conv3_wino(host, tmp.data(), (int)p.shape[0], (int)p.shape[1]);
         src = tmp.data();
@@ -963,6 +975,26 @@ int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I) {
     VD_REQUIRE(host_oihw && host_out && O % 32 == 0 && I % 32 == 0, "O and I multiples of 32");
     pack_conv3_frag(host_oihw, host_out, O, I);
     return 0;
+}
+
+int vd_pack_conv3_wino_split(const float* host_oihw, unsigned short* host_out, int O, int I) {
+    VD_REQUIRE(host_oihw && host_out && O % 32 == 0 && I % 32 == 0, "vd_pack_conv3_wino_split: O, I multiples of 32");
+    pack_conv3_wino_split(host_oihw, host_out, O, I);
+    return 0;
+}
+
+int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
+                          const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
+                          void* stream) {
+    IgemmArgs g{};
+    g.src0 = src0; g.C0 = Cin; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws; g.ups = ups;
+    g.stride = 1; g.pad = 1; g.ksz = 3;
+    g.Ho = Hs << ups; g.Wo = Ws << ups;
+    g.wwino = static_cast<const float*>(w_split); g.wsplit = 1; g.bias = bias; g.res = res; g.res_ld = Cout;
+    g.fbias = fbias; g.fbias_ld = fbias_ld; g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
+    g.stats = gn_part; g.stats_split = conv_wino_stats_split(g.Ho);
+    VD_REQUIRE(conv_wino_split_supported(g), "vd_op_conv_wino_split: shape not covered by the kernel");
+    return launch_igemm(g, static_cast<hipStream_t>(stream));
 }
 
 int vd_pack_linear_split(const float* host_w, unsigned short* host_out, int N, int K) {

@@ -204,7 +204,8 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     VD_REQUIRE(a.M > 0 && a.Cout > 0, "empty problem");
     VD_REQUIRE(a.M == a.nfr * a.Ho * a.Wo, "M != nfr*Ho*Wo");
     if (gemm_split_supported(a)) return launch_gemm_split(a, igemm_tile_class(a.M, a.Cout), s);
-    VD_REQUIRE(!a.wsplit, "bf16-split weights given for a shape the split GEMM does not cover");
+    if (conv_wino_split_supported(a)) return launch_conv_wino_split(a, s);
+    VD_REQUIRE(!a.wsplit, "bf16-split weights given for a shape the split kernels do not cover");
     if (gemm_frag_supported(a)) return launch_gemm_frag(a, igemm_tile_class(a.M, a.Cout), s);
     if (conv_wino_supported(a)) return launch_conv_wino(a, s);
     static const bool no_halo = getenv("VD_NO_HALO") != nullptr;     // A/B switch for tools/bench_conv.py

@@ -101,6 +101,10 @@ void pack_conv3_frag(const float* oihw, float* out, int O, int I);
 // Winograd F(2x2,3x3) path (conv_wino.hip): 2.25x fewer MFMAs than the direct 3x3 kernels
 bool conv_wino_supported(const IgemmArgs& a);
 int conv_wino_stats_split(int Hout);
+// fp32-accurate Winograd conv on the bf16 matrix cores (conv_wino_split.hip); weights: [Cin/16][16][Cout/32][3][64][8] bf16
+bool conv_wino_split_supported(const IgemmArgs& a);
+int launch_conv_wino_split(const IgemmArgs& a, hipStream_t s);
+void pack_conv3_wino_split(const float* oihw, unsigned short* out, int O, int I);
 // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
 bool gemm_split_supported(const IgemmArgs& a);
 int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s);
