@@ -55,32 +55,42 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// x = p1 + p2 + p3 exactly, per pair of values: one packed convert, the two pieces widened back by a shift and a mask,
-// one (packed) subtraction per level -- 9 VALU per pair
-__device__ __forceinline__ void split_pair(f32x2 v, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-    v -= f32x2{__builtin_bit_cast(float, p1 << 16), __builtin_bit_cast(float, p1 & 0xffff0000u)};
-    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-    v -= f32x2{__builtin_bit_cast(float, p2 << 16), __builtin_bit_cast(float, p2 & 0xffff0000u)};
-    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+// x = p1 + p2 + p3 exactly, per pair of fp32 values, by truncation: p1 = top 16 bits of x (a bf16 value), r = x - p1
+// (exact: the low 16 significand bits), p2 = top 16 bits of r, p3 = r - p2 (at most 8 significant bits: a bf16 value).
+// The bf16 pieces of a pair are the high halves of two registers, packed by one v_perm_b32: 11 VALU per pair, no
+// conversions and no dependent-convert latencies; asm so that it stays exactly this sequence.
+__device__ __forceinline__ void split_pair(f32x2 v, unsigned& p1, unsigned& p2, unsigned& p3, unsigned sel) {
+    float h0, h1, r0, r1;
+    asm("v_and_b32 %3, 0xffff0000, %7\n\t"
+        "v_and_b32 %4, 0xffff0000, %8\n\t"
+        "v_perm_b32 %0, %8, %7, %9\n\t"
+        "v_sub_f32 %5, %7, %3\n\t"
+        "v_sub_f32 %6, %8, %4\n\t"
+        "v_and_b32 %3, 0xffff0000, %5\n\t"
+        "v_and_b32 %4, 0xffff0000, %6\n\t"
+        "v_perm_b32 %1, %6, %5, %9\n\t"
+        "v_sub_f32 %5, %5, %3\n\t"
+        "v_sub_f32 %6, %6, %4\n\t"
+        "v_perm_b32 %2, %6, %5, %9"
+        : "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(h0), "=&v"(h1), "=&v"(r0), "=&v"(r1)
+        : "v"(v.x), "v"(v.y), "s"(sel));
 }
-__device__ __forceinline__ void split8(f32x8 v, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-    unsigned a[4], b[4], c[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split_pair(f32x2{v[2 * i], v[2 * i + 1]}, a[i], b[i], c[i]);
-    p1 = __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], a[2], a[3]});
-    p2 = __builtin_bit_cast(bf16x8, u32x4{b[0], b[1], b[2], b[3]});
-    p3 = __builtin_bit_cast(bf16x8, u32x4{c[0], c[1], c[2], c[3]});
-}
-
 template <bool TF4>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_split_kernel(IgemmArgs a, WinoSGeom g) {
     constexpr int TTL = TF4 ? 2 : 3, TT = 1 << TTL, P = 2 * TT + 2;   // tiles per dim per frame, patch width
     constexpr int NX = TF4 ? 7 : 6;            // patch float4 per thread
     constexpr int SS = TF4 ? 16 : 64;          // patch-pixel step between a thread's staged elements
-    constexpr int FS = TF4 ? 112 : 384;        // LDS pixels per frame slot (>= P*P, = NX * SS)
-    constexpr int XBUF = (TF4 ? 4 : 1) * FS * SLD;
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // [2][XBUF]; reused as Z exchange at the end
+    // LDS image of a patch (bytes): pixels of even and odd x in two planes per row, 80 bytes per pixel (16 channels + 16
+    // bytes of padding), rows RSB apart, frames FSB apart.  A fragment read takes the same (row, column) of 16 tiles per
+    // lane group: neighbouring tiles are neighbouring pixels of ONE plane (5 slots of 16 bytes apart), and RSB / FSB are
+    // chosen so that the tile rows / frames of a group land on the remaining slot classes: every ds_read_b128 of the
+    // loop is bank-conflict free (the straightforward [pixel][20 floats] image was 2- to 4-way conflicted, and at the
+    // bf16 MFMA rate the LDS was as busy as the matrix pipe).
+    constexpr int PSB = 80, POB = (P / 2) * PSB;
+    constexpr int RSB = TF4 ? 800 : 1472;      // >= 2*POB; = 2 (TF4) / 4 (else) mod 8 slots
+    constexpr int FSB = TF4 ? 8192 : 0;
+    constexpr int XBUF = (TF4 ? 4 * FSB : P * RSB) / 4;              // floats per patch buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [2][XBUF] + a dump slot; reused as Z exchange
     const int tid = threadIdx.x, lane = tid & 63;
     const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);          // Winograd row owned by this wave (scalar)
     const int lr = lane & 31, lh = lane >> 5;
@@ -109,7 +119,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_split_kernel(IgemmArgs a,
                    : 0x80000000u;
     }
     const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
-    const int xw = (sf * FS + sp0) * SLD + lq * 4;
+    int xw[NX];                                                       // LDS float offset of each staged element
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+        const int pl = sp0 + SS * e;
+        const int py = pl / P, px = pl - py * P;
+        // in 16-byte units: the f32x4 indexing below keeps every LDS access provably aligned (a float-offset pointer
+        // made hipcc fall back to ds_read2_b32 pairs)
+        xw[e] = pl < P * P ? (sf * FSB + py * RSB + (px & 1) * POB + (px >> 1) * PSB) / 16 + lq
+                           : 2 * (XBUF / 4) + (sf * (NX * SS - P * P) + pl - P * P) * 4 + lq;   // past the patch: own dump slot
+    }
     f32x4 rx[2][NX];
     auto x_load_one = [&](int set, int chunk, int e) {
         rx[set][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xo[e], chunk * (SKC * 4), 0));
@@ -117,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_split_kernel(IgemmArgs a,
     auto x_store = [&](int set, int buf, int e0, int e1) {
 #pragma unroll
         for (int e = 0; e < NX; ++e)
-            if (e >= e0 && e < e1) *reinterpret_cast<f32x4*>(smem + xw + buf * XBUF + e * SS * SLD) = rx[set][e];
+            if (e >= e0 && e < e1) reinterpret_cast<f32x4*>(smem)[xw[e] + buf * (XBUF / 4)] = rx[set][e];
     };
 
     // ---- A fragments: lane (tile m*32+lr, k-half lh) holds 8 channels (8*lh ..) of 4 positions, each as 3 bf16 pieces.
@@ -129,12 +148,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_split_kernel(IgemmArgs a,
     for (int m = 0; m < 2; ++m) {
         const int t = m * 32 + lr;
         const int tx = t & (TT - 1), ty = (t >> TTL) & (TT - 1), f = t >> (2 * TTL);
-        const int xb = (f * FS + 2 * ty * P + 2 * tx) * SLD + lh * 8;
-        ab[m][0] = xb + r0 * P * SLD; ab[m][1] = xb + r1 * P * SLD;
+        const int xb = (f * FSB + 2 * ty * RSB + tx * PSB) / 16 + lh * 2;          // 16-byte units
+        ab[m][0] = xb + r0 * (RSB / 16); ab[m][1] = xb + r1 * (RSB / 16);
     }
     f32x4 raw[16];                                                   // [row r0/r1][column 4][channel half 2]
     auto a_read_one = [&](int buf, int m, int i) {
-        raw[i] = *reinterpret_cast<const f32x4*>(smem + ab[m][i >> 3] + buf * XBUF + ((i >> 1) & 3) * SLD + (i & 1) * 4);
+        const int c = (i >> 1) & 3;                                  // patch column 2*tx + c: plane c&1, pixel tx + (c>>1)
+        raw[i] = reinterpret_cast<const f32x4*>(smem)[ab[m][i >> 3] + buf * (XBUF / 4) + ((c & 1) * POB + (c >> 1) * PSB) / 16 + (i & 1)];
     };
     // raw -> three bf16 pieces of the four fragments, in 24 pieces of work, one per MFMA slot of the running group:
     //   pieces 0..3    row combination of patch column c:  t[c] = d[r1][c]*sg + d[r0][c]             (4 packed fma)
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_split_kernel(IgemmArgs a,
                 fcur = j == 0 ? tc[0] - tc[2] : j == 1 ? tc[1] + tc[2] : j == 2 ? tc[2] - tc[1] : tc[1] - tc[3];
             } else {
                 unsigned p1, p2, p3;
-                split_pair(f32x2{fcur[2 * (s_ - 1)], fcur[2 * (s_ - 1) + 1]}, p1, p2, p3);
+                split_pair(f32x2{fcur[2 * (s_ - 1)], fcur[2 * (s_ - 1) + 1]}, p1, p2, p3, 0x07060302u);
                 apc[slot][j][0][s_ - 1] = p1; apc[slot][j][1][s_ - 1] = p2; apc[slot][j][2][s_ - 1] = p3;
             }
         }
@@ -358,7 +378,7 @@ int launch_conv_wino_split(const IgemmArgs& a, hipStream_t s) {
     const int TT = Hl >= 16 ? 8 : 4;
     g.TF = 64 / (TT * TT);
     g.tiles_x = Hl / (2 * TT); g.tiles_y = Hl / (2 * TT);
-    const size_t lds = std::max((size_t)2 * (g.TF == 4 ? 7 : 6) * 64 * SLD * sizeof(float), (size_t)8 * 2048 * sizeof(float));
+    const size_t lds = std::max((size_t)3 * (g.TF == 4 ? 4 * 8192 : 18 * 1472) + 64, (size_t)8 * 2048 * sizeof(float));   // 2 buffers + dump
     static bool attr = false;
     if (!attr) {
         const void* fns[2] = {reinterpret_cast<const void*>(&conv3x3_wino_split_kernel<true>),
