@@ -185,3 +185,32 @@ def test_eval_dir_naming_matches_reference(tmp_path):
         f.write_text("{}")
     with tu.Protect(f, timeout=0.5):
         pass
+
+
+def test_remaining_schedulers_match_reference():
+    """goal-directed / visualisation / frameskip schedules (inference_util.py:534-776) against the
+    sequences -- and the failures -- of the reference itself (tools/gen_golden_full.py)."""
+    import contextlib
+    import io
+
+    from helpers import load_json
+    from video_diffusion_amd import inference_util as iu
+    rec = load_json("schedulers_more.json")
+    assert len(rec["cases"]) >= 15
+    for c in rec["cases"]:
+        L, n_obs, max_frames, step = c["args"]
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                it = iter(iu.inference_strategies[c["mode"]](video_length=L, num_obs=n_obs, max_frames=max_frames, step_size=step))
+                seq = []
+                for o, l in it:
+                    seq.append([[int(i) for i in o], [int(i) for i in l]])
+                    assert len(seq) <= 400
+            assert "seq" in c and seq == c["seq"], (c["mode"], c["args"])
+        except AssertionError as e:
+            if "error" not in c:
+                raise
+            assert c["error"] == "AssertionError", (c, e)
+    # every non-adaptive mode of the reference registry exists here
+    missing = [m for m in rec["modes"] if not m.startswith("adaptive") and m not in iu.inference_strategies]
+    assert not missing, missing

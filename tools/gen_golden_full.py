@@ -105,8 +105,39 @@ def gen_eval_paths():
     json.dump(cases, open(os.path.join(OUT, "eval_paths.json"), "w"), indent=1)
 
 
+def gen_more_schedulers():
+    """the goal-directed / visualisation / frameskip schedules (inference_util.py:534-776), integer logic."""
+    import contextlib
+    import io
+    from improved_diffusion import inference_util as iu
+    cases = []
+    for mode, args in [("goal-directed-autoreg", (30, 4, 10, 3)), ("goal-directed-autoreg", (64, 8, 20, 5)),
+                       ("goal-directed-mixed", (40, 6, 12, 4)), ("goal-directed-mixed", (64, 8, 20, 5)),
+                       ("goal-directed-hierarchy-2", (100, 10, 20, 5)), ("goal-directed-hierarchy-2", (64, 8, 16, 4)),
+                       ("ho-et-al-for-vis", (64, 0, 16, 8)), ("ho-et-al-for-vis", (40, 0, 16, 8)),
+                       ("baby-cond-ho-et-al-for-vis", (30, 4, 7, 3)),
+                       ("google", (64, 8, 16, 8)), ("google", (100, 4, 16, 8)), ("google", (37, 5, 16, 8)),
+                       ("like-google", (64, 8, 16, 8)), ("like-google", (50, 5, 12, 4)), ("like-google", (30, 1, 10, 3))]:
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                it = iter(iu.inference_strategies[mode](video_length=args[0], num_obs=args[1], max_frames=args[2],
+                                                        step_size=args[3]))
+                seq = []
+                for o, l in it:
+                    seq.append([[int(i) for i in o], [int(i) for i in l]])
+                    if len(seq) > 400:
+                        raise RuntimeError("does not terminate")
+            cases.append(dict(mode=mode, args=list(args), seq=seq))
+        except Exception as e:  # noqa: BLE001 -- record what the reference does, including failures
+            cases.append(dict(mode=mode, args=list(args), error=type(e).__name__))
+    json.dump(dict(modes=sorted(iu.inference_strategies.keys()), cases=cases), open(os.path.join(OUT, "schedulers_more.json"), "w"))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    gen_more_schedulers()
+    if "--schedulers-only" in sys.argv:
+        sys.exit(0)
     gen_eval_paths()
     gen_full_sampler()
     for f in ("eval_paths.json", "full_sampler_tiny.npz"):

@@ -6,8 +6,9 @@ bit-exactly by tests/golden/schedulers.json.  A strategy is an iterator of
 `(obs_frame_indices, latent_frame_indices)` pairs; `scripts/video_sample.py:75-97`
 drives it with `iter()` / `next()`.
 
-The adaptive (LPIPS-driven), goal-directed and visualisation strategies of the
-reference need a perceptual network and are outside the hot path.
+The goal-directed, visualisation and frameskip ("google") strategies (:534-776) are
+pinned by tests/golden/schedulers_more.json; the adaptive (LPIPS-driven) ones need a perceptual
+network and are not provided.
 """
 import numpy as np
 
@@ -199,7 +200,202 @@ def get_hierarchy_n_level(n):
     return type(f"Hierarchy{n}Level", (HierarchyNLevel,), {"N": n})
 
 
-# inference_util.py:779-799 (the strategies that need no perceptual network)
+GOAL_FRAMES = 5      # the goal-directed strategies treat the last five frames of the video as given (:536-539, :566-569)
+
+
+class _GoalFramesMixin:
+    """Marks the last `n` frames as observed / finished at construction (:536-539, :566-569, :616-619)."""
+
+    def _give_goal_frames(self, n):
+        for f in range(self._video_length - n, self._video_length):
+            self._obs_frames.append(f)
+            self._done_frames.add(f)
+
+    def _take_goal_frames(self, n):
+        for f in range(self._video_length - n, self._video_length):
+            self._obs_frames.remove(f)
+            self._done_frames.remove(f)
+
+
+class GoalDirectedHierarchyNLevel(_GoalFramesMixin, HierarchyNLevel):
+    """:534-555 -- the hierarchy schedule of a video that ends five frames early, every window also conditioning on the
+    five goal frames (the window budget shrinks by five for the inner schedule)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._give_goal_frames(GOAL_FRAMES)
+
+    def next_indices(self):
+        self._take_goal_frames(GOAL_FRAMES)
+        self._video_length -= GOAL_FRAMES
+        self._max_frames -= GOAL_FRAMES
+        try:
+            obs, latent = super().next_indices()
+            obs = obs + list(range(self._video_length, self._video_length + GOAL_FRAMES))
+        finally:
+            self._video_length += GOAL_FRAMES
+            self._max_frames += GOAL_FRAMES
+            self._give_goal_frames(GOAL_FRAMES)
+        return obs, latent
+
+
+def get_goal_directed_hierarchy_n_level(n):
+    return type(f"GoalDirectedHierarchy{n}Level", (GoalDirectedHierarchyNLevel,), {"N": n})
+
+
+class GoalDirectedAutoreg(_GoalFramesMixin, InferenceStrategyBase):
+    """:565-582 -- autoregressive from the left with the five goal frames among the newest finished frames; the next
+    latents start at the first unfinished frame and stop short of the last frame."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._give_goal_frames(GOAL_FRAMES)
+
+    def next_indices(self):
+        obs = sorted(self._done_frames)[-(self._max_frames - self._step_size):]
+        first = next(i for i in range(self._video_length + 1) if i not in self._done_frames)
+        return obs, list(range(first, min(first + self._step_size, self._video_length - 1)))
+
+
+class GoalDirectedMixed(_GoalFramesMixin, InferenceStrategyBase):
+    """:615-636 -- one goal frame (the last); half of the conditioning budget on the newest finished frames, the rest
+    filled from the observed frames, latest first."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._give_goal_frames(1)
+
+    def next_indices(self):
+        budget = self._max_frames - self._step_size
+        chosen = set(sorted(self._done_frames)[-(budget // 2):])
+        for f in sorted(self._obs_frames, reverse=True):
+            chosen.add(f)
+            if len(chosen) == budget:
+                break
+        first = sorted(self._done_frames)[-2] + 1                   # just after the newest non-goal frame
+        return sorted(chosen), self._next_chunk(first, self._step_size)
+
+
+class BabyCondHoEtAlForVis(InferenceStrategyBase):
+    """:585-593 -- a fixed 7-window illustration schedule (bypasses the bookkeeping, as the reference does)."""
+
+    _WINDOWS = (([3, 5, 7, 9], [11, 13, 15]), ([9, 11, 13, 15], [17, 19, 21]), ([15, 17, 19, 21], [23, 25, 27]),
+                ([9, 11, 13, 15], [10, 12, 14]), ([15, 17, 19, 21], [16, 18, 20]), ([21, 23, 25, 27], [22, 24, 26]),
+                ([23, 24, 25, 26, 27], [28, 29]))
+
+    def __iter__(self):
+        return iter([(list(o), list(l)) for o, l in self._WINDOWS])
+
+
+class HoEtAlForVis(InferenceStrategyBase):
+    """:596-612 -- 16 frames spread over 0..60 first, then 9-frame windows [start-1, start+8) around the first
+    unfinished frame, conditioning on whatever in them is finished."""
+
+    def next_indices(self):
+        if not self._done_frames:
+            return [], [int(i) for i in np.linspace(0, 60, 16) if i < self._video_length]
+        start = min(i for i in range(64) if i not in self._done_frames)
+        window = range(start - 1, start + 8)
+        obs = [i for i in window if i in self._done_frames]
+        latent = [i for i in window if i not in self._done_frames]
+        if 64 in latent:
+            latent.remove(64)
+            obs.append(55)
+        return obs, latent
+
+
+class GoogleFS4(InferenceStrategyBase):
+    """:639-665 -- the frameskip-4 model of the two-model schedule: 16-frame windows on every 4th frame."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert self._max_frames == 16, f"For GoogleFS4 strategy, max_frames must be 16, but got {self._max_frames}"
+
+    def next_indices(self):
+        newest = max(self._done_frames)
+        obs = sorted(int(newest - 4 * i) for i in range(self._max_frames - self._step_size))
+        first = max(obs) + 4
+        latent = list(range(first, min(first + 4 * self._step_size, self._video_length), 4))
+        while len(obs) + len(latent) < self._max_frames or min(obs) // 4 == 0:
+            obs = [min(obs) - 4] + obs                              # pad to a full window with earlier every-4th frames
+        return obs, latent
+
+    def is_done(self):
+        return self._video_length - max(self._done_frames) <= 4
+
+
+class GoogleFS1(InferenceStrategyBase):
+    """:668-706 -- the frameskip-1 model: fills the gaps the frameskip-4 pass left, 9-frame windows."""
+
+    def __init__(self, done_frames, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert self._max_frames == 9, "For GoogleFS1, max_frames should be 9."
+        assert self._step_size == 6, ("For GoogleFS1, step_size should be 6, meaning that 6 frames will be generated in "
+                                      "each inference step.")
+        done = sorted(done_frames)
+        fs4 = np.array(done[done.index(self._num_obs - 1):])
+        assert np.all(fs4 % 4 == fs4[0] % 4), (
+            "done_frames should come from a GoogleFS4 model and should only include frames that, starting from the last "
+            f"observed frame, are 4 frames apart. Received {done}")
+        assert max(done) + 4 >= self._video_length, (
+            "done_frames should come from a GoogleFS4 model and should cover the entire video. But the last done_frame "
+            f"is {max(done)}")
+        self._done_frames = set(done)
+        self._obs_frames = list(self._done_frames)
+
+    def next_indices(self):
+        first = self._num_obs - 1 + 8 * self._current_step
+        obs = list(range(first, min(first + 9, self._video_length), 4))
+        latent = list(range(obs[0] + 1, min(obs[0] + 8, self._video_length)))
+        if len(obs) >= 2:
+            latent.remove(obs[1])
+        assert not set(obs) & set(latent)
+        while len(obs) + len(latent) < 9:
+            obs += [min(min(latent), min(obs)) - 1]
+        return obs, latent
+
+
+class Google(InferenceStrategyBase):
+    """:709-736 -- frameskip-4 pass over the whole video, then the frameskip-1 pass in between (both forced to the
+    window sizes of the two published models: 16/8 and 9/6)."""
+
+    def __init__(self, video_length, num_obs, **ignored):
+        super().__init__(video_length=video_length, num_obs=num_obs, max_frames=16, step_size=8)
+        self.base_schedule = GoogleFS4(video_length=self._video_length, num_obs=self._num_obs,
+                                       max_frames=self._max_frames, step_size=self._step_size)
+        self._stage = "fs4"
+
+    def next_indices(self):
+        if self._stage == "fs4" and self.base_schedule.is_done():
+            self.base_schedule = GoogleFS1(video_length=self._video_length, num_obs=self._num_obs, max_frames=9,
+                                           step_size=6, done_frames=self.base_schedule._done_frames)
+            self._stage = "fs1"
+        return next(self.base_schedule)
+
+
+class LikeGoogle(InferenceStrategyBase):
+    """:739-776 -- one model playing both roles: first every 4th frame (in phase with the last observed frame),
+    conditioning on the newest such frames; then runs of three latents between consecutive finished frames."""
+
+    def next_indices(self):
+        every4 = list(range((len(self._obs_frames) - 1) % 4, self._video_length, 4))
+        todo = [i for i in every4 if i not in self._done_frames]
+        if todo:
+            latent = sorted(todo)[:self._step_size]
+            n_cond = self._max_frames - len(latent)
+            return sorted(i for i in every4 if i in self._done_frames)[-n_cond:], latent
+        first = next(i for i in range(self._video_length) if i not in self._done_frames)
+        obs, latent = [first - 1], []
+        while len(obs) + len(latent) + 4 < self._max_frames and max(obs + latent) < self._video_length - 1:
+            nxt = max(obs) + 1
+            latent.extend(i for i in range(nxt, nxt + 3) if i < self._video_length)
+            after = max(latent) + 1
+            if after < self._video_length:
+                obs.append(after)
+        return obs, latent
+
+
+# inference_util.py:779-799 (every strategy that needs no perceptual network; the adaptive-* ones need LPIPS)
 inference_strategies = {
     "autoreg": Autoregressive,
     "independent": Independent,
@@ -210,4 +406,11 @@ inference_strategies = {
     "hierarchy-3": get_hierarchy_n_level(3),
     "hierarchy-4": get_hierarchy_n_level(4),
     "hierarchy-5": get_hierarchy_n_level(5),
+    "goal-directed-autoreg": GoalDirectedAutoreg,
+    "goal-directed-mixed": GoalDirectedMixed,
+    "goal-directed-hierarchy-2": get_goal_directed_hierarchy_n_level(2),
+    "ho-et-al-for-vis": HoEtAlForVis,
+    "baby-cond-ho-et-al-for-vis": BabyCondHoEtAlForVis,
+    "google": Google,
+    "like-google": LikeGoogle,
 }

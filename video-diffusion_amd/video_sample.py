@@ -41,12 +41,14 @@ def get_masks(x0, num_obs):
 def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size=1, optimal_schedule_path=None, *,
                 use_gradient_method=False, observed_frames="x_0", sampler="p_sample", eta=0.0):
     """video_sample.py:50-190 (non-adaptive modes).  Returns (samples ndarray (B,T,C,H,W), None)."""
-    if "adaptive" in mode or "goal-directed" in mode:
+    if "adaptive" in mode:
         raise NotImplementedError(f"inference mode {mode!r} needs the LPIPS network (out of scope)")
     B, T, C, H, W = batch.shape
     device = model.device
     samples = torch.zeros_like(batch).cpu()
     samples[:, :obs_length] = batch[:, :obs_length].cpu()
+    if "goal-directed" in mode:
+        samples[:, -5] = batch[:, -5].cpu()              # the reference hands over ONE goal frame (index -5) here
     schedule = iter(inference_util.inference_strategies[mode](
         video_length=T, num_obs=obs_length, max_frames=max_frames, step_size=step_size,
         optimal_schedule_path=optimal_schedule_path))

@@ -46,12 +46,14 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
     """video_sample_full.py:50-323 (non-adaptive modes).  `vertical_steps`, `observed_frames` and
     `save_all_timesteps` are the reference's `args.*` globals.  Returns (samples (B,T,C,H,W) ndarray,
     all_timestep_samples (B,num_timesteps,T,C,H,W) ndarray or a one-element array)."""
-    if "adaptive" in mode or "goal-directed" in mode:
+    if "adaptive" in mode:
         raise NotImplementedError(f"inference mode {mode!r} needs the LPIPS network (out of scope)")
     B, T, C, H, W = batch.shape
     device = model.device
     samples = torch.zeros_like(batch).cpu()
     samples[:, :obs_length] = batch[:, :obs_length].cpu()
+    if "goal-directed" in mode:
+        samples[:, -5] = batch[:, -5].cpu()              # the reference hands over ONE goal frame (index -5) here
     nts = diffusion.num_timesteps
     if save_all_timesteps:
         all_timestep_samples = torch.zeros([B, nts, T, C, H, W])
