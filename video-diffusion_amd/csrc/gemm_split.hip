@@ -22,6 +22,9 @@ namespace vd {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef VD_GS_SKIP
+#define VD_GS_SKIP 0       // kernel-experiment builds: bit 0 no weight loads, 1 no A staging, 2 no split VALU (timing only)
+#endif
 constexpr int SROW = 80;                   // bytes per LDS row of one plane: 32 bf16 + 16 bytes of padding
 
 __device__ __forceinline__ void split3(f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     auto kstep = [&](int chunk, int ks, int gslot, int aslot) {          // gslot = (2*chunk + ks) % 3, compile time
         const int g = 2 * chunk + ks;
         const char* Acur = smem_c + (chunk & 1) * ABUF;
-        b_load((gslot + 2) % 3, min(g + 2, nks - 1));
+        if (!(VD_GS_SKIP & 1)) b_load((gslot + 2) % 3, min(g + 2, nks - 1));
         if (ks == 0) a_frags(aslot ^ 1, Acur, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -171,10 +174,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
             const int chunk = chunk0 + cc;
             if (chunk < nchunk) {
                 const int nxt = min(chunk + 1, nchunk - 1);
-                a_prefetch(nxt);
+                if (!(VD_GS_SKIP & 2)) a_prefetch(nxt);
                 kstep(chunk, 0, (2 * cc) % 3, 0);
                 kstep(chunk, 1, (2 * cc + 1) % 3, 1);
-                a_store(smem_c + ((chunk + 1) & 1) * ABUF);
+                if (!(VD_GS_SKIP & 6)) a_store(smem_c + ((chunk + 1) & 1) * ABUF);
                 __syncthreads();
                 a_frags(0, smem_c + ((chunk + 1) & 1) * ABUF, 0);
             }
