@@ -173,6 +173,12 @@ int vd_pack_conv3_wino_split(const float* host_oihw, unsigned short* host_out, i
 int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
                           const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
                           void* stream);
+/* 3x3 convolutions that Winograd does not cover (the stride-2 Downsample convs, unet.py:98) on the same six-product
+ * arithmetic: the split GEMM kernel walks an implicit im2col operand (k = tap*I + c; taps outside the image read 0).
+ * Weights: OIHW -> split fragment image of the [O][9*I] matrix = 27*O*I uint16.  stride 1 or 2, padding 1. */
+int vd_pack_conv3_split(const float* host_oihw, unsigned short* host_out, int O, int I);
+int vd_op_conv_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int stride, const void* w_split, const float* bias,
+                     const float* res, float* out, int Cout, void* stream);
 int vd_op_linear_split(const float* a, int M, int K, const void* w_split, const float* bias, const float* res, int act,
                        float* out, int N, void* stream);
 /* GroupNorm32 statistics folded to y = x*A + B per (frame, channel); film ([nfr][2C] scale|shift) optional. */

@@ -525,3 +525,39 @@ def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups):
     tot = part.sum(1).cpu()
     close(tot[..., 0], o64.sum((1, 2)).cpu(), atol=1e-3, rtol=1e-5)
     close(tot[..., 1], (o64 * o64).sum((1, 2)).cpu(), atol=1e-3, rtol=1e-5)
+
+
+def pack_conv_split(w):
+    O, I = w.shape[:2]
+    out = torch.empty(27 * O * I, dtype=torch.int16)
+    _lib.check(_lib.lib().vd_pack_conv3_split(_lib.ptr(w.contiguous().float()), _lib.ptr(out), O, I))
+    return out
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,stride,res", [(3, 64, 64, 16, 2, 0), (2, 128, 128, 64, 2, 0), (5, 32, 96, 8, 2, 1),
+                                                     (7, 96, 32, 4, 1, 1), (7, 96, 32, 4, 1, 0), (1, 64, 160, 32, 2, 0),
+                                                     (3, 32, 32, 2, 2, 0)])
+def test_conv3x3_split_gemm_bf16x6_is_fp32_accurate(N, Cin, Cout, H, stride, res):
+    """csrc/gemm_split.hip, CONV mode: the stride-2 Downsample conv (unet.py:98) as the split GEMM over an implicit
+    im2col operand.  Held to the op tolerance against torch fp32 and, against an fp64 conv, required to be no further
+    away than the generic fp32-MFMA kernel on the same inputs."""
+    L = _lib.lib()
+    x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, scale=(3.0 / (9 * Cin)) ** 0.5), rnd(Cout, scale=0.1)
+    Ho = (H - 1) // stride + 1
+    r = rnd(N, Cout, Ho, Ho, seed=4) if res else None
+    xd, bd, rd = dev(nhwc(x)), dev(b), (dev(nhwc(r)) if res else None)
+    out_s = torch.empty(N, Ho, Ho, Cout, device="cuda")
+    ws = dev(pack_conv_split(w))
+    _lib.check(L.vd_op_conv_split(_lib.ptr(xd), Cin, N, H, H, stride, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(out_s),
+                                  Cout, _lib.current_stream()))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, w, b, stride=stride, padding=1) + (r if res else 0)
+    got = out_s.permute(0, 3, 1, 2).cpu()
+    close(got, ref, **TOL)
+    if res:          # the split kernel starts its accumulator at bias + residual, the generic one adds them last: the
+        return       # rounding of the two differs by the residual's magnitude, so the fp64 comparison is made without
+    ref64 = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1)
+    out_f = run_conv(x, None, w, b, stride=stride, generic=True)
+    e_split, e_fp32 = (got.double() - ref64).abs(), (out_f.double() - ref64).abs()
+    assert e_split.max() <= 1.5 * e_fp32.max() + 1e-7, (e_split.max(), e_fp32.max())
+    assert e_split.mean() <= 1.5 * e_fp32.mean() + 1e-8, (e_split.mean(), e_fp32.mean())

@@ -25,7 +25,7 @@ int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hip
 
 // CONV3F / LINF: MFMA-fragment-major images (conv_halo.hip / gemm_frag.hip)
 // CONV3W: Winograd F(2x2,3x3)-transformed weights, 16/9 of the checkpoint size (conv_wino.hip)
-enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_CONV3F, PK_LINF, PK_CONV3W };
+enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_CONV3F, PK_LINF, PK_CONV3W, PK_CONV3S };
 
 struct Param {
     std::string name;
@@ -192,6 +192,7 @@ struct vd_engine {
         const int k = params[p].kind;
         g.w = g.wfrag = g.wwino = nullptr;
         if (k == PK_CONV3W) { g.wwino = W(p); g.wsplit = split_conv(); }
+        else if (k == PK_CONV3S) { g.wfrag = W(p); g.wsplit = 1; }
         else if (k == PK_CONV3F || k == PK_LINF) { g.wfrag = W(p); g.wsplit = k == PK_LINF && split_math(); }
         else g.w = W(p);
     }
@@ -207,6 +208,7 @@ struct vd_engine {
         p.packed = p.numel;
         if (kind == PK_STEM) p.packed = (size_t)p.shape[0] * STEM_KPAD;
         if ((kind == PK_STEM || kind == PK_LINF) && split_math()) p.packed = p.packed * 3 / 2;       // three bf16 planes
+        if (kind == PK_CONV3S) p.packed = p.numel * 3 / 2;
         if (kind == PK_CONV3W) p.packed = (size_t)16 * p.shape[0] * p.shape[1] * (split_conv() ? 3 : 2) / 2;
         params.push_back(p);
         pidx[name] = (int)params.size() - 1;
@@ -324,7 +326,8 @@ int vd_engine::build() {
         }
         if (lvl != nlev - 1) {
             const std::string pre = "input_blocks." + std::to_string(input_blocks.size());
-            input_blocks.push_back({Layer{3, add_conv(pre + ".0.op", ch, ch, PK_CONV3)}});
+            // Downsample (unet.py:98): stride-2 3x3 -> the split GEMM over an implicit im2col operand
+            input_blocks.push_back({Layer{3, add_conv(pre + ".0.op", ch, ch, split_math() ? PK_CONV3S : PK_CONV3)}});
             chans.push_back(ch);
             ds *= 2;
         }
@@ -781,6 +784,10 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
         tmp.resize(p.packed);
         pack_conv3_wino(host, tmp.data(), (int)p.shape[0], (int)p.shape[1]);
         src = tmp.data();
+    } else if (p.kind == PK_CONV3S) {
+        tmp.resize(p.packed);
+        pack_conv3_split(host, reinterpret_cast<unsigned short*>(tmp.data()), (int)p.shape[0], (int)p.shape[1]);
+        src = tmp.data();
     } else if (p.kind == PK_CONV3F) {
         tmp.resize(p.numel);
         pack_conv3_frag(host, tmp.data(), (int)p.shape[0], (int)p.shape[1]);
@@ -994,6 +1001,24 @@ int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, i
     g.fbias = fbias; g.fbias_ld = fbias_ld; g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
     g.stats = gn_part; g.stats_split = conv_wino_stats_split(g.Ho);
     VD_REQUIRE(conv_wino_split_supported(g), "vd_op_conv_wino_split: shape not covered by the kernel");
+    return launch_igemm(g, static_cast<hipStream_t>(stream));
+}
+
+int vd_pack_conv3_split(const float* host_oihw, unsigned short* host_out, int O, int I) {
+    VD_REQUIRE(host_oihw && host_out && O % 32 == 0 && I % 32 == 0, "vd_pack_conv3_split: O, I multiples of 32");
+    pack_conv3_split(host_oihw, host_out, O, I);
+    return 0;
+}
+
+int vd_op_conv_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int stride, const void* w_split, const float* bias,
+                     const float* res, float* out, int Cout, void* stream) {
+    IgemmArgs g{};
+    g.src0 = src0; g.C0 = Cin; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws;
+    g.stride = stride; g.pad = 1; g.ksz = 3;
+    g.Ho = (Hs + 2 - 3) / stride + 1; g.Wo = (Ws + 2 - 3) / stride + 1;
+    g.wfrag = static_cast<const float*>(w_split); g.wsplit = 1; g.bias = bias; g.res = res; g.res_ld = Cout;
+    g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
+    VD_REQUIRE(conv_split_supported(g), "vd_op_conv_split: shape not covered by the kernel");
     return launch_igemm(g, static_cast<hipStream_t>(stream));
 }
 

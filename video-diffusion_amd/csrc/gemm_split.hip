@@ -14,6 +14,7 @@
 // bf16 planes in LDS (rows padded to 80 bytes: conflict-free ds_read_b128 fragments), the weights are split on the
 // host at load time and stream from L2 in fragment order [K/16][N/32][piece 3][lane 64][8 bf16], three k-steps ahead.
 #include <cstring>
+#include <vector>
 
 #include "vd_common.h"
 
@@ -35,7 +36,10 @@ __device__ __forceinline__ void split3(f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& 
     p3 = __builtin_convertvector(r, bf16x4);
 }
 
-template <int BM, int BN, bool ACT>
+// CONV: the A operand is the implicit im2col matrix of a 3x3 convolution (any stride, zero padding 1) over one NHWC
+// source: K runs tap-major (k = tap*Cin + c, the order pack_conv3_split stores), the row of an output pixel moves with
+// the tap, and a tap that falls outside the image reads zeros through the descriptor's range check.
+template <int BM, int BN, bool ACT, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
     constexpr int PLANE = BM * SROW, ABUF = 3 * PLANE;                    // bytes
@@ -45,7 +49,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     const int lr = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int lrow = tid >> 3, lq = tid & 7;
-    const int nchunk = a.Cin >> 5, ncoblk = a.Cout >> 5;
+    const int cpt = a.Cin >> 5;                                            // chunks per tap
+    const int nchunk = CONV ? 9 * cpt : cpt, ncoblk = a.Cout >> 5;
     const int C1 = a.Cin - a.C0;
     if (a.zcount > 1) {                          // batched problems of one shape
         const int z = blockIdx.z;
@@ -53,18 +58,29 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         if (a.bias) a.bias += (size_t)z * a.zs_bias;
     }
 
-    const auto asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.M * a.C0 * 4, 0x00020000);
+    const auto asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0,
+                                                         (CONV ? a.nfr * a.Hs * a.Ws : a.M) * a.C0 * 4, 0x00020000);
     const auto asrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1 ? a.src1 : a.src0), 0,
                                                          a.src1 ? a.M * C1 * 4 : 0, 0x00020000);
     unsigned ao0[AR], ao1[AR];
+    int iy0[AR], ix0[AR];                        // CONV: top-left tap of the row's output pixel; ao0 = its byte offset
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
         const unsigned row = (unsigned)min(m0 + lrow + 32 * j, a.M - 1);
-        ao0[j] = row * (unsigned)(a.C0 * 4) + lq * 16u;
-        ao1[j] = row * (unsigned)(C1 * 4) + lq * 16u;
+        if constexpr (CONV) {
+            const unsigned ox = row % (unsigned)a.Wo, t = row / (unsigned)a.Wo;
+            const unsigned oy = t % (unsigned)a.Ho, n = t / (unsigned)a.Ho;
+            iy0[j] = (int)oy * a.stride - 1;
+            ix0[j] = (int)ox * a.stride - 1;
+            ao0[j] = (unsigned)(((int)n * a.Hs + iy0[j]) * a.Ws + ix0[j]) * (unsigned)(a.Cin * 4) + lq * 16u;   // may wrap: only used when valid
+            ao1[j] = 0;
+        } else {
+            ao0[j] = row * (unsigned)(a.C0 * 4) + lq * 16u;
+            ao1[j] = row * (unsigned)(C1 * 4) + lq * 16u;
+        }
     }
     // weights: [K/16][N/32][piece][lane][8 bf16] = 3072 bytes per (k-step, column block)
-    const auto bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, a.Cin * a.Cout * 6, 0x00020000);
+    const auto bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, (CONV ? 9 : 1) * a.Cin * a.Cout * 6, 0x00020000);
     unsigned bo[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) bo[j] = (unsigned)min((int)blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1) * 3072u + lane * 16u;
@@ -72,6 +88,17 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     f32x4 ra[AR];
     bf16x8 bfr[3][NI][3], afr[2][MI][3];         // [ring slot][tile][piece]
     auto a_prefetch = [&](int chunk) {
+        if constexpr (CONV) {
+            const int tap = chunk / cpt, c = (chunk - tap * cpt) * 32;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const unsigned shift = (unsigned)((kh * a.Ws + kw) * a.Cin * 4);
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                const bool ok = (unsigned)(iy0[j] + kh) < (unsigned)a.Hs && (unsigned)(ix0[j] + kw) < (unsigned)a.Ws;
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc0, ok ? ao0[j] + shift : 0x80000000u, c * 4, 0));
+            }
+            return;
+        }
         const int c = chunk * 32;
         if (c < a.C0) {
 #pragma unroll
@@ -199,6 +226,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         }
 }
 
+// 3x3 convolutions whose weights came from pack_conv3_split (the stride-2 Downsample convs, unet.py:98)
+bool conv_split_supported(const IgemmArgs& a) {
+    return a.wsplit && a.wfrag != nullptr && a.ksz == 3 && a.pad == 1 && (a.stride == 1 || a.stride == 2) && a.ups == 0 &&
+           a.Cout % 32 == 0 && a.Cin % 32 == 0 && a.C0 == a.Cin && a.affA == nullptr && a.fbias == nullptr && a.zcount <= 1 &&
+           (a.res == nullptr || a.res_ld == a.ldo) && (size_t)a.nfr * a.Hs * a.Ws * a.Cin < (1u << 28) &&
+           (size_t)a.M * a.ldo < (1u << 28) && (size_t)9 * a.Cin * a.Cout * 6 < (1u << 31);
+}
+
 bool gemm_split_supported(const IgemmArgs& a) {
     return a.wsplit && a.wfrag != nullptr && a.ksz == 1 && a.stride == 1 && a.pad == 0 && a.ups == 0 && a.Cout % 32 == 0 &&
            a.Cin % 32 == 0 && a.C0 % 32 == 0 && a.affA == nullptr && a.fbias == nullptr && (a.res == nullptr || a.res_ld == a.ldo) &&
@@ -209,8 +244,11 @@ template <int BM, int BN>
 static int launch_gs(const IgemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * 3 * BM * SROW;
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.zcount > 1 ? a.zcount : 1);
-    if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false>), grid, dim3(256), lds, s, a);
+    if (a.ksz == 3) {
+        if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, true>), grid, dim3(256), lds, s, a);
+    } else if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, false>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, false>), grid, dim3(256), lds, s, a);
     VD_HIP(hipGetLastError());
     return 0;
 }
@@ -255,6 +293,16 @@ void pack_linear_split(const float* w, unsigned short* out_base, int rows, int K
                         for (int q = 0; q < 3; ++q)
                             out_base[((((size_t)ks * ncoblk + row0 / 32 + cb) * 3 + q) * 64 + h * 32 + r) * 8 + j] = p[q];
                     }
+}
+
+// OIHW 3x3 weights -> the split fragment image of the [Cout][9*Cin] matrix with k = tap*Cin + c (the order the CONV
+// mode of the kernel walks K)
+void pack_conv3_split(const float* w, unsigned short* out, int Cout, int Cin) {
+    std::vector<float> lin((size_t)Cout * 9 * Cin);
+    for (int o = 0; o < Cout; ++o)
+        for (int i = 0; i < Cin; ++i)
+            for (int t = 0; t < 9; ++t) lin[(size_t)o * 9 * Cin + (size_t)t * Cin + i] = w[((size_t)o * Cin + i) * 9 + t];
+    pack_linear_split(lin.data(), out, Cout, 9 * Cin, Cout, 0);
 }
 
 }  // namespace vd

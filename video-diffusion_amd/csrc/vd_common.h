@@ -107,6 +107,8 @@ int launch_conv_wino_split(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino_split(const float* oihw, unsigned short* out, int O, int I);
 // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
 bool gemm_split_supported(const IgemmArgs& a);
+bool conv_split_supported(const IgemmArgs& a);          // 3x3, stride 1|2: the same kernel over an implicit im2col A
+void pack_conv3_split(const float* w_oihw, unsigned short* out, int Cout, int Cin);
 int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s);
 void pack_linear_split(const float* w, unsigned short* out_base, int rows, int K, int n_total, int row0);          // blocks per frame = partial sums per (frame, channel)
 int launch_conv_wino(const IgemmArgs& a, hipStream_t s);
