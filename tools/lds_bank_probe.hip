@@ -58,5 +58,17 @@ int main() {
     run("32 consecutive pixels of 80 B, halves +32", a);
     for (int l = 0; l < 64; ++l) { int r = l & 31, h = l >> 5; a[l] = r * 80 + h * 2560; }
     run("32 consecutive pixels of 80 B, halves +2560", a);
+    // which 16 lanes share a pass?  slot = 16-byte slot within the 256 B of the 64 banks
+    for (int l = 0; l < 64; ++l) a[l] = ((l & 7) + 8 * ((l >> 5) & 1)) * 16 + (l >> 3 & 3) * 4096; run("slots (l&7)+8*(l>>5): free iff pass = {8 lanes, +32}", a);
+    for (int l = 0; l < 64; ++l) a[l] = ((l & 7) + 8 * ((l >> 4) & 1)) * 16 + (l >> 3 & 1) * 4096 + (l >> 5) * 8192; run("slots (l&7)+8*(l>>4&1): free iff pass = {8 lanes, +16}", a);
+    for (int l = 0; l < 64; ++l) a[l] = (l & 15) * 16 + (l >> 4) * 4096; run("slots l&15: free iff pass = 16 contiguous lanes", a);
+    for (int l = 0; l < 64; ++l) a[l] = ((l & 3) + 4 * (l >> 4)) * 16 + (l >> 2 & 3) * 4096; run("slots (l&3)+4*(l>>4): free iff pass = {4 lanes of each 16}", a);
+    // V fragment image of conv_wino_split64: lane (tile lr, k-half lh) reads slot lr*4 + ((2*lh+e) ^ ((lr>>2)&3))
+    for (int l = 0; l < 64; ++l) { int lr = l & 31, lh = l >> 5; a[l] = lr * 64 + (((2 * lh) ^ ((lr >> 2) & 3)) * 16); }
+    run("V fragment read, swizzle (lr>>2)&3", a);
+    for (int l = 0; l < 64; ++l) { int lr = l & 31, lh = l >> 5; a[l] = lr * 64 + (((2 * lh) ^ ((lr >> 2) & 3) ^ ((lr >> 4) & 1)) * 16); }
+    run("V fragment read, swizzle (lr>>2)&3 ^ lr>>4", a);
+    for (int l = 0; l < 64; ++l) { int lr = l & 31, lh = l >> 5; a[l] = lr * 80 + lh * 32; }
+    run("V fragment read, 80 B rows", a);
     return 0;
 }

@@ -57,9 +57,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // x = p1 + p2 + p3 exactly, per pair of fp32 values, by truncation: p1 = top 16 bits of x (a bf16 value), r = x - p1
 // (exact: the low 16 significand bits), p2 = top 16 bits of r, p3 = r - p2 (at most 8 significant bits: a bf16 value).
-// The bf16 pieces of a pair are the high halves of two registers, packed by one v_perm_b32: 11 VALU per pair, no
-// conversions and no dependent-convert latencies; asm so that it stays exactly this sequence.
-__device__ __forceinline__ void split_pair(f32x2 v, unsigned& p1, unsigned& p2, unsigned& p3, unsigned sel) {
+// The bf16 pieces of a pair are the high halves of two registers, packed by one v_perm_b32: 11 VALU per pair.
+// Only PLAIN vector instructions may appear in this loop: v_pk_*_f32 and v_dot2c_f32_bf16 do not overlap the bf16 MFMA
+// (each costs its 4 cycles plus a ~20-cycle bubble once per slot), plain fp32 / integer / v_cvt_pk_bf16_f32 ones do, up
+// to 6 per MFMA for free and 4 cycles each beyond (tools/mfma_bf16_coissue.hip).  v_cvt_pk_bf16_f32 + v_dot2c would
+// split a pair in 7 instructions (tools/dot2_probe.hip) but is slower here for that reason.
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3, unsigned sel) {
     float h0, h1, r0, r1;
     asm("v_and_b32 %3, 0xffff0000, %7\n\t"
         "v_and_b32 %4, 0xffff0000, %8\n\t"
@@ -73,7 +76,7 @@ __device__ __forceinline__ void split_pair(f32x2 v, unsigned& p1, unsigned& p2, 
         "v_sub_f32 %6, %6, %4\n\t"
         "v_perm_b32 %2, %6, %5, %9"
         : "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(h0), "=&v"(h1), "=&v"(r0), "=&v"(r1)
-        : "v"(v.x), "v"(v.y), "s"(sel));
+        : "v"(x0), "v"(x1), "s"(sel));
 }
 template <bool TF4>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_split_kernel(IgemmArgs a, WinoSGeom g) {
@@ -158,22 +161,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_split_kernel(IgemmArgs a,
     };
     // raw -> three bf16 pieces of the four fragments, in 24 pieces of work, one per MFMA slot of the running group:
     //   pieces 0..3    row combination of patch column c:  t[c] = d[r1][c]*sg + d[r0][c]             (4 packed fma)
-    //   then per position j: the column combination (4 packed add) and the split of its four value pairs (9 VALU each)
+    //   then per position j: the column combination (4 packed add) and the split of its four value pairs (11 VALU each)
     u32x4 apc[2][4][3];                                              // [slot][position j][piece] = 8 bf16
-    f32x8 tc[4], fcur;
+    float tc[4][8], fcur[8];                                         // [column][channel]
     auto a_piece = [&](int slot, int k) {
-        if (k < 4) {
+        if (k < 4) {                                                 // asm: hipcc would pair these into v_pk_fma_f32
             const f32x4 lo0 = raw[k * 2], hi0 = raw[k * 2 + 1], lo1 = raw[8 + k * 2], hi1 = raw[8 + k * 2 + 1];
-            const f32x8 d0 = {lo0.x, lo0.y, lo0.z, lo0.w, hi0.x, hi0.y, hi0.z, hi0.w};
-            const f32x8 d1 = {lo1.x, lo1.y, lo1.z, lo1.w, hi1.x, hi1.y, hi1.z, hi1.w};
-            tc[k] = d1 * sg + d0;
+            const float d0[8] = {lo0.x, lo0.y, lo0.z, lo0.w, hi0.x, hi0.y, hi0.z, hi0.w};
+            const float d1[8] = {lo1.x, lo1.y, lo1.z, lo1.w, hi1.x, hi1.y, hi1.z, hi1.w};
+#pragma unroll
+            for (int h = 0; h < 8; ++h) asm("v_fma_f32 %0, %1, %2, %3" : "=v"(tc[k][h]) : "v"(d1[h]), "v"(sg), "v"(d0[h]));
         } else {
             const int j = (k - 4) / 5, s_ = (k - 4) % 5;
             if (s_ == 0) {
-                fcur = j == 0 ? tc[0] - tc[2] : j == 1 ? tc[1] + tc[2] : j == 2 ? tc[2] - tc[1] : tc[1] - tc[3];
+                // j0: t0 - t2   j1: t1 + t2   j2: t2 - t1   j3: t1 - t3
+                const int ca = j == 0 ? 0 : j == 2 ? 2 : 1, cb = j == 3 ? 3 : j == 2 ? 1 : 2;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    if (j == 1) asm("v_add_f32 %0, %1, %2" : "=v"(fcur[h]) : "v"(tc[ca][h]), "v"(tc[cb][h]));
+                    else asm("v_sub_f32 %0, %1, %2" : "=v"(fcur[h]) : "v"(tc[ca][h]), "v"(tc[cb][h]));
+                }
             } else {
                 unsigned p1, p2, p3;
-                split_pair(f32x2{fcur[2 * (s_ - 1)], fcur[2 * (s_ - 1) + 1]}, p1, p2, p3, 0x07060302u);
+                split_pair(fcur[2 * (s_ - 1)], fcur[2 * (s_ - 1) + 1], p1, p2, p3, 0x07060302u);
                 apc[slot][j][0][s_ - 1] = p1; apc[slot][j][1][s_ - 1] = p2; apc[slot][j][2][s_ - 1] = p3;
             }
         }
