@@ -179,6 +179,12 @@ int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, i
 int vd_pack_conv3_split(const float* host_oihw, unsigned short* host_out, int O, int I);
 int vd_op_conv_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int stride, const void* w_split, const float* bias,
                      const float* res, float* out, int Cout, void* stream);
+/* The same arithmetic with 64 couts per block and the input transform done once per block (csrc/conv_wino_s64.hip): its
+ * own weight image (row 3 of U negated), same size and argument meaning as the two functions above; O % 64 == 0. */
+int vd_pack_conv3_wino_s64(const float* host_oihw, unsigned short* host_out, int O, int I);
+int vd_op_conv_wino_s64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
+                        const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
+                        void* stream);
 int vd_op_linear_split(const float* a, int M, int K, const void* w_split, const float* bias, const float* res, int act,
                        float* out, int N, void* stream);
 /* GroupNorm32 statistics folded to y = x*A + B per (frame, channel); film ([nfr][2C] scale|shift) optional. */

@@ -12,8 +12,11 @@ from video_diffusion_amd import _lib  # noqa: E402
 
 SHAPES = [(128, 128, 128, 64), (128, 256, 256, 32), (128, 640, 256, 32), (128, 384, 384, 16), (128, 512, 512, 8), (128, 1024, 512, 8)]
 L = _lib.lib()
-L.vd_debug_winos_stamps.restype = ctypes.c_int
-L.vd_debug_winos_stamps.argtypes = [ctypes.c_void_p]
+S64 = "--s64" in sys.argv                      # conv_wino_s64.hip (64 couts per block) instead of conv_wino_split.hip
+stamps = L.vd_debug_s64_stamps if S64 else L.vd_debug_winos_stamps
+op = L.vd_op_conv_wino_s64 if S64 else L.vd_op_conv_wino_split
+stamps.restype = ctypes.c_int
+stamps.argtypes = [ctypes.c_void_p]
 for nfr, Cin, Cout, H in SHAPES:
     x0 = torch.rand(nfr, H, H, Cin, device="cuda") - 0.5
     ws = torch.randint(-2000, 2000, (48 * Cout * Cin,), device="cuda", dtype=torch.int16)
@@ -22,11 +25,11 @@ for nfr, Cin, Cout, H in SHAPES:
     out = torch.empty(nfr, H, H, Cout, device="cuda")
     st = (ctypes.c_ulonglong * 10)()
     for _ in range(3):
-        _lib.check(L.vd_op_conv_wino_split(_lib.ptr(x0), Cin, nfr, H, H, 0, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(res), None, 0,
+        _lib.check(op(_lib.ptr(x0), Cin, nfr, H, H, 0, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(res), None, 0,
                                            _lib.ptr(out), Cout, None, _lib.current_stream()))
         torch.cuda.synchronize()
-    assert L.vd_debug_winos_stamps(st) == 0
+    assert stamps(st) == 0
     t = list(st)
     nch = Cin // 16
-    print(f"Cin {Cin:4d} Cout {Cout:4d} H {H:2d}: prologue {t[1]-t[0]:6d}  loop {t[2]-t[1]:8d} ({(t[2]-t[1])/nch:6.0f}/chunk, 48 MFMA = 1536)"
+    print(f"Cin {Cin:4d} Cout {Cout:4d} H {H:2d}: prologue {t[1]-t[0]:6d}  loop {t[2]-t[1]:8d} ({(t[2]-t[1])/nch:6.0f}/chunk, {96 if S64 else 48} MFMA = {3072 if S64 else 1536})"
           f"  epilogue {t[3]-t[2]:6d}  total {t[3]-t[0]:8d} = {(t[9]-t[8])/100:.1f} us -> {(t[3]-t[0])/max(t[9]-t[8],1)*0.1:.2f} GHz", flush=True)

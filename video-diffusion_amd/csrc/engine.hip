@@ -191,7 +191,7 @@ struct vd_engine {
     void set_w(vd::IgemmArgs& g, int p) const {
         const int k = params[p].kind;
         g.w = g.wfrag = g.wwino = nullptr;
-        if (k == PK_CONV3W) { g.wwino = W(p); g.wsplit = split_conv(); }
+        if (k == PK_CONV3W) { g.wwino = W(p); g.wsplit = split_conv() ? 2 : 0; }
         else if (k == PK_CONV3S) { g.wfrag = W(p); g.wsplit = 1; }
         else if (k == PK_CONV3F || k == PK_LINF) { g.wfrag = W(p); g.wsplit = k == PK_LINF && split_math(); }
         else g.w = W(p);
@@ -778,7 +778,7 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
     }
     if (p.kind == PK_CONV3W && split_conv()) {
         tmp.resize(p.packed);
-        pack_conv3_wino_split(host, reinterpret_cast<unsigned short*>(tmp.data()), (int)p.shape[0], (int)p.shape[1]);
+        pack_conv3_wino_s64(host, reinterpret_cast<unsigned short*>(tmp.data()), (int)p.shape[0], (int)p.shape[1]);
         src = tmp.data();
     } else if (p.kind == PK_CONV3W) {
         tmp.resize(p.packed);
@@ -982,6 +982,26 @@ int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I) {
     VD_REQUIRE(host_oihw && host_out && O % 32 == 0 && I % 32 == 0, "O and I multiples of 32");
     pack_conv3_frag(host_oihw, host_out, O, I);
     return 0;
+}
+
+int vd_pack_conv3_wino_s64(const float* host_oihw, unsigned short* host_out, int O, int I) {
+    VD_REQUIRE(host_oihw && host_out && O % 64 == 0 && I % 32 == 0, "vd_pack_conv3_wino_s64: O multiple of 64, I of 32");
+    pack_conv3_wino_s64(host_oihw, host_out, O, I);
+    return 0;
+}
+
+int vd_op_conv_wino_s64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
+                        const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
+                        void* stream) {
+    IgemmArgs g{};
+    g.src0 = src0; g.C0 = Cin; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws; g.ups = ups;
+    g.stride = 1; g.pad = 1; g.ksz = 3;
+    g.Ho = Hs << ups; g.Wo = Ws << ups;
+    g.wwino = static_cast<const float*>(w_split); g.wsplit = 2; g.bias = bias; g.res = res; g.res_ld = Cout;
+    g.fbias = fbias; g.fbias_ld = fbias_ld; g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
+    g.stats = gn_part; g.stats_split = conv_wino_stats_split(g.Ho);
+    VD_REQUIRE(conv_wino_s64_supported(g), "vd_op_conv_wino_s64: shape not covered by the kernel");
+    return launch_igemm(g, static_cast<hipStream_t>(stream));
 }
 
 int vd_pack_conv3_wino_split(const float* host_oihw, unsigned short* host_out, int O, int I) {

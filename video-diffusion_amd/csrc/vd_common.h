@@ -64,6 +64,7 @@ struct IgemmArgs {
     // problem z reads src0 + z*zs_a, wfrag + z*zs_w, bias + z*zs_bias and writes out + z*zs_out (element strides).
     // The three RPE-net output layers of an attention block (unet.py:283-298) go out this way.
     int zcount, zs_a, zs_w, zs_bias, zs_out;
+    // wsplit == 2: wwino is the image of pack_conv3_wino_s64 (conv_wino_s64.hip).  Otherwise:
     // wfrag is the bf16-split image of the weights (gemm_split.hip: fp32 accuracy from six bf16 piece products);
     // zs_w then counts floats of that image as well
     int wsplit;
@@ -106,6 +107,9 @@ bool conv_wino_split_supported(const IgemmArgs& a);
 int launch_conv_wino_split(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino_split(const float* oihw, unsigned short* out, int O, int I);
 // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
+bool conv_wino_s64_supported(const IgemmArgs& a);        // conv_wino_s64.hip: wsplit == 2 (its own weight image)
+int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s);
+void pack_conv3_wino_s64(const float* oihw, unsigned short* out, int O, int I);
 bool gemm_split_supported(const IgemmArgs& a);
 bool conv_split_supported(const IgemmArgs& a);          // 3x3, stride 1|2: the same kernel over an implicit im2col A
 void pack_conv3_split(const float* w_oihw, unsigned short* out, int Cout, int Cin);
