@@ -34,6 +34,7 @@ import video_diffusion_amd as vda  # noqa: E402
 from video_diffusion_amd import _lib, dist as vdist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6    # v_mfma_f32_32x32x16_bf16: 32 cycles per 32x32x16, 1024 SIMDs, 2.4 GHz (dense, no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -221,17 +222,24 @@ def main():
                 rec = json.load(open(pmc))
                 if rec.get("kernel") == name:
                     traffic = round(rec["hbm_bytes_per_launch"])
-            roofline = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                            unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+            split_conv = name == "conv3x3_wino_s64_kernel"
+            # the dominant kernel runs on the bf16 matrix pipe (fp32 operands split exactly into three bf16 pieces) unless
+            # VD_CONV_SPLIT=0 / VD_MATH=fp32 keep it on the fp32 MFMA: `peak` is the dense peak of the pipe it uses
+            peak = PEAK_BF16_MFMA_TFLOPS if split_conv else PEAK_FP32_MFMA_TFLOPS
+            roofline = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=peak,
+                            unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
                             launches_per_step=c["launches"], avg_launch_us=round(1e3 * c["ms"] / c["launches"], 1),
                             alg_gflop_per_launch=round(c["gflop"] / c["launches"], 3),
                             alg_mb_per_launch=round(c["mb"] / c["launches"], 2))
-            if name == "conv3x3_wino_kernel":
-                # `achieved` counts the ALGORITHMIC flops of a direct 3x3 convolution (2*M*Cout*Cin*9); Winograd
-                # F(2x2,3x3) executes 16/36 of them on the matrix pipe, so frac can exceed 1: the share of the MFMA
-                # peak the kernel actually keeps busy is achieved / 2.25
-                roofline["mfma_executed_tflops"] = round(achieved / 2.25, 2)
-                roofline["mfma_executed_frac"] = round(achieved / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4)
+            if name.startswith("conv3x3_wino"):
+                # `achieved` counts the ALGORITHMIC flops of a direct fp32 3x3 convolution (2*M*Cout*Cin*9).  Winograd
+                # F(2x2,3x3) executes 16/36 of the multiplications; the split kernel spends six bf16 piece products
+                # on each, so the matrix pipe executes achieved * 6 / 2.25 bf16 flops (fp32 kernel: achieved / 2.25)
+                ex = achieved * (6 / 2.25 if split_conv else 1 / 2.25)
+                roofline["mfma_executed_tflops"] = round(ex, 2)
+                roofline["mfma_executed_frac"] = round(ex / peak, 4)
+                roofline["fp32_mfma_peak"] = PEAK_FP32_MFMA_TFLOPS          # what a plain fp32 kernel is bounded by
+                roofline["achieved_over_fp32_mfma_peak"] = round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)
     vdist.barrier()
 
     if rank != 0:
@@ -241,10 +249,12 @@ def main():
         "metric": "denoise-steps/sec", "value": round(value, 4), "unit": "denoise-steps/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": "fp32 operands and fp32 accumulation throughout; 3x3 convs: Winograd F(2x2,3x3) on the fp32 MFMA; "
-                      "linear layers / 1x1 convs: fp32 operands split EXACTLY into three bf16 pieces, six piece products on "
-                      "the bf16 MFMA with fp32 accumulation (error vs fp64 <= that of the fp32 MFMA; tests/test_gpu_ops.py)"
-                      if os.environ.get("VD_MATH") != "fp32" else "every matrix product on the fp32 MFMA",
+        "arithmetic": "every matrix product on the fp32 MFMA" if os.environ.get("VD_MATH") == "fp32" else
+                      "fp32 operands and fp32 accumulation throughout; matrix products (3x3 convs as Winograd F(2x2,3x3), "
+                      "linear layers, 1x1 and stride-2 convs): fp32 operands split EXACTLY into three bf16 pieces, six piece "
+                      "products on the bf16 MFMA with fp32 accumulation (error vs fp64 <= that of the fp32 MFMA; "
+                      "tests/test_gpu_ops.py)" + ("; VD_CONV_SPLIT=0: 3x3 convs on the fp32 MFMA"
+                                                  if os.environ.get("VD_CONV_SPLIT") == "0" else ""),
         "sec_per_clip_batch": round(250 * elapsed / args.steps, 2),
         "config": {"workload": "BASELINE configs[1]: BAIR-shaped 64x64, T=16 (4 obs + 12 latent), batch 8 per GPU, "
                                "ddim250 respacing, p_sample, independent mode, default 116M-param video UNet",

@@ -70,5 +70,16 @@ int main() {
     run("V fragment read, swizzle (lr>>2)&3 ^ lr>>4", a);
     for (int l = 0; l < 64; ++l) { int lr = l & 31, lh = l >> 5; a[l] = lr * 80 + lh * 32; }
     run("V fragment read, 80 B rows", a);
+    // conv_wino_s64: block transform reads of the raw image, V writes, staging stores
+    for (int l = 0; l < 64; ++l) { int t = l >> 2, kq = l & 3, tx = t & 7, ty = t >> 3; a[l] = 2 * ty * 1280 + tx * 64 + kq * 16; }
+    run("s64 raw read, 8x8 tiles (rows 1280 B)", a);
+    for (int l = 0; l < 64; ++l) { int t = l >> 2, kq = l & 3, tx = t & 3, ty = t >> 2; a[l] = 2 * ty * 768 + tx * 64 + kq * 16; }
+    run("s64 raw read, 4x4 tiles (rows 768 B)", a);
+    for (int l = 0; l < 64; ++l) { int t = l >> 2, kq = l & 3; a[l] = t * 64 + ((kq ^ ((t >> 2) & 3)) * 16); }
+    run("s64 V write (swizzled slots)", a);
+    for (int l = 0; l < 64; ++l) { int pl = l >> 2, lq = l & 3, py = pl / 18, px = pl % 18; a[l] = py * 1280 + (px & 1) * 640 + (px >> 1) * 64 + lq * 16; }
+    run("s64 staging store, 18-wide patch", a);
+    for (int l = 0; l < 64; ++l) { int pl = l >> 2, lq = l & 3, py = pl / 10, px = pl % 10; a[l] = py * 768 + (px & 1) * 384 + (px >> 1) * 64 + lq * 16; }
+    run("s64 staging store, 10-wide patch", a);
     return 0;
 }

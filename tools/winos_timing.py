@@ -28,8 +28,15 @@ for nfr, Cin, Cout, H in SHAPES:
         _lib.check(op(_lib.ptr(x0), Cin, nfr, H, H, 0, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(res), None, 0,
                                            _lib.ptr(out), Cout, None, _lib.current_stream()))
         torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        op(_lib.ptr(x0), Cin, nfr, H, H, 0, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(res), None, 0, _lib.ptr(out), Cout, None, _lib.current_stream())
+    ev1.record()
+    torch.cuda.synchronize()
+    kus = ev0.elapsed_time(ev1) * 50.0
     assert stamps(st) == 0
     t = list(st)
     nch = Cin // 16
     print(f"Cin {Cin:4d} Cout {Cout:4d} H {H:2d}: prologue {t[1]-t[0]:6d}  loop {t[2]-t[1]:8d} ({(t[2]-t[1])/nch:6.0f}/chunk, {96 if S64 else 48} MFMA = {3072 if S64 else 1536})"
-          f"  epilogue {t[3]-t[2]:6d}  total {t[3]-t[0]:8d} = {(t[9]-t[8])/100:.1f} us -> {(t[3]-t[0])/max(t[9]-t[8],1)*0.1:.2f} GHz", flush=True)
+          f"  epilogue {t[3]-t[2]:6d}  total {t[3]-t[0]:8d} = {(t[9]-t[8])/100:.1f} us -> {(t[3]-t[0])/max(t[9]-t[8],1)*0.1:.2f} GHz | kernel {kus:7.1f} us = {2*9*Cin*Cout*nfr*H*H/kus*1e-6:6.1f} TFLOP/s direct-equivalent", flush=True)

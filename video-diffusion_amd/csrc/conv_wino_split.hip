@@ -375,7 +375,7 @@ static bool wsp_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 bool conv_wino_split_supported(const IgemmArgs& a) {
     const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
-    return a.wsplit && a.wwino != nullptr && a.ksz == 3 && a.stride == 1 && a.pad == 1 && Hl == Wl && wsp_pow2(Hl) && Hl >= 8 &&
+    return a.wsplit == 1 && a.wwino != nullptr && a.ksz == 3 && a.stride == 1 && a.pad == 1 && Hl == Wl && wsp_pow2(Hl) && Hl >= 8 &&
            a.Cout % 32 == 0 && a.Cin % (2 * SKC) == 0 && a.src1 == nullptr && a.C0 == a.Cin && a.affA == nullptr && a.act == 0 &&
            (size_t)a.nfr * a.Hs * a.Ws * a.Cin < (1u << 29) && (size_t)a.Cin * a.Cout * 96 < (1u << 31) &&
            (size_t)a.nfr * Hl * Wl * a.ldo < (1u << 29) && (a.res == nullptr || a.res_ld == a.ldo);

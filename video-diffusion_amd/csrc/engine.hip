@@ -66,10 +66,10 @@ static bool split_math() {
     return v;
 }
 
-// The 3x3 Winograd convs have the same option (conv_wino_split.hip); it is not yet faster than the fp32-MFMA kernel
-// (VALU- and LDS-bound, tools/winos_timing.py), so it is opt-in: VD_CONV_SPLIT=1.
+// The 3x3 Winograd convs run the same arithmetic (conv_wino_s64.hip: 64 couts per block, block-wide input transform);
+// VD_CONV_SPLIT=0 keeps them on the fp32-MFMA kernel (conv_wino.hip) while the linear layers stay split.
 static bool split_conv() {
-    static const bool v = [] { const char* e = getenv("VD_CONV_SPLIT"); return e && std::string(e) == "1" && split_math(); }();
+    static const bool v = [] { const char* e = getenv("VD_CONV_SPLIT"); return !(e && std::string(e) == "0") && split_math(); }();
     return v;
 }
 
@@ -126,12 +126,13 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     const double in_pix = (double)g.nfr * g.Hs * g.Ws;
     const double nz = g.zcount > 1 ? g.zcount : 1;
     const double bytes = nz * 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout);
-    const int cls = conv_wino_supported(g) || conv_wino_split_supported(g) ? (int)PC_CONV_WINO
+    const bool wino = conv_wino_supported(g) || conv_wino_split_supported(g) || conv_wino_s64_supported(g);
+    const int cls = wino ? (int)PC_CONV_WINO
                                            : igemm_tile_class(g.M, g.Cout) + (conv_halo_supported(g) ? (int)PC_CONV_128x128 : 0);
     char tag[56];
     snprintf(tag, sizeof(tag), "M=%d N=%d K=%d k%d s%d%s%s%s", g.M, g.Cout, g.Cin, g.ksz, g.stride, g.ups ? " ups" : "",
              g.affA ? " pro" : (g.act ? " act" : ""), g.res ? " res" : "");
-    VD_REQUIRE(g.stats == nullptr || conv_wino_supported(g) || conv_wino_split_supported(g),
+    VD_REQUIRE(g.stats == nullptr || wino,
                "GroupNorm partial sums requested from a kernel that has no such epilogue");
     ProfScope ps(cls, nz * 2.0 * g.M * g.Cout * cin * taps, bytes, st, tag);
     return launch_igemm(g, st);
@@ -1095,7 +1096,10 @@ int vd_profile_end(double* out, int cap) {
 }
 
 int vd_profile_classes(void) { return PC_COUNT; }
-const char* vd_profile_class_name(int i) { return i >= 0 && i < PC_COUNT ? kProfNames[i] : ""; }
+const char* vd_profile_class_name(int i) {
+    if (i == PC_CONV_WINO && split_conv()) return "conv3x3_wino_s64_kernel";      // the kernel that class runs on
+    return i >= 0 && i < PC_COUNT ? kProfNames[i] : "";
+}
 
 // ---- single-operator entry points ---------------------------------------------------------------
 int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, int ups, int stride,
