@@ -39,4 +39,4 @@ for nfr, Cin, Cout, H in SHAPES:
     t = list(st)
     nch = Cin // 16
     print(f"Cin {Cin:4d} Cout {Cout:4d} H {H:2d}: prologue {t[1]-t[0]:6d}  loop {t[2]-t[1]:8d} ({(t[2]-t[1])/nch:6.0f}/chunk, {96 if S64 else 48} MFMA = {3072 if S64 else 1536})"
-          f"  epilogue {t[3]-t[2]:6d}  total {t[3]-t[0]:8d} = {(t[9]-t[8])/100:.1f} us -> {(t[3]-t[0])/max(t[9]-t[8],1)*0.1:.2f} GHz | kernel {kus:7.1f} us = {2*9*Cin*Cout*nfr*H*H/kus*1e-6:6.1f} TFLOP/s direct-equivalent", flush=True)
+          f"  epilogue {t[3]-t[2]:6d}  total {t[3]-t[0]:8d} = {(t[9]-t[8])/100:.1f} us -> {(t[3]-t[0])/max(t[9]-t[8],1)*0.1:.2f} GHz |" + (f" pro: patch {t[4]-t[0]} transform {t[5]-t[4]} split {t[1]-t[5]}; epi: n0 {t[6]-t[2]} n1 {t[3]-t[6]} |" if S64 else "") + f" kernel {kus:7.1f} us = {2*9*Cin*Cout*nfr*H*H/kus*1e-6:6.1f} TFLOP/s direct-equivalent", flush=True)

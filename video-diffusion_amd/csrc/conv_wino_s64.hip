@@ -34,13 +34,13 @@ namespace vd {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-struct WinoS64Geom { int TF, tiles_x, tiles_y; };
+struct WinoS64Geom { int TF, tiles_x, tiles_y, nbx, nitems; };   // nbx = tiles_x*tiles_y*frame groups, nitems = nbx * Cout/64
 
 #ifdef VD_WINO_TIMING
 __device__ unsigned long long g_s64_stamp[10];
 #define S64_STAMP(i)                                                                                                   \
     do {                                                                                                               \
-        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {                                                  \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && s64_first) {                                                        \
             g_s64_stamp[i] = __builtin_readcyclecounter();                                                             \
             if (i == 0) g_s64_stamp[8] = __builtin_amdgcn_s_memrealtime();                                             \
             if (i == 3) g_s64_stamp[9] = __builtin_amdgcn_s_memrealtime();                                             \
@@ -87,55 +87,66 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <bool TF4>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, WinoS64Geom g) {
     constexpr int TTL = TF4 ? 2 : 3, TT = 1 << TTL, P = 2 * TT + 2;   // tiles per dim per frame, patch width
-    constexpr int NX = TF4 ? 7 : 6;            // patch float4 per thread
-    constexpr int SS = TF4 ? 16 : 64;          // patch-pixel step between a thread's staged elements
     // raw patch image (bytes): 64 B per pixel, pixels of even and odd x in two planes per row (neighbouring tiles read
-    // neighbouring 64 B of one plane), plane stride = 128 mod 256 so that four consecutive pixels of a staging store
-    // land in four different bank quarters
-    constexpr int PLB = TF4 ? 384 : 640, RSB = 2 * PLB, FSB = TF4 ? P * RSB : 0;
-    constexpr int XBUF = TF4 ? 4 * FSB : P * RSB;                    // 30720 / 23040
+    // neighbouring 64 B of one plane; a plane row is padded by one pixel slot).  It is filled by LDS-DMA
+    // (buffer_load_dwordx4 ... lds): lane l of a wave instruction writes 16 bytes at M0 + 16*l, whatever global address it
+    // gathers from, and zeros where that address fails the descriptor's range check (tools/lds_dma_probe.hip) -- so the
+    // image is a linear array of 16-byte slots, thread tid owns slots e*256 + tid, and padding, halo pixels outside the
+    // picture and frames past the end are simply out-of-range offsets.  No staging registers, no ds_write.
+    constexpr int SPP = TF4 ? 6 : 10;          // 64-byte pixel slots per plane row (P/2 pixels + 1 pad)
+    constexpr int PLB = SPP * 64, RSB = 2 * PLB, FSB = TF4 ? P * RSB : 0;
+    constexpr int NX = TF4 ? 8 : 6;            // DMA instructions per thread and patch: ceil(slots / 256)
+    constexpr int XBUF = NX * 4096;            // 32768 / 24576 >= 4 * FSB / P * RSB
     constexpr int VH = 32768;                                         // one V half-buffer: [16 positions][32 tiles][64 B]
-    constexpr int RAW0 = 2 * VH, DUMP = RAW0 + 2 * XBUF;
+    constexpr int RAW0 = 2 * VH;
+    constexpr int XON = RAW0 + 2 * XBUF;                              // 8 KB: the next item's patch offsets
     constexpr int HALF = TF4 ? 2 * FSB : 8 * RSB;                    // raw offset of tile t + 32 relative to tile t
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // [Vh 2][raw 2][dump 4 KB + one raw size]; reused as Z exchange
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [Vh 2][raw 2][8 KB]; Vh reused as Z exchange
     f32x4* const lds4 = reinterpret_cast<f32x4*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);          // Winograd row owned by this wave (scalar)
     const int lr = lane & 31, lh = lane >> 5;
+    [[maybe_unused]] bool s64_first = true;
     S64_STAMP(0);
-    int bx = blockIdx.x;
-    const int bxx = bx % g.tiles_x; bx /= g.tiles_x;
-    const int byy = bx % g.tiles_y; bx /= g.tiles_y;
-    const int f0 = bx * (TF4 ? 4 : 1);
-    const int ox0 = bxx * 2 * TT, oy0 = byy * 2 * TT;               // output-pixel origin of the block
     const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
     const int nchunk = a.Cin >> 4, ncoblk = a.Cout >> 5;
-    const int cob0 = blockIdx.y * 2;
-
-    // ---- patch staging: thread -> patch pixels sp0 + SS*e of its frame slot, channel quad lq
-    const int lq = tid & 3;
-    const int sf = TF4 ? wi : 0;
-    const int sp0 = (TF4 ? lane : tid) >> 2;
-    unsigned xo[NX];
-    int xw[NX];                                                       // LDS offset (16-byte units) in raw buffer 0
-#pragma unroll
-    for (int e = 0; e < NX; ++e) {
-        const int pl = sp0 + SS * e;
-        const int py = pl / P, px = pl - py * P;
-        const int ly = oy0 + py - 1, lx = ox0 + px - 1;
-        const bool in = pl < P * P && f0 + sf < a.nfr && ly >= 0 && ly < Hl && lx >= 0 && lx < Wl;
-        xo[e] = in ? (unsigned)(((f0 + sf) * a.Hs + (ly >> a.ups)) * a.Ws + (lx >> a.ups)) * (unsigned)(a.Cin * 4) + lq * 16u
-                   : 0x80000000u;
-        xw[e] = pl < P * P ? (RAW0 + sf * FSB + py * RSB + (px & 1) * PLB + (px >> 1) * 64) / 16 + lq
-                           : (DUMP + tid * 16) / 16 - 0;              // past the patch: own dump slot
-    }
-    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
-    f32x4 rx[NX];
-    auto x_load_one = [&](int chunk, int e) {
-        rx[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xo[e], chunk * 64, 0));
+    // work items: (tile block, frame group) fastest, cout block slowest; a block walks items blockIdx.x, +gridDim.x, ...
+    struct Item { int bxx, byy, f0, cob0, ox0, oy0; };
+    auto decode = [&](int it) {
+        Item r;
+        int bx = it % g.nbx;
+        r.cob0 = (it / g.nbx) * 2;
+        r.bxx = bx % g.tiles_x; bx /= g.tiles_x;
+        r.byy = bx % g.tiles_y; bx /= g.tiles_y;
+        r.f0 = bx * (TF4 ? 4 : 1);
+        r.ox0 = r.bxx * 2 * TT; r.oy0 = r.byy * 2 * TT;             // output-pixel origin of the item
+        return r;
     };
-    auto x_store_one = [&](int buf, int e) {
-        lds4[xw[e] + buf * (XBUF / 16)] = rx[e];                      // (dump slots follow raw buffer 1 and move with buf too)
+
+    // ---- patch staging: thread -> 16-byte slots e*256 + tid of the image = (pixel slot, channel quad)
+    unsigned xo[NX];
+    auto set_xo = [&](unsigned (&xo)[NX], const Item& w, int tid) {
+#pragma unroll
+        for (int e = 0; e < NX; ++e) {
+            const int gs = e * 256 + tid, lq = gs & 3, ps = gs >> 2;
+            const int fr = TF4 ? ps / (P * 2 * SPP) : 0, rr = TF4 ? ps % (P * 2 * SPP) : ps;
+            const int py = rr / (2 * SPP), r = rr % (2 * SPP), pxh = r % SPP, px = 2 * pxh + r / SPP;
+            const int ly = w.oy0 + py - 1, lx = w.ox0 + px - 1;
+            const bool in = fr < (TF4 ? 4 : 1) && py < P && pxh < P / 2 && w.f0 + fr < a.nfr && ly >= 0 && ly < Hl && lx >= 0 && lx < Wl;
+            xo[e] = in ? (unsigned)(((w.f0 + fr) * a.Hs + (ly >> a.ups)) * a.Ws + (lx >> a.ups)) * (unsigned)(a.Cin * 4) + lq * 16u
+                       : 0x80000000u;
+        }
+    };
+    const Item first = decode(blockIdx.x);
+    set_xo(xo, first, tid);
+    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto x_dma_one = [&](int chunk, int buf, int e) {               // 1 KiB of the image per wave instruction; chunk >= nchunk:
+        chunk = chunk >= nchunk ? chunk - nchunk : chunk;           // chunk - nchunk of the next item (xo has been swapped by then)
+#if defined(__HIP_DEVICE_COMPILE__)     // (the host pass of hipcc drops the whole kernel, stub included, if it sees this builtin)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr)(smem + (RAW0 + buf * XBUF + e * 4096) / 4 + wi * 256), 16, xo[e],
+                                                 chunk * 64, 0, 0);
+#endif
     };
 
     // ---- block transform: wave w -> row pair ih = w >> 1, tiles (w & 1)*16 + lane/4 of the half, channel quad lane & 3
@@ -149,27 +160,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
     const float tsg[2] = {-1.f, ih ? -1.f : 1.f};
     const int vwb = (tl * 64 + ((kq ^ ((tl >> 2) & 3)) * 16) + ih * 8 * 2048) / 16;     // + (il*4 + j)*128 + half*2048
     float tS[4][4], tX[4][4];                                        // [column][channel]
-    // one transform "half window" = row il of the pair for the 32 tiles of `half` of the patch in raw buffer `buf`:
-    //   t_read: 8 fragment reads; t_unit(u), u = 0..3: t[u] = dX[u] + s*dS[u]; u = 4..7: V column u-4 -> Vh[half]
-    auto t_read = [&](int buf, int half, int il, int c0, int c1) {
-        const int o = buf * (XBUF / 16) + half * (HALF / 16);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c >= c0 && c < c1) {
-                const int co = ((c & 1) * PLB + (c >> 1) * 64) / 16;
-                const f32x4 vs = lds4[trS + o + co], vx = lds4[trX[il] + o + co];
-                tS[c][0] = vs.x; tS[c][1] = vs.y; tS[c][2] = vs.z; tS[c][3] = vs.w;
-                tX[c][0] = vx.x; tX[c][1] = vx.y; tX[c][2] = vx.z; tX[c][3] = vx.w;
-            }
+    // one transform "half window" = row il of the pair for the 32 tiles of `half` of the patch in raw buffer `buf`, streamed
+    // by patch column so that few values are live at a time (the main loop has no register to spare):
+    //   t_read(c): the two fragments of column c;  t_unit(u), u = 0..7 =
+    //   t2, t0, V0 = t0 - t2, t1, V1 = t1 + t2, V2 = t2 - t1, t3, V3 = t1 - t3      with t[c] = dX[c] + s*dS[c], V -> Vh[half]
+    auto t_read = [&](int buf, int half, int il, int c) {
+        const int o = buf * (XBUF / 16) + half * (HALF / 16) + ((c & 1) * PLB + (c >> 1) * 64) / 16;
+        const f32x4 vs = lds4[trS + o], vx = lds4[trX[il] + o];
+        tS[c][0] = vs.x; tS[c][1] = vs.y; tS[c][2] = vs.z; tS[c][3] = vs.w;
+        tX[c][0] = vx.x; tX[c][1] = vx.y; tX[c][2] = vx.z; tX[c][3] = vx.w;
     };
     auto t_unit = [&](int half, int il, int u) {
-        if (u < 4) {
+        constexpr int ROWC[8] = {2, 0, -1, 1, -1, -1, 3, -1};       // row-combination units: the column they form
+        constexpr int VJ[8] = {-1, -1, 0, -1, 1, 2, -1, 3};         // column-combination units: the position they write
+        if (ROWC[u] >= 0) {
+            const int c = ROWC[u];
             const float s = tsg[il];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(tX[u][h]) : "v"(tS[u][h]), "v"(s));
+            for (int h = 0; h < 4; ++h) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(tX[c][h]) : "v"(tS[c][h]), "v"(s));
         } else {
-            const int j = u - 4;
-            // j0: t0 - t2   j1: t1 + t2   j2: t2 - t1   j3: t1 - t3
+            const int j = VJ[u];
             const int ca = j == 0 ? 0 : j == 2 ? 2 : 1, cb = j == 3 ? 3 : j == 2 ? 1 : 2;
             float v[4];
 #pragma unroll
@@ -208,55 +218,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
     const auto usrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wwino), 0, 16 * a.Cout * a.Cin * 6, 0x00020000);
     const int ustride = 16 * ncoblk * 3072;
     const unsigned blane = lane * 16u;
-    int bso[4][2];                                                    // scalar byte offsets of (j, n) within a chunk
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) bso[j][n] = ((wi * 4 + j) * ncoblk + cob0 + n) * 3072;
+    // scalar byte offset of (j, n) within a chunk = base(item) + j * bstep + n * 3072
+    const int bstep = ncoblk * 3072;
+    int bsb = 0;
     bf16x8 bfr[4][2][3];                                              // [j][n][piece], single set
-    auto b_load_one = [&](int chunk, int j, int n, int p) {
-        bfr[j][n][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, chunk * ustride + bso[j][n] + p * 1024, 0));
+    auto b_load_one = [&](int chunk, int j, int n, int p) {         // past the last chunk: the last one again (unused)
+        const int so = min(chunk, nchunk - 1) * ustride + bsb + j * bstep + n * 3072;
+        bfr[j][n][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, so + p * 1024, 0));
     };
 
     f32x16 acc[2][4][2];                                             // [m][j][n]
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][j][n][r] = 0.f;
 
-    // ---- prologue: raw[0] in LDS, raw[1] in flight, weights of chunk 0, V of groups 0 and 1, pieces of position 0
+    // ---- first item: raw[0], raw[1] requested.  Later items find exactly this state: the last two chunks of an item request the
+    // first two patches of the NEXT one (patch offsets swapped with the chunk index folded in); they land under the last
+    // groups and the output transform.
 #pragma unroll
-    for (int e = 0; e < NX; ++e) x_load_one(0, e);
+    for (int e = 0; e < NX; ++e) x_dma_one(0, 0, e);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) b_load_one(0, j, n, p);
-#pragma unroll
-    for (int e = 0; e < NX; ++e) x_store_one(0, e);
-#pragma unroll
-    for (int e = 0; e < NX; ++e) x_load_one(min(1, nchunk - 1), e);
-    __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; ++half)
-#pragma unroll
-        for (int il = 0; il < 2; ++il) {
-            t_read(0, half, il, 0, 4);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t_unit(half, il, u);
-        }
-    __syncthreads();
-    v_read(0, 0, 0);
-#pragma unroll
-    for (int pr = 0; pr < 4; ++pr) { s_split(0, pr, 0); s_split(0, pr, 1); }
-    v_read(1, 0, 1);
+    for (int e = 0; e < NX; ++e) x_dma_one(1, 1, e);
 
-    S64_STAMP(1);
     // one position = 12 MFMA slots.  (chunk, m, j) with chunk parity cp compile-time; everything else immediate.
     auto position = [&](int chunk, int cp, int m, int j) {
         const int pi = (m * 4 + j) & 1;                               // ring slot of this position's pieces / fragment
@@ -270,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
         const int thalf = j >= 2 ? m : m ^ 1;
         const int tbuf = (j >= 2 || m == 1) ? cp ^ 1 : cp;
         const int ubase = (j & 1) * 4;
-        const int n1 = min(chunk + 1, nchunk - 1), n2 = min(chunk + 2, nchunk - 1);
+        const int n1 = chunk + 1;                                     // past the last chunk: the next item's (b_load_one, patch offsets)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             f32x16 c = acc[m][j][n];
@@ -281,10 +261,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, apc[pi][PA[q]]), bfr[j][n][PB[q]], c, 0, 0, 0);
                 // split of position p+1: pairs at slots (0,1) (3,4) (6,7) (9,10)
                 if (!(VD_S64_SKIP & 1) && k % 3 != 2) s_split(pi ^ 1, k / 3, k % 3);
-                // transform unit at slots 2, 5, 8, 11; its reads at slot 0 of the even positions
+                // transform unit at slots 2, 5, 8, 11
                 if (!(VD_S64_SKIP & 16)) {
-                    if ((j & 1) == 0 && k == 0) t_read(tbuf, thalf, til, 0, 2);
-                    if ((j & 1) == 0 && k == 1) t_read(tbuf, thalf, til, 2, 4);
+                    // column fragments two to five slots ahead of the unit that combines them
+                    if ((j & 1) == 0 && k == 0) t_read(tbuf, thalf, til, 2);
+                    if ((j & 1) == 0 && k == 1) t_read(tbuf, thalf, til, 0);
+                    if ((j & 1) == 0 && k == 6) t_read(tbuf, thalf, til, 1);
+                    if ((j & 1) == 1 && k == 3) t_read(tbuf, thalf, til, 3);
                     if (k % 3 == 2) t_unit(thalf, til, ubase + k / 3);
                 }
                 // fragment of position p+2 (its ring slot is free: position p's was consumed during p-1)
@@ -294,13 +277,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
                     if (n == 1 && q < 3) b_load_one(n1, j, 0, q);
                     if (n == 0 && q >= 3 && j > 0) b_load_one(n1, j - 1, 1, q - 3);
                 }
-                // patch: raw[chunk+1] registers -> LDS in positions 0,1 of (chunk, 0), raw[chunk+2] requested in 2,3
-                if (!(VD_S64_SKIP & 8) && m == 0) {
-                    const int xe = (j & 1) * 6 + (k >> 1);            // 0..11, one every other slot
-                    if ((k & 1) == 1 && xe < NX) {
-                        if (j < 2) x_store_one(cp ^ 1, xe);
-                        else x_load_one(n2, xe);
-                    }
+                // patch: raw[chunk+2] by LDS-DMA into the buffer of raw[chunk] (free since this group's barrier), one request
+                // every other slot of positions 2,3 of (chunk, 0); it has a whole chunk to land (read from (chunk+1, 0) 2,3 on)
+                if (!(VD_S64_SKIP & 8) && m == 0 && j >= 2) {
+                    const int xe = (j & 1) * 6 + (k >> 1);            // 0..11
+                    if ((k & 1) == 1 && xe < NX) x_dma_one(chunk + 2, cp, xe);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -310,124 +291,189 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
 #pragma unroll
             for (int p = 0; p < 3; ++p) b_load_one(n1, 3, 1, p);
         }
-        if (j == 1) lds_barrier();
+        if (j == 1) {
+            // the patch requested in (chunk-1, 0) must have landed: only the 24 weight loads of (chunk-1, 1) are younger
+            if (m == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            lds_barrier();
+        }
         __builtin_amdgcn_sched_barrier(0);
         (void)nj; (void)nm;
     };
-    for (int chunk = 0; chunk < nchunk; chunk += 2) {               // nchunk is even (conv_wino_s64_supported)
+    for (int it = blockIdx.x; it < g.nitems; it += gridDim.x) {
+        const int itn = it + (int)gridDim.x < g.nitems ? it + (int)gridDim.x : it;   // no next item: its own again (unused)
+        // weights of chunk 0: requested here, not under the previous item's output transform -- 96 live registers there
+        // made the compiler spill; they come from L2
+        bsb = (wi * 4 * ncoblk + (it / g.nbx) * 2) * 3072;
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) position(chunk + cp, cp, m, j);
-    }
-
-    S64_STAMP(2);
-    // ---- output transform (conv_wino.hip), one cout block (n) at a time: Z[q] = sum_j M[wi][j] A[j][q] wave-local, sum
-    // over i through LDS, wave (p, q) owns output pixel (p, q) of every tile; branch-free via buffer range checks
-    const int p = wi >> 1, q = wi & 1;
-    unsigned oo[2][16];
+                for (int p = 0; p < 3; ++p) b_load_one(0, j, n, p);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int tx = t & (TT - 1), ty = (t >> TTL) & (TT - 1), f = t >> (2 * TTL);
-            const int nf = f0 + f;
-            const unsigned o = (unsigned)(((nf * Hl + oy0 + 2 * ty + p) * Wl + ox0 + 2 * tx + q) * a.ldo + cob0 * 32 + lr) * 4u;
-            oo[m][r] = nf < a.nfr ? o : 0x80000000u;
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][j][n][r] = 0.f;
+        {   // the next item's patch offsets, computed while few registers are live and parked in LDS until the last chunks
+            unsigned xn[NX];
+            int tidv = tid;                          // re-materialised: the lane-dependent parts of set_xo must not be hoisted
+            asm volatile("" : "+v"(tidv));           // out of the item loop (they would be spilled and reloaded one by one)
+            set_xo(xn, decode(itn), tidv);
+            lds4[XON / 16 + tid * 2] = __builtin_bit_cast(f32x4, u32x4{xn[0], xn[1], xn[2], xn[3]});
+            lds4[XON / 16 + tid * 2 + 1] = __builtin_bit_cast(f32x4, u32x4{xn[4], xn[5], NX > 6 ? xn[6] : 0u, NX > 6 ? xn[NX - 1] : 0u});
         }
-    const int obytes = a.nfr * Hl * Wl * a.ldo * 4;
-    const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
-    float* Zs = smem;                                                // [plane = 2i + q][m 2][reg16/4][lane 64][4]  (8 planes of 8 KB)
-    const float sgn = p ? -1.f : 1.f;
-    // the true M rows: row 3 of both U and V carries a flipped sign, their product does not
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // raw[0] of this item (LDS-DMA) and the weights of chunk 0 have landed
+        __syncthreads();                             // ... for every wave; the previous item is done with the LDS
+        S64_STAMP(4);
+        // V of groups 0 and 1, pieces of position 0
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int co = (cob0 + n) * 32 + lr;
-        const float bv = a.bias ? a.bias[co] : 0.f;
-        f32x16 rv[2];
-        __syncthreads();                                             // every wave is done with the LDS (V / previous Z)
+        for (int half = 0; half < 2; ++half)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+            for (int il = 0; il < 2; ++il) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], n * 128, 0));
-            const f32x16 z0 = acc[m][0][n] + acc[m][1][n] + acc[m][2][n];
-            const f32x16 z1 = acc[m][1][n] - acc[m][2][n] - acc[m][3][n];
+                for (int c = 0; c < 4; ++c) t_read(0, half, il, c);
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                float* d0 = Zs + ((((wi * 2 + 0) * 2 + m) * 4 + c4) * 64 + lane) * 4;
-                float* d1 = Zs + ((((wi * 2 + 1) * 2 + m) * 4 + c4) * 64 + lane) * 4;
-                *reinterpret_cast<f32x4*>(d0) = f32x4{z0[4 * c4], z0[4 * c4 + 1], z0[4 * c4 + 2], z0[4 * c4 + 3]};
-                *reinterpret_cast<f32x4*>(d1) = f32x4{z1[4 * c4], z1[4 * c4 + 1], z1[4 * c4 + 2], z1[4 * c4 + 3]};
+                for (int u = 0; u < 8; ++u) t_unit(half, il, u);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
         __syncthreads();
-        const float* zw = Zs + wi * 2048 + lane * 4;                 // Z[p + k][q] is plane wi + 2k
-        float gsum[TF4 ? 4 : 1][2] = {};
+        S64_STAMP(5);
+        v_read(0, 0, 0);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            f32x16 y;
+        for (int pr = 0; pr < 4; ++pr) { s_split(0, pr, 0); s_split(0, pr, 1); }
+        v_read(1, 0, 1);
+        S64_STAMP(1);
+        for (int chunk = 0; chunk < nchunk; chunk += 2) {           // nchunk is even (conv_wino_s64_supported)
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const float* zp = zw + (m * 4 + c4) * 256;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(zp) +
-                                (*reinterpret_cast<const f32x4*>(zp + 2 * 2048) + *reinterpret_cast<const f32x4*>(zp + 4 * 2048)) * sgn;
-                y[4 * c4] = v.x; y[4 * c4 + 1] = v.y; y[4 * c4 + 2] = v.z; y[4 * c4 + 3] = v.w;
-            }
-            y += rv[m];
-            if (a.fbias) {
+            for (int cp = 0; cp < 2; ++cp)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int t = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    y[r] += a.fbias[(size_t)min(f0 + (t >> (2 * TTL)), a.nfr - 1) * a.fbias_ld + co];
-                }
-            }
-            y += bv;
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)y[r]), osrc, oo[m][r], n * 128, 0);
-            if (a.stats) {
-#pragma unroll
-                for (int h = 0; h < (TF4 ? 2 : 1); ++h) {
-                    float s = 0.f, ss = 0.f;
-#pragma unroll
-                    for (int r = h * (TF4 ? 8 : 0); r < (TF4 ? 8 * h + 8 : 16); ++r) { s += y[r]; ss += y[r] * y[r]; }
-                    const int fs = TF4 ? 2 * m + h : 0;
-                    gsum[fs][0] += s; gsum[fs][1] += ss;
-                }
-            }
+                    for (int j = 0; j < 4; ++j) {
+                        if (cp == 0 && m == 0 && j == 2 && chunk + 2 == nchunk) {   // from here on the patch requests are the next item's
+                            const u32x4 n0 = __builtin_bit_cast(u32x4, lds4[XON / 16 + tid * 2]), n1 = __builtin_bit_cast(u32x4, lds4[XON / 16 + tid * 2 + 1]);
+                            xo[0] = n0.x; xo[1] = n0.y; xo[2] = n0.z; xo[3] = n0.w; xo[4] = n1.x; xo[5] = n1.y;
+                            if constexpr (NX > 6) { xo[6] = n1.z; xo[NX - 1] = n1.w; }
+                        }
+                        position(chunk + cp, cp, m, j);
+                    }
         }
-        if (a.stats) {                                               // GroupNorm partial sums of the output (conv_wino.hip)
-            constexpr int NFS = TF4 ? 4 : 1;
-            __syncthreads();
-            double* red = reinterpret_cast<double*>(smem);           // [wave 4][lh 2][fs][lr 32][2]
-#pragma unroll
-            for (int fs = 0; fs < NFS; ++fs) {
-                double* d = red + ((((wi * 2 + lh) * NFS + fs) * 32 + lr) * 2);
-                d[0] = (double)gsum[fs][0]; d[1] = (double)gsum[fs][1];
+        S64_STAMP(2);
+        const Item cur = decode(it);
+        // lane-derived values re-materialised here: otherwise hipcc hoists the epilogue's lane-dependent address terms out of
+        // the item loop and they sit in VGPRs through the main loop, which has none to spare
+        int e_lr = lr, e_lh = lh, e_lane = lane, e_tid = tid;
+        asm volatile("" : "+v"(e_lr), "+v"(e_lh), "+v"(e_lane), "+v"(e_tid));
+        // ---- output transform (conv_wino.hip), one cout block (n) at a time: Z[q] = sum_j M[wi][j] A[j][q] wave-local, sum
+        // over i through LDS, wave (p, q) owns output pixel (p, q) of every tile; branch-free via buffer range checks
+        const int p = wi >> 1, q = wi & 1;
+        unsigned oo[2][16];
+    #pragma unroll
+        for (int m = 0; m < 2; ++m)
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * e_lh;
+                const int tx = t & (TT - 1), ty = (t >> TTL) & (TT - 1), f = t >> (2 * TTL);
+                const int nf = cur.f0 + f;
+                const unsigned o = (unsigned)(((nf * Hl + cur.oy0 + 2 * ty + p) * Wl + cur.ox0 + 2 * tx + q) * a.ldo + cur.cob0 * 32 + e_lr) * 4u;
+                oo[m][r] = nf < a.nfr ? o : 0x80000000u;
+            }
+        const int obytes = a.nfr * Hl * Wl * a.ldo * 4;
+        const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
+        float* Zs = smem;                                                // [plane = 2i + q][m 2][reg16/4][e_lane 64][4]  (8 planes of 8 KB)
+        const float sgn = p ? -1.f : 1.f;
+        // the true M rows: row 3 of both U and V carries a flipped sign, their product does not
+    #pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int co = (cur.cob0 + n) * 32 + e_lr;
+            const float bv = a.bias ? a.bias[co] : 0.f;
+            f32x16 rv[2];
+            __syncthreads();                                             // every wave is done with the LDS (V / previous Z)
+    #pragma unroll
+            for (int m = 0; m < 2; ++m) {
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], n * 128, 0));
+                const f32x16 z0 = acc[m][0][n] + acc[m][1][n] + acc[m][2][n];
+                const f32x16 z1 = acc[m][1][n] - acc[m][2][n] - acc[m][3][n];
+    #pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    float* d0 = Zs + ((((wi * 2 + 0) * 2 + m) * 4 + c4) * 64 + e_lane) * 4;
+                    float* d1 = Zs + ((((wi * 2 + 1) * 2 + m) * 4 + c4) * 64 + e_lane) * 4;
+                    *reinterpret_cast<f32x4*>(d0) = f32x4{z0[4 * c4], z0[4 * c4 + 1], z0[4 * c4 + 2], z0[4 * c4 + 3]};
+                    *reinterpret_cast<f32x4*>(d1) = f32x4{z1[4 * c4], z1[4 * c4 + 1], z1[4 * c4 + 2], z1[4 * c4 + 3]};
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
-            if (tid < NFS * 32) {
-                const int fs = tid >> 5, c = tid & 31;
-                double s = 0.0, ss = 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const double* d = red + (((k * NFS + fs) * 32 + c) * 2);
-                    s += d[0]; ss += d[1];
+            const float* zw = Zs + wi * 2048 + e_lane * 4;                 // Z[p + k][q] is plane wi + 2k
+            float gsum[TF4 ? 4 : 1][2] = {};
+    #pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x16 y;
+    #pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const float* zp = zw + (m * 4 + c4) * 256;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(zp) +
+                                    (*reinterpret_cast<const f32x4*>(zp + 2 * 2048) + *reinterpret_cast<const f32x4*>(zp + 4 * 2048)) * sgn;
+                    y[4 * c4] = v.x; y[4 * c4 + 1] = v.y; y[4 * c4 + 2] = v.z; y[4 * c4 + 3] = v.w;
                 }
-                const int nf = f0 + fs;
-                const int sp = TF4 ? 0 : byy * g.tiles_x + bxx;
-                if (nf < a.nfr) {
-                    double* o = a.stats + (((size_t)nf * a.stats_split + sp) * a.Cout + (cob0 + n) * 32 + c) * 2;
-                    o[0] = s; o[1] = ss;
+                y += rv[m];
+                if (a.fbias) {
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int t = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * e_lh;
+                        y[r] += a.fbias[(size_t)min(cur.f0 + (t >> (2 * TTL)), a.nfr - 1) * a.fbias_ld + co];
+                    }
+                }
+                y += bv;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)y[r]), osrc, oo[m][r], n * 128, 0);
+                if (a.stats) {
+    #pragma unroll
+                    for (int h = 0; h < (TF4 ? 2 : 1); ++h) {
+                        float s = 0.f, ss = 0.f;
+    #pragma unroll
+                        for (int r = h * (TF4 ? 8 : 0); r < (TF4 ? 8 * h + 8 : 16); ++r) { s += y[r]; ss += y[r] * y[r]; }
+                        const int fs = TF4 ? 2 * m + h : 0;
+                        gsum[fs][0] += s; gsum[fs][1] += ss;
+                    }
                 }
             }
+            if (a.stats) {                                               // GroupNorm partial sums of the output (conv_wino.hip)
+                constexpr int NFS = TF4 ? 4 : 1;
+                __syncthreads();
+                double* red = reinterpret_cast<double*>(smem);           // [wave 4][e_lh 2][fs][e_lr 32][2]
+    #pragma unroll
+                for (int fs = 0; fs < NFS; ++fs) {
+                    double* d = red + ((((wi * 2 + e_lh) * NFS + fs) * 32 + e_lr) * 2);
+                    d[0] = (double)gsum[fs][0]; d[1] = (double)gsum[fs][1];
+                }
+                __syncthreads();
+                if (e_tid < NFS * 32) {
+                    const int fs = e_tid >> 5, c = e_tid & 31;
+                    double s = 0.0, ss = 0.0;
+    #pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const double* d = red + (((k * NFS + fs) * 32 + c) * 2);
+                        s += d[0]; ss += d[1];
+                    }
+                    const int nf = cur.f0 + fs;
+                    const int sp = TF4 ? 0 : cur.byy * g.tiles_x + cur.bxx;
+                    if (nf < a.nfr) {
+                        double* o = a.stats + (((size_t)nf * a.stats_split + sp) * a.Cout + (cur.cob0 + n) * 32 + c) * 2;
+                        o[0] = s; o[1] = ss;
+                    }
+                }
+            }
+            if (n == 0) S64_STAMP(6);
         }
+        S64_STAMP(3);
+        s64_first = false;
     }
-    S64_STAMP(3);
 }
 
 static bool s64_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -447,7 +493,7 @@ int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s) {
     const int TT = Hl >= 16 ? 8 : 4;
     g.TF = 64 / (TT * TT);
     g.tiles_x = Hl / (2 * TT); g.tiles_y = Hl / (2 * TT);
-    const size_t lds = 2 * 32768 + 3 * (g.TF == 4 ? 30720 : 23040) + 4096;
+    const size_t lds = 2 * 32768 + 2 * (g.TF == 4 ? 8 : 6) * 4096 + 8192;
     static bool attr = false;
     if (!attr) {
         const void* fns[2] = {reinterpret_cast<const void*>(&conv3x3_wino_s64_kernel<true>),
@@ -456,7 +502,15 @@ int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s) {
         attr = true;
     }
     const int fgroups = (a.nfr + g.TF - 1) / g.TF;
-    dim3 grid(g.tiles_x * g.tiles_y * fgroups, a.Cout / 64);
+    g.nbx = g.tiles_x * g.tiles_y * fgroups;
+    g.nitems = g.nbx * (a.Cout / 64);
+    static int ncu = 0;                               // one block per CU (512 registers per lane, > 110 KB of LDS): a persistent grid
+    if (!ncu) {
+        int dev = 0;
+        VD_HIP(hipGetDevice(&dev));
+        VD_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    dim3 grid(std::min(g.nitems, ncu));
     if (g.TF == 4) hipLaunchKernelGGL((conv3x3_wino_s64_kernel<true>), grid, dim3(256), lds, s, a, g);
     else hipLaunchKernelGGL((conv3x3_wino_s64_kernel<false>), grid, dim3(256), lds, s, a, g);
     VD_HIP(hipGetLastError());
