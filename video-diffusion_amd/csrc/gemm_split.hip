@@ -159,10 +159,18 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int srow = ((r & 3) + 8 * (r >> 2)) * a.ldo * 4;
-                acc[i][j][r] = bv[j] + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vb[i][j] + srow, 0, 0));
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];
+    if (a.res) {                                 // (uniform) 16 residual requests per tile only where there is a residual
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int srow = ((r & 3) + 8 * (r >> 2)) * a.ldo * 4;
+                    acc[i][j][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vb[i][j] + srow, 0, 0));
+                }
+    }
 
     const int nks = 2 * nchunk;
     a_prefetch(0);
