@@ -263,10 +263,11 @@ def test_infer_video_autoreg_vs_oracle(monkeypatch):
     assert to_uint8(got).dtype == np.uint8 and to_uint8(np.array([1.0, -1.0, 0.0])).tolist() == [255, 0, 127]
 
 
-@pytest.mark.parametrize("size,mc,B,T,n_obs", [(128, 32, 1, 4, 2), (64, 64, 2, 20, 13), (32, 64, 1, 32, 16)])
+@pytest.mark.parametrize("size,mc,B,T,n_obs", [(128, 32, 1, 4, 2), (128, 64, 1, 3, 1), (64, 64, 2, 20, 13), (32, 64, 1, 32, 16)])
 def test_other_baseline_shapes_vs_oracle(size, mc, B, T, n_obs):
     """BASELINE configs 3-5 in miniature: the 128x128 topology (channel_mult (1,1,2,3,4), five levels, script_util.py:255-264),
-    Tw = 20 autoregressive windows (TMAX=32 code paths of the temporal kernels) and the 32-frame limit."""
+    Tw = 20 autoregressive windows (TMAX=32 code paths of the temporal kernels) and the 32-frame limit.  The 64-channel
+    128x128 case puts the Winograd kernels on 128x128 and 64x64 feature maps (8x8 and 4x4 tile blocks per frame)."""
     cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=T, image_size=size, num_channels=mc, num_res_blocks=1,
                                                               rp_alpha=T, rp_beta=T, rp_gamma=T,
                                                               timestep_respacing="ddim50")}
