@@ -454,7 +454,10 @@ def pack_lin_split(w):
 
 
 @pytest.mark.parametrize("M,K,N,act,res", [(128, 128, 512, 0, 0), (4099, 96, 288, 0, 1), (300, 1024, 64, 1, 0),
-                                           (2048, 384, 384, 0, 1), (70, 64, 128, 1, 1)])
+                                           (2048, 384, 384, 0, 1), (70, 64, 128, 1, 1),
+                                           # large enough for gemm_wave.hip (VD_GEMM_WAVE=1: one wave per 128 x 32*NT tile; NT = 3, 4, 2)
+                                           (8192, 64, 1536, 0, 1), (8135, 96, 1536, 0, 0), (8192, 128, 1536, 1, 0),
+                                           (32768, 64, 512, 0, 1), (65536, 32, 320, 0, 0)])
 def test_linear_split_bf16x6_is_fp32_accurate(M, K, N, act, res):
     """csrc/gemm_split.hip: fp32 operands split exactly into three bf16 pieces, six piece products on the bf16 matrix
     cores, fp32 accumulation.  Held to the op tolerance against torch fp32 AND, against an fp64 product, required to be

@@ -56,30 +56,6 @@ extern "C" int vd_debug_s64_stamps(unsigned long long* host_out) {
 #define VD_S64_SKIP 0      // kernel-experiment builds (timing only, results wrong): bit 0 no split VALU, 1 no weight loads,
 #endif                     // 2 no fragment reads, 3 no patch loads/stores, 4 no transform
 
-// first half of the exact three-way split of a value pair (conv_wino_split.hip): p1 = top halves, r = x - p1
-__device__ __forceinline__ void split_a(float x0, float x1, unsigned& p1, float& r0, float& r1, unsigned sel) {
-    float h0, h1;
-    asm("v_and_b32 %3, 0xffff0000, %5\n\t"
-        "v_and_b32 %4, 0xffff0000, %6\n\t"
-        "v_perm_b32 %0, %6, %5, %7\n\t"
-        "v_sub_f32 %1, %5, %3\n\t"
-        "v_sub_f32 %2, %6, %4"
-        : "=&v"(p1), "=&v"(r0), "=&v"(r1), "=&v"(h0), "=&v"(h1)
-        : "v"(x0), "v"(x1), "s"(sel));
-}
-// second half: p2 = top halves of r, p3 = r - p2 (exactly a bf16 value)
-__device__ __forceinline__ void split_b(float r0, float r1, unsigned& p2, unsigned& p3, unsigned sel) {
-    float h0, h1;
-    asm("v_and_b32 %2, 0xffff0000, %4\n\t"
-        "v_and_b32 %3, 0xffff0000, %5\n\t"
-        "v_perm_b32 %0, %5, %4, %6\n\t"
-        "v_sub_f32 %2, %4, %2\n\t"
-        "v_sub_f32 %3, %5, %3\n\t"
-        "v_perm_b32 %1, %3, %2, %6"
-        : "=&v"(p2), "=&v"(p3), "=&v"(h0), "=&v"(h1)
-        : "v"(r0), "v"(r1), "s"(sel));
-}
-
 // workgroup barrier that waits for this wave's LDS traffic only (a __syncthreads() would also drain the weight and
 // patch loads in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

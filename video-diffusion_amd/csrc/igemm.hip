@@ -203,6 +203,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     VD_REQUIRE(a.ksz == 1 || a.ksz == 3, "kernel size 1 or 3");
     VD_REQUIRE(a.M > 0 && a.Cout > 0, "empty problem");
     VD_REQUIRE(a.M == a.nfr * a.Ho * a.Wo, "M != nfr*Ho*Wo");
+    if (gemm_wave_supported(a)) return launch_gemm_wave(a, s);
     if (gemm_split_supported(a) || conv_split_supported(a)) return launch_gemm_split(a, igemm_tile_class(a.M, a.Cout), s);
     if (conv_wino_s64_supported(a)) return launch_conv_wino_s64(a, s);
     if (conv_wino_split_supported(a)) return launch_conv_wino_split(a, s);

@@ -107,10 +107,38 @@ bool conv_wino_split_supported(const IgemmArgs& a);
 int launch_conv_wino_split(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino_split(const float* oihw, unsigned short* out, int O, int I);
 // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
+// ---- exact three-way bf16 split of a pair of fp32 values (conv_wino_s64.hip, gemm_wave.hip), plain VALU only: v_pk_*_f32
+// and v_dot2c_f32_bf16 do not overlap the bf16 MFMA (tools/mfma_bf16_coissue.hip)
+// first half: p1 = top halves (a bf16 pair), r = x - p1 (exact)
+__device__ __forceinline__ void split_a(float x0, float x1, unsigned& p1, float& r0, float& r1, unsigned sel) {
+    float h0, h1;
+    asm("v_and_b32 %3, 0xffff0000, %5\n\t"
+        "v_and_b32 %4, 0xffff0000, %6\n\t"
+        "v_perm_b32 %0, %6, %5, %7\n\t"
+        "v_sub_f32 %1, %5, %3\n\t"
+        "v_sub_f32 %2, %6, %4"
+        : "=&v"(p1), "=&v"(r0), "=&v"(r1), "=&v"(h0), "=&v"(h1)
+        : "v"(x0), "v"(x1), "s"(sel));
+}
+// second half: p2 = top halves of r, p3 = r - p2 (exactly a bf16 value)
+__device__ __forceinline__ void split_b(float r0, float r1, unsigned& p2, unsigned& p3, unsigned sel) {
+    float h0, h1;
+    asm("v_and_b32 %2, 0xffff0000, %4\n\t"
+        "v_and_b32 %3, 0xffff0000, %5\n\t"
+        "v_perm_b32 %0, %5, %4, %6\n\t"
+        "v_sub_f32 %2, %4, %2\n\t"
+        "v_sub_f32 %3, %5, %3\n\t"
+        "v_perm_b32 %1, %3, %2, %6"
+        : "=&v"(p2), "=&v"(p3), "=&v"(h0), "=&v"(h1)
+        : "v"(r0), "v"(r1), "s"(sel));
+}
+
 bool conv_wino_s64_supported(const IgemmArgs& a);        // conv_wino_s64.hip: wsplit == 2 (its own weight image)
 int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino_s64(const float* oihw, unsigned short* out, int O, int I);
 bool gemm_split_supported(const IgemmArgs& a);
+bool gemm_wave_supported(const IgemmArgs& a);            // gemm_wave.hip: large plain GEMMs, one wave per 128 x 32*NT tile
+int launch_gemm_wave(const IgemmArgs& a, hipStream_t s);
 bool conv_split_supported(const IgemmArgs& a);          // 3x3, stride 1|2: the same kernel over an implicit im2col A
 void pack_conv3_split(const float* w_oihw, unsigned short* out, int Cout, int Cin);
 int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s);
