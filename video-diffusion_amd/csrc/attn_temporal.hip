@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(AttnTemporalArgs a) 
         const float* rq = RPE ? a.Rq + (((size_t)b * T + s) * T + t) * C + h * F : nullptr;
         const float* qrow = qs + t * FP;
         const float* krow = ks + s * FP;
+#pragma unroll 3
         for (int f0 = 0; f0 < F; f0 += 8) {
             f32x4 rk0, rk1, rq0, rq1;
             if constexpr (RPE) {
