@@ -705,7 +705,11 @@ int vd_engine::ensure_ws(int B, int T) {
 extern "C" {
 
 const char* vd_last_error(void) { return g_last_error.c_str(); }
-const char* vd_version(void) { return "vdamd 0.1 (gfx950, fp32 MFMA)"; }
+const char* vd_version(void) {
+    return split_conv() ? "vdamd 0.2 (gfx950; fp32 operands, matrix products as six bf16 piece products with fp32 accumulation)"
+           : split_math() ? "vdamd 0.2 (gfx950; linear layers as six bf16 piece products, 3x3 convs on the fp32 MFMA)"
+                          : "vdamd 0.2 (gfx950, fp32 MFMA)";
+}
 
 int vd_create(const vd_config* cfg, vd_engine** out) {
     VD_REQUIRE(cfg && out, "null argument");
