@@ -52,6 +52,9 @@ extern "C" int vd_debug_s64_stamps(unsigned long long* host_out) {
 #else
 #define S64_STAMP(i)
 #endif
+#ifndef VD_S64_ILV
+#define VD_S64_ILV 1       // A/B builds: 0 = the six piece products of a tile back to back on one accumulator
+#endif
 #ifndef VD_S64_SKIP
 #define VD_S64_SKIP 0      // kernel-experiment builds (timing only, results wrong): bit 0 no split VALU, 1 no weight loads,
 #endif                     // 2 no fragment reads, 3 no patch loads/stores, 4 no transform
@@ -227,14 +230,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
         const int tbuf = (j >= 2 || m == 1) ? cp ^ 1 : cp;
         const int ubase = (j & 1) * 4;
         const int n1 = chunk + 1;                                     // past the last chunk: the next item's (b_load_one, patch offsets)
+        f32x16 cc[2] = {acc[m][j][0], acc[m][j][1]};
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            f32x16 c = acc[m][j][n];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
+        for (int k = 0; k < 12; ++k) {                               // slot 0..11 of the position
+            {
                 constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};     // small terms first
-                const int k = n * 6 + q;                             // slot 0..11 of the position
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, apc[pi][PA[q]]), bfr[j][n][PB[q]], c, 0, 0, 0);
+                // VD_S64_ILV: the two cout tiles alternate, so that consecutive MFMAs never share an accumulator
+                const int n = VD_S64_ILV ? (k & 1) : k / 6, q = VD_S64_ILV ? (k >> 1) : k % 6;
+                cc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, apc[pi][PA[q]]), bfr[j][n][PB[q]], cc[n], 0, 0, 0);
                 // split of position p+1: pairs at slots (0,1) (3,4) (6,7) (9,10)
                 if (!(VD_S64_SKIP & 1) && k % 3 != 2) s_split(pi ^ 1, k / 3, k % 3);
                 // transform unit at slots 2, 5, 8, 11
@@ -250,8 +253,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
                 if (!(VD_S64_SKIP & 4) && k == 3) v_read(pi, rm, rj);
                 // weights of the next chunk: each fragment right after its last use (second M-tile only)
                 if (!(VD_S64_SKIP & 2) && m == 1) {
-                    if (n == 1 && q < 3) b_load_one(n1, j, 0, q);
-                    if (n == 0 && q >= 3 && j > 0) b_load_one(n1, j - 1, 1, q - 3);
+                    if (VD_S64_ILV) {
+                        if (k == 2 || k == 3) b_load_one(n1, j, k - 2, 2);
+                        if (k == 8 || k == 9) b_load_one(n1, j, k - 8, 1);
+                        if (k < 2 && j > 0) b_load_one(n1, j - 1, k, 0);
+                    } else {
+                        if (n == 1 && q < 3) b_load_one(n1, j, 0, q);
+                        if (n == 0 && q >= 3 && j > 0) b_load_one(n1, j - 1, 1, q - 3);
+                    }
                 }
                 // patch: raw[chunk+2] by LDS-DMA into the buffer of raw[chunk] (free since this group's barrier), one request
                 // every other slot of positions 2,3 of (chunk, 0); it has a whole chunk to land (read from (chunk+1, 0) 2,3 on)
@@ -261,11 +270,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            acc[m][j][n] = c;
         }
+        acc[m][j][0] = cc[0]; acc[m][j][1] = cc[1];
         if (!(VD_S64_SKIP & 2) && m == 1 && j == 3) {
+            if (VD_S64_ILV) { b_load_one(n1, 3, 0, 0); b_load_one(n1, 3, 1, 0); }
+            else {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b_load_one(n1, 3, 1, p);
+                for (int p = 0; p < 3; ++p) b_load_one(n1, 3, 1, p);
+            }
         }
         if (j == 1) {
             // the patch requested in (chunk-1, 0) must have landed: only the 24 weight loads of (chunk-1, 1) are younger
