@@ -34,7 +34,10 @@ namespace vd {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-struct WinoS64Geom { int TF, tiles_x, tiles_y, nbx, nitems; };   // nbx = tiles_x*tiles_y*frame groups, nitems = nbx * Cout/64
+// nbx = tiles_x*tiles_y*frame groups, ncb = Cout/64, nitems = nbx*ncb.  cob_inner: the cout blocks of one tile block run on
+// blocks 8 apart (same XCD, same L2) at the same time, so the input is read from HBM once instead of ncb times; chosen
+// when the whole layer's weights fit an XCD's L2 next to it (launch_conv_wino_s64)
+struct WinoS64Geom { int TF, tiles_x, tiles_y, nbx, ncb, nitems, cob_inner; };
 
 #ifdef VD_WINO_TIMING
 __device__ unsigned long long g_s64_stamp[10];
@@ -93,8 +96,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
     struct Item { int bxx, byy, f0, cob0, ox0, oy0; };
     auto decode = [&](int it) {
         Item r;
-        int bx = it % g.nbx;
-        r.cob0 = (it / g.nbx) * 2;
+        int bx = it % g.nbx, cb = it / g.nbx;                         // tile block fastest: concurrent items share one cout block's weights
+        if (g.cob_inner) {                                            // (nbx % 8 == 0) items it, it+8, .., it+8*(ncb-1): one tile block, all cout blocks
+            const int grp = it / (8 * g.ncb), rem = it - grp * (8 * g.ncb);
+            bx = grp * 8 + (rem & 7); cb = rem >> 3;
+        }
+        r.cob0 = cb * 2;
         r.bxx = bx % g.tiles_x; bx /= g.tiles_x;
         r.byy = bx % g.tiles_y; bx /= g.tiles_y;
         r.f0 = bx * (TF4 ? 4 : 1);
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
         const int itn = it + (int)gridDim.x < g.nitems ? it + (int)gridDim.x : it;   // no next item: its own again (unused)
         // weights of chunk 0: requested here, not under the previous item's output transform -- 96 live registers there
         // made the compiler spill; they come from L2
-        bsb = (wi * 4 * ncoblk + (it / g.nbx) * 2) * 3072;
+        bsb = (wi * 4 * ncoblk + decode(it).cob0) * 3072;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -491,7 +498,11 @@ int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s) {
     }
     const int fgroups = (a.nfr + g.TF - 1) / g.TF;
     g.nbx = g.tiles_x * g.tiles_y * fgroups;
-    g.nitems = g.nbx * (a.Cout / 64);
+    g.ncb = a.Cout / 64;
+    g.nitems = g.nbx * g.ncb;
+    // weights of the whole layer (96 bytes per (cin, cout)) next to the streaming input in a 4 MB L2
+    static const bool no_inner = getenv("VD_S64_NO_COB_INNER") != nullptr;      // A/B switch
+    g.cob_inner = !no_inner && g.ncb > 1 && g.nbx % 8 == 0 && (size_t)a.Cin * a.Cout * 96 <= (size_t)(getenv("VD_S64_COB_MB") ? atoi(getenv("VD_S64_COB_MB")) : 3) << 20;
     static int ncu = 0;                               // one block per CU (512 registers per lane, > 110 KB of LDS): a persistent grid
     if (!ncu) {
         int dev = 0;
