@@ -498,13 +498,14 @@ def pack_wino_split(w, s64=False):
 @pytest.mark.parametrize("s64", [False, True])
 @pytest.mark.parametrize("N,Cin,Cout,H,ups", [(3, 64, 128, 16, 0), (5, 32, 64, 8, 0), (2, 96, 160, 32, 0), (9, 64, 32, 8, 0),
                                                (1, 128, 64, 64, 0), (2, 64, 64, 8, 1), (6, 160, 192, 8, 0), (41, 32, 128, 32, 0),
-                                               (37, 64, 256, 16, 0), (1100, 32, 64, 8, 0)])
+                                               (37, 64, 256, 16, 0), (1100, 32, 64, 8, 0), (8, 64, 128, 32, 0), (64, 32, 128, 32, 0)])
 def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups, s64):
     """csrc/conv_wino_split.hip: Winograd F(2x2,3x3) with the element products as six bf16 piece products of exactly
     split fp32 operands.  Held to the op tolerance against torch fp32, required to be no further from an fp64 conv than
     the fp32-MFMA Winograd kernel, and its GroupNorm partial sums checked against the stored output.  The last three
     shapes have more work items than the GPU has CUs: conv_wino_s64.hip walks them with a persistent grid and requests
-    the next item's first patches under the tail of the current one."""
+    the next item's first patches under the tail of the current one; the last two also take its cout-inner item order
+    (tile blocks a multiple of 8, more than one cout block, weights that fit an L2)."""
     if s64 and Cout % 64:
         pytest.skip("conv_wino_s64.hip owns 64 couts per block")
     L = _lib.lib()
