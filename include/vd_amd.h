@@ -6,7 +6,10 @@
  * arguments are DEVICE pointers owned by the caller unless the name says `host`; `stream` is a
  * hipStream_t passed as void*.  Every function returns 0 on success or a negative code
  * (-1 bad argument / unsupported configuration, -2 HIP runtime error); text via vd_last_error().
- * No entry point synchronises the stream except vd_load_weight (a blocking H2D copy).
+ * No entry point synchronises the stream except vd_load_weight (a blocking H2D copy) and vd_device_errors.
+ * Contract: ONE device per process (the reference launches one process per GPU, command_launchers.py:32-62) and one
+ * stream at a time per engine: kernel attributes are cached process-wide and an engine owns a single workspace.
+ * vd_set_weight_storage binds the process to the current device and refuses a second one.
  */
 #ifndef VD_AMD_H
 #define VD_AMD_H
@@ -48,15 +51,23 @@ void vd_destroy(vd_engine* e);
 int vd_param_count(vd_engine* e);
 int vd_param_info(vd_engine* e, int index, char* name, int name_cap, int* ndim, long long shape[4]);
 
-/* model.load_state_dict(sd) (scripts/video_sample.py:565).  Weights live in ONE packed device buffer
- * (engine layout: conv OIHW -> [tap][O][I], spatial_encoding -> [HW][C]) so that a single RCCL
- * broadcast replaces dist_util.sync_params' per-tensor broadcasts (dist_util.py:139-143).
+/* model.load_state_dict(sd) (scripts/video_sample.py:565).  Weights live in ONE packed device buffer in kernel-ready
+ * layouts chosen at load time (default arithmetic: 3x3 stride-1 convs as the Winograd image U = G g G^T split into three
+ * bf16 planes [I/16][16][O/32][3][64][8]; linear / 1x1 / stem / stride-2 convs as split MFMA fragments
+ * [K/16][N/32][3][64][8]; spatial_encoding -> [HW][C]) so that a single RCCL broadcast replaces
+ * dist_util.sync_params' per-tensor broadcasts (dist_util.py:139-143).  The layout depends on VD_MATH / VD_CONV_SPLIT /
+ * VD_CONV: vd_weights_layout_id() identifies it, and ranks compare it before accepting a broadcast buffer.
  * The buffer is caller-owned (e.g. a torch tensor) and must outlive the engine. */
 long long vd_weights_bytes(vd_engine* e);
 int vd_set_weight_storage(vd_engine* e, void* dev_buffer, long long bytes);
+/* The same packed image assembled in HOST memory (no GPU needed): pack once, then ship it -- a broadcast, a file, one
+ * H2D copy into a buffer later given to vd_set_weight_storage followed by vd_mark_weights_loaded.  The compute entry
+ * points refuse an engine whose storage is still on the host. */
+int vd_set_weight_storage_host(vd_engine* e, void* host_buffer, long long bytes);
 int vd_load_weight(vd_engine* e, const char* name, const float* host_data, long long numel);
 int vd_weights_missing(vd_engine* e);          /* number of parameters not loaded yet */
 int vd_mark_weights_loaded(vd_engine* e);      /* after receiving the packed buffer by broadcast */
+unsigned long long vd_weights_layout_id(vd_engine* e);   /* hash of (parameter table, kinds, offsets, arithmetic mode) */
 
 /* Channels / resolution of the tensor the positional encodings are added to (unet.py:669-675,914-926). */
 int vd_pos_channels(vd_engine* e);
@@ -74,6 +85,12 @@ enum { VD_TAB_SQRT_RECIP = 0, VD_TAB_SQRT_RECIPM1, VD_TAB_COEF1, VD_TAB_COEF2, V
        VD_TAB_ACP_PREV, VD_TAB_SQRT_ACP, VD_TAB_SQRT_1M_ACP, VD_NTAB };
 int vd_set_schedule(vd_engine* e, int num_timesteps, const float* host_tab, const int* host_timestep_map,
                     float rescale);
+
+/* Timestep indices outside [0, num_timesteps) make the reference raise IndexError (_extract_into_tensor,
+ * gaussian_diffusion.py:1019-1031).  The step entry points stay asynchronous: such a batch element is written as NaN
+ * and a sticky device flag is set; this call copies the flags to the host (it SYNCHRONISES), clears them, and the host
+ * mirror raises IndexError.  bit 0: timestep index out of range. */
+int vd_device_errors(vd_engine* e, int* flags);
 
 /* Bytes of engine-owned workspace a (B, T) window needs; allocated lazily by the first call. */
 int vd_workspace_bytes(vd_engine* e, int B, int T, long long* bytes);
@@ -165,22 +182,17 @@ int vd_pack_linear_frag(const float* host_w, float* host_out, int N, int K);
  * out[m][n] = bias[n] + res[m][n] + sum_k f(a[m][k]) w[n][k], f = SiLU if act.  The engine's default for every
  * nn.Linear / 1x1 conv / the stem (environment VD_MATH=fp32 selects the plain fp32-MFMA kernels instead). */
 int vd_pack_linear_split(const float* host_w, unsigned short* host_out, int N, int K);
-/* The same arithmetic for the 3x3 convs (csrc/conv_wino_split.hip): Winograd F(2x2,3x3) whose element products run as
- * six bf16 piece products of the exactly split fp32 operands.  Weights: OIHW -> U = G g G^T (row 2 negated) split into
- * [I/16][16][O/32][3][64][8] bf16 = 48*O*I uint16.  One plain source tensor, stride 1, square power-of-two >= 8x8,
- * O % 32 == 0, I % 32 == 0; gn_part as vd_op_conv_stats (or NULL). */
-int vd_pack_conv3_wino_split(const float* host_oihw, unsigned short* host_out, int O, int I);
-int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
-                          const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
-                          void* stream);
 /* 3x3 convolutions that Winograd does not cover (the stride-2 Downsample convs, unet.py:98) on the same six-product
  * arithmetic: the split GEMM kernel walks an implicit im2col operand (k = tap*I + c; taps outside the image read 0).
  * Weights: OIHW -> split fragment image of the [O][9*I] matrix = 27*O*I uint16.  stride 1 or 2, padding 1. */
 int vd_pack_conv3_split(const float* host_oihw, unsigned short* host_out, int O, int I);
 int vd_op_conv_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int stride, const void* w_split, const float* bias,
                      const float* res, float* out, int Cout, void* stream);
-/* The same arithmetic with 64 couts per block and the input transform done once per block (csrc/conv_wino_s64.hip): its
- * own weight image (row 3 of U negated), same size and argument meaning as the two functions above; O % 64 == 0. */
+/* The same arithmetic for the 3x3 stride-1 convs (csrc/conv_wino_s64.hip): Winograd F(2x2,3x3) whose element products
+ * run as six bf16 piece products of the exactly split fp32 operands, 64 couts per block, the input transform done once
+ * per block.  Weights: OIHW -> U = G g G^T (fp64, row 3 negated) split into [I/16][16][O/32][3][64][8] bf16 = 48*O*I
+ * uint16.  One plain source tensor, stride 1, square power-of-two >= 8x8, O % 64 == 0, I % 32 == 0; gn_part as
+ * vd_op_conv_stats (or NULL). */
 int vd_pack_conv3_wino_s64(const float* host_oihw, unsigned short* host_out, int O, int I);
 int vd_op_conv_wino_s64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
                         const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,

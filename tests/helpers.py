@@ -38,11 +38,6 @@ def synth_sd(specs):
     return {n: torch.from_numpy(vda.weights_init.synth_param(n, s)) for n, s in specs}
 
 
-def specs_from_oracle(cfg):
-    """(name, shape) list derived from the golden param_specs (no reference needed)."""
-    raise NotImplementedError
-
-
 def close(a, b, atol=ATOL, rtol=RTOL):
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)

@@ -34,6 +34,9 @@ class _FakeModel:
     def mark_weights_received(self):
         self.received = True
 
+    def weights_layout_id(self):
+        return 42
+
 
 def _worker(rank, world, port, out):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
@@ -73,6 +76,73 @@ def test_two_rank_sharding_and_weight_broadcast():
     assert [r[1] for r in res] == [2.0, 2.0] and [r[2] for r in res] == [20.0, 20.0]
     assert res[0][3] == [0, 2, 4, 6] and res[1][3] == [1, 3, 5]
     assert sorted(res[0][3] + res[1][3]) == list(range(7))   # a partition: nothing dropped, nothing doubled
+
+
+def _tiny_model():
+    import video_diffusion_amd as vda
+    cfg = vda.video_model_and_diffusion_defaults()
+    cfg.update(T=4, image_size=32, num_channels=32, num_res_blocks=1, rp_alpha=4, rp_beta=4, rp_gamma=4, timestep_respacing="ddim5")
+    model, _ = vda.create_video_model_and_diffusion(**cfg)
+    return vda, model
+
+
+def _engine_worker(rank, world, port, out, env):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), **env.get(rank, {}))
+    vdist.init(backend="gloo")
+    vda, model = _tiny_model()
+    specs = model.param_specs()
+
+    def make_sd():
+        return {k: torch.from_numpy(vda.weights_init.synth_param(k, s)) for k, s in specs}
+
+    try:
+        vdist.share_weights(model, make_sd, rank)          # the REAL packer -> one broadcast -> mark_weights_received
+    except RuntimeError as e:
+        out.put((rank, "error", str(e)[:80]))
+        dist.destroy_process_group()
+        return
+    got = model.packed_weights().clone()
+    # what this rank would have packed by itself from the same checkpoint: the broadcast payload (bf16 bit patterns
+    # carried in an fp32 tensor) must arrive byte for byte
+    _, own = _tiny_model()
+    own.load_state_dict(make_sd())
+    want = own.pack_on_host()
+    from video_diffusion_amd import _lib
+    missing = _lib.lib().vd_weights_missing(model._handle)
+    out.put((rank, "ok", bool(torch.equal(got.view(torch.int32), want.view(torch.int32))), int(got.numel()), missing,
+             int(got.view(torch.int32).ne(0).sum())))
+    dist.destroy_process_group()
+
+
+def _run_engine_ranks(env):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q, env)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_real_packed_weights_broadcast_is_byte_exact():
+    """The engine's own packed image (kernel-ready layouts: bf16 piece planes inside an fp32 buffer) built on rank 0 by
+    the C ABI's packer in host memory, broadcast once over gloo, marked received on rank 1: bit-identical to what rank 1
+    packs by itself, nothing missing afterwards."""
+    res = _run_engine_ranks({})
+    for rank, status, same, numel, missing, nonzero in res:
+        assert status == "ok" and same and missing == 0 and numel > 2_000_000 and nonzero > numel // 2, res
+
+
+def test_layout_mismatch_between_ranks_is_refused():
+    """a rank whose environment selects another arithmetic mode lays the buffer out differently; it must not
+    accept rank 0's bytes."""
+    res = _run_engine_ranks({1: {"VD_MATH": "fp32"}})
+    assert [r[1] for r in res] == ["error", "error"] and all("layout" in r[2] for r in res), res
 
 
 def test_task_to_indices_mapping():

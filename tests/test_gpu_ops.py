@@ -455,7 +455,7 @@ def pack_lin_split(w):
 
 @pytest.mark.parametrize("M,K,N,act,res", [(128, 128, 512, 0, 0), (4099, 96, 288, 0, 1), (300, 1024, 64, 1, 0),
                                            (2048, 384, 384, 0, 1), (70, 64, 128, 1, 1),
-                                           # large enough for gemm_wave.hip (VD_GEMM_WAVE=1: one wave per 128 x 32*NT tile; NT = 3, 4, 2)
+                                           # many-tile shapes (128x128 / 64x128 tile classes, ragged M)
                                            (8192, 64, 1536, 0, 1), (8135, 96, 1536, 0, 0), (8192, 128, 1536, 1, 0),
                                            (32768, 64, 512, 0, 1), (65536, 32, 320, 0, 0)])
 def test_linear_split_bf16x6_is_fp32_accurate(M, K, N, act, res):
@@ -487,27 +487,25 @@ def test_linear_split_bf16x6_is_fp32_accurate(M, K, N, act, res):
         assert e_split.mean() <= 1.5 * e_fp32.mean() + 1e-8, (e_split.mean(), e_fp32.mean())
 
 
-def pack_wino_split(w, s64=False):
+def pack_wino_split(w):
     O, I = w.shape[:2]
     out = torch.empty(48 * O * I, dtype=torch.int16)
-    fn = _lib.lib().vd_pack_conv3_wino_s64 if s64 else _lib.lib().vd_pack_conv3_wino_split
-    _lib.check(fn(_lib.ptr(w.contiguous().float()), _lib.ptr(out), O, I))
+    _lib.check(_lib.lib().vd_pack_conv3_wino_s64(_lib.ptr(w.contiguous().float()), _lib.ptr(out), O, I))
     return out
 
 
-@pytest.mark.parametrize("s64", [False, True])
 @pytest.mark.parametrize("N,Cin,Cout,H,ups", [(3, 64, 128, 16, 0), (5, 32, 64, 8, 0), (2, 96, 160, 32, 0), (9, 64, 32, 8, 0),
                                                (1, 128, 64, 64, 0), (2, 64, 64, 8, 1), (6, 160, 192, 8, 0), (41, 32, 128, 32, 0),
                                                (37, 64, 256, 16, 0), (1100, 32, 64, 8, 0), (8, 64, 128, 32, 0), (64, 32, 128, 32, 0)])
-def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups, s64):
-    """csrc/conv_wino_split.hip: Winograd F(2x2,3x3) with the element products as six bf16 piece products of exactly
+def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups):
+    """csrc/conv_wino_s64.hip: Winograd F(2x2,3x3) with the element products as six bf16 piece products of exactly
     split fp32 operands.  Held to the op tolerance against torch fp32, required to be no further from an fp64 conv than
     the fp32-MFMA Winograd kernel, and its GroupNorm partial sums checked against the stored output.  The last three
     shapes have more work items than the GPU has CUs: conv_wino_s64.hip walks them with a persistent grid and requests
     the next item's first patches under the tail of the current one; the last two also take its cout-inner item order
     (tile blocks a multiple of 8, more than one cout block, weights that fit an L2)."""
-    if s64 and Cout % 64:
-        pytest.skip("conv_wino_s64.hip owns 64 couts per block")
+    if Cout % 64:
+        pytest.skip("conv_wino_s64.hip owns 64 couts per block (the engine sends other widths to the fragment kernels)")
     L = _lib.lib()
     x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, scale=(3.0 / (9 * Cin)) ** 0.5), rnd(Cout, scale=0.1)
     Ho = H << ups
@@ -517,8 +515,8 @@ def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups, s6
     out_s = torch.empty(N, Ho, Ho, Cout, device="cuda")
     split = L.vd_conv_stats_split(Ho)
     part = torch.full((N, split, Cout, 2), float("nan"), dtype=torch.float64, device="cuda")
-    ws = dev(pack_wino_split(w, s64))
-    _lib.check((L.vd_op_conv_wino_s64 if s64 else L.vd_op_conv_wino_split)(_lib.ptr(xd), Cin, N, H, H, ups, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(fd), Cout,
+    ws = dev(pack_wino_split(w))
+    _lib.check(L.vd_op_conv_wino_s64(_lib.ptr(xd), Cin, N, H, H, ups, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(fd), Cout,
                                        _lib.ptr(out_s), Cout, _lib.ptr(part), _lib.current_stream()))
     torch.cuda.synchronize()
     xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x

@@ -72,12 +72,12 @@ def main():
                 _lib.check(L.vd_op_linear_split(_lib.ptr(x0), nfr * H * H, Cin, _lib.ptr(ws), _lib.ptr(b), None, 0, _lib.ptr(out), Cout,
                                                 _lib.current_stream()))
             run.__name__ = "split"
-        elif (k == 3 and stride == 1 and x1 is None and not pro and Cout % 32 == 0 and Cin % 32 == 0 and H << ups >= 8
+        elif (k == 3 and stride == 1 and x1 is None and not pro and Cout % 64 == 0 and Cin % 32 == 0 and H << ups >= 8
               and os.environ.get("VD_MATH") != "fp32" and not os.environ.get("VD_NO_WINO")):
             wsp = torch.randint(-2000, 2000, (48 * Cout * Cin,), device="cuda", dtype=torch.int16)  # timing only
 
             def run():
-                _lib.check(L.vd_op_conv_wino_split(_lib.ptr(x0), Cin, nfr, H, H, ups, _lib.ptr(wsp), _lib.ptr(b), _lib.ptr(res), None, 0,
+                _lib.check(L.vd_op_conv_wino_s64(_lib.ptr(x0), Cin, nfr, H, H, ups, _lib.ptr(wsp), _lib.ptr(b), _lib.ptr(res), None, 0,
                                                    _lib.ptr(out), Cout, None, _lib.current_stream()))
         else:
             run = None

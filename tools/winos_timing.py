@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Phase timing of conv3x3_wino_split_kernel (block 0, wave 0) from shader-clock stamps; needs a library built with
--DVD_WINO_TIMING (VD_LIB=... python tools/winos_timing.py).  Cycles: prologue / main loop / output transform."""
+"""Phase timing of conv3x3_wino_s64_kernel (block 0, wave 0) from shader-clock stamps; needs a library built with
+-DVD_WINO_TIMING (VD_HIPCC_FLAGS=-DVD_WINO_TIMING, or VD_LIB=... python tools/winos_timing.py).
+Cycles: prologue / main loop / output transform."""
 import ctypes
 import os
 import sys
@@ -12,9 +13,9 @@ from video_diffusion_amd import _lib  # noqa: E402
 
 SHAPES = [(128, 128, 128, 64), (128, 256, 256, 32), (128, 640, 256, 32), (128, 384, 384, 16), (128, 512, 512, 8), (128, 1024, 512, 8)]
 L = _lib.lib()
-S64 = "--s64" in sys.argv                      # conv_wino_s64.hip (64 couts per block) instead of conv_wino_split.hip
-stamps = L.vd_debug_s64_stamps if S64 else L.vd_debug_winos_stamps
-op = L.vd_op_conv_wino_s64 if S64 else L.vd_op_conv_wino_split
+S64 = True
+stamps = L.vd_debug_s64_stamps
+op = L.vd_op_conv_wino_s64
 stamps.restype = ctypes.c_int
 stamps.argtypes = [ctypes.c_void_p]
 for nfr, Cin, Cout, H in SHAPES:

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libvdamd.so")
-SOURCES = ["igemm.hip", "conv_halo.hip", "conv_wino.hip", "conv_wino_split.hip", "conv_wino_s64.hip", "gemm_frag.hip", "gemm_split.hip", "gemm_wave.hip", "norm.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "conv_halo.hip", "conv_wino.hip", "conv_wino_s64.hip", "gemm_frag.hip", "gemm_split.hip", "norm.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vd_amd.h")
 
 
@@ -22,27 +22,52 @@ def _stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def _needs(obj, deps):
+    return not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps if os.path.exists(d))
+
+
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> in-tree libvdamd.so (cross-compiles without a GPU).
-    One process per GPU may get here at once (torchrun): the build is serialised by a lock file and written under a
-    per-process name, so a rank either builds or waits and then finds the library fresh."""
+    """hipcc --offload-arch=gfx950 -> in-tree libvdamd.so (cross-compiles without a GPU): one object per source
+    (csrc/.obj/, compiled in parallel, rebuilt only when the source or a header is newer), then one link.
+    One process per GPU may get here at once (torchrun): the build is serialised by a lock file and the library is
+    written under a per-process name, so a rank either builds or waits and then finds the library fresh."""
     if not force and not _stale():
         return SO_PATH
     import fcntl
+    from concurrent.futures import ThreadPoolExecutor
     with open(SO_PATH + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and not _stale():
                 return SO_PATH
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            objdir = os.path.join(_CSRC, ".obj")
+            os.makedirs(objdir, exist_ok=True)
+            hdrs = [os.path.join(_CSRC, "vd_common.h"), HEADER]
+            flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + \
+                os.environ.get("VD_HIPCC_FLAGS", "").split()
+
+            def compile_one(src):
+                obj = os.path.join(objdir, src.replace(".hip", ".o"))
+                path = os.path.join(_CSRC, src)
+                if force or _needs(obj, [path] + hdrs):
+                    cmd = [hipcc, *flags, "-c", path, "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd), flush=True)
+                    r = subprocess.run(cmd, capture_output=True, text=True)
+                    if r.returncode != 0:
+                        raise RuntimeError(f"hipcc failed on {src}:\n" + r.stdout + r.stderr)
+                return obj
+
+            with ThreadPoolExecutor(max_workers=min(8, len(SOURCES), os.cpu_count() or 1)) as pool:
+                objs = list(pool.map(compile_one, SOURCES))
             tmp = f"{SO_PATH}.{os.getpid()}.tmp"
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-                   *[os.path.join(_CSRC, s) for s in SOURCES], "-o", tmp]
+            cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", tmp]
             if verbose:
-                print(" ".join(cmd))
+                print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
-                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+                raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
             os.replace(tmp, SO_PATH)
             return SO_PATH
         finally:
@@ -75,9 +100,12 @@ SIGNATURES = {
     "vd_param_info": (_I, [_P, _I, ctypes.c_char_p, _I, ctypes.POINTER(_I), ctypes.POINTER(_L)]),
     "vd_weights_bytes": (_L, [_P]),
     "vd_set_weight_storage": (_I, [_P, _P, _L]),
+    "vd_set_weight_storage_host": (_I, [_P, _P, _L]),
     "vd_load_weight": (_I, [_P, ctypes.c_char_p, _P, _L]),
     "vd_weights_missing": (_I, [_P]),
     "vd_mark_weights_loaded": (_I, [_P]),
+    "vd_weights_layout_id": (_U, [_P]),
+    "vd_device_errors": (_I, [_P, ctypes.POINTER(_I)]),
     "vd_pos_channels": (_I, [_P]),
     "vd_pos_resolution": (_I, [_P]),
     "vd_set_freqs": (_I, [_P, _P, _I, _P, _I]),
@@ -101,10 +129,8 @@ SIGNATURES = {
     "vd_pack_conv3_frag": (_I, [_P, _P, _I, _I]),
     "vd_pack_linear_frag": (_I, [_P, _P, _I, _I]),
     "vd_pack_linear_split": (_I, [_P, _P, _I, _I]),
-    "vd_pack_conv3_wino_split": (_I, [_P, _P, _I, _I]),
     "vd_pack_conv3_wino_s64": (_I, [_P, _P, _I, _I]),
     "vd_op_conv_wino_s64": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
-    "vd_op_conv_wino_split": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "vd_pack_conv3_split": (_I, [_P, _P, _I, _I]),
     "vd_op_conv_split": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "vd_op_linear_split": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _I, _P]),

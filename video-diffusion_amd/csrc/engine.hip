@@ -96,17 +96,26 @@ struct Arena {
 enum ProfClass { PC_IGEMM_128x128 = 0, PC_IGEMM_128x64, PC_IGEMM_64x128, PC_IGEMM_64x64, PC_GN_STATS, PC_GN_TEMPORAL,
                  PC_ATTN_SPATIAL, PC_ATTN_TEMPORAL, PC_OUT_CONV, PC_ELEMENTWISE, PC_POSTERIOR,
                  PC_CONV_128x128, PC_CONV_128x64, PC_CONV_64x128, PC_CONV_64x64, PC_CONV_WINO, PC_COUNT };
-static const char* kProfNames[PC_COUNT] = {"igemm_kernel<128,128>", "igemm_kernel<128,64>", "igemm_kernel<64,128>",
-                                           "igemm_kernel<64,64>", "gn_stats", "gn_temporal", "attn_spatial",
-                                           "attn_temporal", "out_conv", "elementwise", "posterior",
-                                           "conv3x3_frag_kernel<128,128>", "conv3x3_frag_kernel<128,64>",
-                                           "conv3x3_frag_kernel<64,128>", "conv3x3_frag_kernel<64,64>", "conv3x3_wino_kernel"};
+// names of the kernels a class runs on: [0] default arithmetic (bf16x6 split), [1] VD_MATH=fp32 / VD_CONV_SPLIT=0
+static const char* kProfNames[PC_COUNT][2] = {
+    {"gemm_split_kernel<128,128>", "gemm_frag_kernel<128,128>"}, {"gemm_split_kernel<128,64>", "gemm_frag_kernel<128,64>"},
+    {"gemm_split_kernel<64,128>", "gemm_frag_kernel<64,128>"}, {"gemm_split_kernel<64,64>", "gemm_frag_kernel<64,64>"},
+    {"gn_stats_partial", "gn_stats_partial"}, {"gn_temporal_kernel", "gn_temporal_kernel"},
+    {"attn_spatial_kernel", "attn_spatial_kernel"}, {"attn_temporal_kernel", "attn_temporal_kernel"},
+    {"out_conv_kernel", "out_conv_kernel"}, {"affine_act_kernel", "affine_act_kernel"}, {"posterior_kernel", "posterior_kernel"},
+    {"conv3x3_frag_kernel<128,128>", "conv3x3_frag_kernel<128,128>"}, {"conv3x3_frag_kernel<128,64>", "conv3x3_frag_kernel<128,64>"},
+    {"conv3x3_frag_kernel<64,128>", "conv3x3_frag_kernel<64,128>"}, {"conv3x3_frag_kernel<64,64>", "conv3x3_frag_kernel<64,64>"},
+    {"conv3x3_wino_s64_kernel", "conv3x3_wino_kernel"}};
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; char tag[56]; };
 struct Profiler {
     bool on = false;
     std::vector<ProfRec> recs;
 };
 static Profiler g_prof;
+static const char* prof_name(int i) {
+    if (i < 0 || i >= PC_COUNT) return "";
+    return kProfNames[i][i == PC_CONV_WINO ? !split_conv() : !split_math()];
+}
 
 struct ProfScope {
     hipStream_t st; bool live;
@@ -126,9 +135,12 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     const double in_pix = (double)g.nfr * g.Hs * g.Ws;
     const double nz = g.zcount > 1 ? g.zcount : 1;
     const double bytes = nz * 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout);
-    const bool wino = conv_wino_supported(g) || conv_wino_split_supported(g) || conv_wino_s64_supported(g);
+    IgemmArgs one = g;                         // a big window goes out as several launches over frame ranges (igemm.hip)
+    one.nfr = std::max(1, std::min(g.nfr, igemm_frames_per_launch(g)));
+    one.M = one.nfr * g.Ho * g.Wo;
+    const bool wino = conv_wino_supported(one) || conv_wino_s64_supported(one);
     const int cls = wino ? (int)PC_CONV_WINO
-                                           : igemm_tile_class(g.M, g.Cout) + (conv_halo_supported(g) ? (int)PC_CONV_128x128 : 0);
+                         : igemm_tile_class(one.M, g.Cout) + (conv_halo_supported(one) ? (int)PC_CONV_128x128 : 0);
     char tag[56];
     snprintf(tag, sizeof(tag), "M=%d N=%d K=%d k%d s%d%s%s%s", g.M, g.Cout, g.Cin, g.ksz, g.stride, g.ups ? " ups" : "",
              g.affA ? " pro" : (g.act ? " act" : ""), g.res ? " res" : "");
@@ -172,13 +184,23 @@ struct vd_engine {
     int film_total = 0, te_total = 0;
     size_t packed_total = 0;
     float* wbuf = nullptr;           // caller-owned packed weights
+    bool wbuf_on_host = false;       // vd_set_weight_storage_host: the packed image is assembled in host memory
+    int put(void* dst, const void* src, size_t bytes) {
+        if (wbuf_on_host) { std::memcpy(dst, src, bytes); return 0; }
+        VD_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        return 0;
+    }
     // small device tables
     float* d_freq_time = nullptr; int n_freq_time = 0;
     float* d_freq_frame = nullptr; int n_freq_frame = 0;
     float* d_tab = nullptr; int num_timesteps = 0;
     float* d_tmap = nullptr; float rescale = 1.f;
-    // workspace
+    // workspace: activations of one (B, T) window [0, ws_tail), then t_model [B] and the eps scratch
     char* ws = nullptr; size_t ws_cap = 0;
+    int ws_B = 0, ws_T = 0; size_t ws_tail = 0;      // the window shape ws_tail was computed for (dry run of the topology)
+    std::unordered_map<long long, size_t> ws_peaks;  // (B << 32 | T) -> arena peak
+    int* d_err = nullptr;                            // sticky device flags: bit 0 = timestep index out of range
+    int device = -1;
 
     ~vd_engine() {
         if (d_freq_time) (void)hipFree(d_freq_time);
@@ -186,6 +208,7 @@ struct vd_engine {
         if (d_tab) (void)hipFree(d_tab);
         if (d_tmap) (void)hipFree(d_tmap);
         if (ws) (void)hipFree(ws);
+        if (d_err) (void)hipFree(d_err);
     }
 
     const float* W(int p) const { return wbuf + params[p].off; }
@@ -687,17 +710,26 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
 }
 
 int vd_engine::ensure_ws(int B, int T) {
-    Arena dry; dry.dry = true;
-    FwdIn fi{}; fi.B = B; fi.T = T;
-    int rc = forward(fi, nullptr, dry);
-    if (rc) return rc;
-    const size_t need = dry.peak + (size_t)B * T * 3 * cfg.image_size * cfg.image_size * sizeof(float) + 4096;
+    if (B == ws_B && T == ws_T && ws) return 0;      // the common case: every step of a window
+    const long long key = ((long long)B << 32) | (unsigned)T;
+    auto it = ws_peaks.find(key);
+    if (it == ws_peaks.end()) {
+        Arena dry; dry.dry = true;
+        FwdIn fi{}; fi.B = B; fi.T = T;
+        int rc = forward(fi, nullptr, dry);
+        if (rc) return rc;
+        it = ws_peaks.emplace(key, dry.peak).first;
+    }
+    const size_t tail = (it->second + 255) & ~(size_t)255;
+    const size_t tm_bytes = ((size_t)B * sizeof(float) + 255) & ~(size_t)255;
+    const size_t need = tail + tm_bytes + (size_t)B * T * 3 * cfg.image_size * cfg.image_size * sizeof(float);
     if (need > ws_cap) {
         if (ws) VD_HIP(hipFree(ws));
-        ws = nullptr; ws_cap = 0;
+        ws = nullptr; ws_cap = 0; ws_B = ws_T = 0;
         VD_HIP(hipMalloc(reinterpret_cast<void**>(&ws), need));
         ws_cap = need;
     }
+    ws_B = B; ws_T = T; ws_tail = tail;
     return 0;
 }
 
@@ -736,10 +768,41 @@ int vd_param_info(vd_engine* e, int i, char* name, int cap, int* ndim, long long
 
 long long vd_weights_bytes(vd_engine* e) { return e ? (long long)(e->packed_total * sizeof(float)) : -1; }
 
+// FNV-1a over everything that decides where a parameter's bytes sit in the packed buffer and how they are encoded
+unsigned long long vd_weights_layout_id(vd_engine* e) {
+    if (!e) return 0;
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](unsigned long long v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
+    mix(split_math()); mix(split_conv()); mix(e->packed_total); mix(e->params.size());
+    for (const Param& p : e->params) {
+        for (char c : p.name) mix((unsigned char)c);
+        mix(p.kind); mix(p.off); mix(p.packed); mix(p.frag_rows); mix(p.frag_row0);
+    }
+    return h;
+}
+
+// One process drives one GPU (the reference's launcher does the same, command_launchers.py:32-62): kernel attributes and
+// CU counts are cached process-wide, an engine owns one workspace and runs its steps on one stream at a time.
+static int g_bound_device = -1;
+
 int vd_set_weight_storage(vd_engine* e, void* buf, long long bytes) {
     VD_REQUIRE(e && buf, "null argument");
     VD_REQUIRE(bytes >= (long long)(e->packed_total * sizeof(float)), "weight buffer too small");
+    int dev = -1;
+    VD_HIP(hipGetDevice(&dev));
+    if (g_bound_device < 0) g_bound_device = dev;
+    VD_REQUIRE(dev == g_bound_device, "libvdamd drives ONE device per process (one process per GPU); this process is already bound to another device");
+    e->device = dev;
+    e->wbuf_on_host = false;
     e->wbuf = static_cast<float*>(buf);
+    return 0;
+}
+
+int vd_set_weight_storage_host(vd_engine* e, void* host_buf, long long bytes) {
+    VD_REQUIRE(e && host_buf, "null argument");
+    VD_REQUIRE(bytes >= (long long)(e->packed_total * sizeof(float)), "weight buffer too small");
+    e->wbuf = static_cast<float*>(host_buf);
+    e->wbuf_on_host = true;
     return 0;
 }
 
@@ -755,6 +818,7 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
     }
     std::vector<float> tmp;
     const float* src = host;
+    int rc_put = 0;
     if (p.kind == PK_LINF && split_math()) {
         // rows [row0, row0+rows) of a [frag_rows][K] matrix -> K/16 contiguous pieces of its bf16-split fragment image
         const int rows = (int)p.shape[0], K = (int)p.shape[1];
@@ -763,7 +827,7 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
         const size_t piece = (size_t)(rows / 32) * 1536;                   // ushorts per k-step of this member
         for (int ks = 0; ks < K / 16; ++ks) {
             float* dst = e->wbuf + p.off + ((size_t)ks * (p.frag_rows / 32) + p.frag_row0 / 32) * 768;
-            VD_HIP(hipMemcpy(dst, sp.data() + ks * piece, piece * sizeof(unsigned short), hipMemcpyHostToDevice));
+            if ((rc_put = e->put(dst, sp.data() + ks * piece, piece * sizeof(unsigned short)))) return rc_put;
         }
         p.loaded = true;
         return 0;
@@ -776,7 +840,7 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
         const size_t piece = (size_t)(rows / 32) * 1024;
         for (int ch = 0; ch < K / 32; ++ch) {
             float* dst = e->wbuf + p.off + ((size_t)ch * (p.frag_rows / 32) + p.frag_row0 / 32) * 1024;
-            VD_HIP(hipMemcpy(dst, tmp.data() + ch * piece, piece * sizeof(float), hipMemcpyHostToDevice));
+            if ((rc_put = e->put(dst, tmp.data() + ch * piece, piece * sizeof(float)))) return rc_put;
         }
         p.loaded = true;
         return 0;
@@ -825,7 +889,7 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
             for (int q = 0; q < HW; ++q) tmp[(size_t)q * C + c] = host[(size_t)c * HW + q];
         src = tmp.data();
     }
-    VD_HIP(hipMemcpy(e->wbuf + p.off, src, p.packed * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc_put = e->put(e->wbuf + p.off, src, p.packed * sizeof(float)))) return rc_put;
     p.loaded = true;
     return 0;
 }
@@ -873,6 +937,19 @@ int vd_set_schedule(vd_engine* e, int nts, const float* tab, const int* tmap, fl
     VD_HIP(hipMemcpy(e->d_tmap, tm.data(), nts * sizeof(float), hipMemcpyHostToDevice));
     e->num_timesteps = nts;
     e->rescale = rescale;
+    if (!e->d_err) {
+        VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_err), sizeof(int)));
+        VD_HIP(hipMemset(e->d_err, 0, sizeof(int)));
+    }
+    return 0;
+}
+
+int vd_device_errors(vd_engine* e, int* flags) {
+    VD_REQUIRE(e && flags, "null argument");
+    *flags = 0;
+    if (!e->d_err) return 0;
+    VD_HIP(hipMemcpy(flags, e->d_err, sizeof(int), hipMemcpyDeviceToHost));       // synchronises
+    if (*flags) VD_HIP(hipMemset(e->d_err, 0, sizeof(int)));
     return 0;
 }
 
@@ -889,7 +966,7 @@ int vd_workspace_bytes(vd_engine* e, int B, int T, long long* bytes) {
 static int check_ready(vd_engine* e, int B, int T) {
     VD_REQUIRE(e, "null engine");
     VD_REQUIRE(B > 0 && T > 0 && T <= 32, "window of 1..32 frames");
-    VD_REQUIRE(e->wbuf, "weights not set");
+    VD_REQUIRE(e->wbuf && !e->wbuf_on_host, "weights not set (the packed image must live in device memory: vd_set_weight_storage)");
     int miss = vd_weights_missing(e);
     if (miss) {
         for (auto& p : e->params) if (!p.loaded) { set_error("missing key in state_dict: " + p.name + " (+" + std::to_string(miss - 1) + " more)"); break; }
@@ -911,12 +988,19 @@ int vd_unet_forward(vd_engine* e, int B, int T, const float* x, const float* obs
     return e->forward(fi, static_cast<hipStream_t>(stream), ar);
 }
 
-__global__ void map_t_kernel(const int64_t* t, const float* tmap, float rescale, int B, int nts, float* out) {
+// _WrappedModel.__call__ (respace.py:111-119): t_model = map[t] * rescale.  The reference raises IndexError for an index
+// outside the table; here the step stays asynchronous: the network is fed NaN, the posterior kernel writes NaN for that
+// batch element (misc.hip) and bit 0 of the engine's sticky error word is set for vd_device_errors().
+__global__ void map_t_kernel(const int64_t* t, const float* tmap, float rescale, int B, int nts, float* out, int* err) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
-        long long i = t[b];
-        i = i < 0 ? 0 : (i >= nts ? nts - 1 : i);
-        out[b] = tmap[i] * rescale;
+        const long long i = t[b];
+        if (i < 0 || i >= nts) {
+            out[b] = __builtin_nanf("");
+            atomicOr(err, 1);
+        } else {
+            out[b] = tmap[i] * rescale;
+        }
     }
 }
 
@@ -927,15 +1011,17 @@ static int sample_impl(vd_engine* e, int mode, int B, int T, const float* x, con
     int rc = check_ready(e, B, T);
     if (rc) return rc;
     VD_REQUIRE(e->d_tab, "vd_set_schedule not called");
-    VD_REQUIRE(x && t && sample, "null tensor");
+    VD_REQUIRE(x && obs_src && obs && lat && km && fidx && t && sample, "null tensor");
+    VD_REQUIRE(obs_mode >= 0 && obs_mode <= 2, "observed_frames must be x_0 / x_t / x_t_minus_1");
+    VD_REQUIRE(mode == 0 || eta >= 0.f, "eta");
     if ((rc = e->ensure_ws(B, T))) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t per = (size_t)T * 3 * e->cfg.image_size * e->cfg.image_size;
-    // tail of the workspace: t_model [B] + eps scratch
-    float* tm = reinterpret_cast<float*>(e->ws + e->ws_cap - 4096);
-    float* eps = eps_out ? eps_out : reinterpret_cast<float*>(e->ws + e->ws_cap - 4096 - B * per * sizeof(float));
+    // tail of the workspace: t_model [B] + eps scratch (sized by ensure_ws for this B)
+    float* tm = reinterpret_cast<float*>(e->ws + e->ws_tail);
+    float* eps = eps_out ? eps_out : reinterpret_cast<float*>(e->ws + e->ws_tail + (((size_t)B * sizeof(float) + 255) & ~(size_t)255));
     hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(t), e->d_tmap,
-                       e->rescale, B, e->num_timesteps, tm);
+                       e->rescale, B, e->num_timesteps, tm, e->d_err);
     Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
     FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
     if ((rc = e->forward(fi, st, ar))) return rc;
@@ -1009,26 +1095,6 @@ int vd_op_conv_wino_s64(const float* src0, int Cin, int nfr, int Hs, int Ws, int
     return launch_igemm(g, static_cast<hipStream_t>(stream));
 }
 
-int vd_pack_conv3_wino_split(const float* host_oihw, unsigned short* host_out, int O, int I) {
-    VD_REQUIRE(host_oihw && host_out && O % 32 == 0 && I % 32 == 0, "vd_pack_conv3_wino_split: O, I multiples of 32");
-    pack_conv3_wino_split(host_oihw, host_out, O, I);
-    return 0;
-}
-
-int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
-                          const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
-                          void* stream) {
-    IgemmArgs g{};
-    g.src0 = src0; g.C0 = Cin; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws; g.ups = ups;
-    g.stride = 1; g.pad = 1; g.ksz = 3;
-    g.Ho = Hs << ups; g.Wo = Ws << ups;
-    g.wwino = static_cast<const float*>(w_split); g.wsplit = 1; g.bias = bias; g.res = res; g.res_ld = Cout;
-    g.fbias = fbias; g.fbias_ld = fbias_ld; g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
-    g.stats = gn_part; g.stats_split = conv_wino_stats_split(g.Ho);
-    VD_REQUIRE(conv_wino_split_supported(g), "vd_op_conv_wino_split: shape not covered by the kernel");
-    return launch_igemm(g, static_cast<hipStream_t>(stream));
-}
-
 int vd_pack_conv3_split(const float* host_oihw, unsigned short* host_out, int O, int I) {
     VD_REQUIRE(host_oihw && host_out && O % 32 == 0 && I % 32 == 0, "vd_pack_conv3_split: O, I multiples of 32");
     pack_conv3_split(host_oihw, host_out, O, I);
@@ -1091,7 +1157,7 @@ int vd_profile_end(double* out, int cap) {
         VD_HIP(hipEventElapsedTime(&ms, r.a, r.b));
         out[r.cls * 4 + 0] += 1.0; out[r.cls * 4 + 1] += ms; out[r.cls * 4 + 2] += r.flops; out[r.cls * 4 + 3] += r.bytes;
         if (getenv("VD_PROF_DUMP"))                    // per-launch listing for kernel work (tools/)
-            fprintf(stderr, "[vd_prof] %-28s %-40s %8.1f us %7.1f TFLOP/s\n", kProfNames[r.cls], r.tag, ms * 1e3,
+            fprintf(stderr, "[vd_prof] %-28s %-40s %8.1f us %7.1f TFLOP/s\n", prof_name(r.cls), r.tag, ms * 1e3,
                     ms > 0 ? r.flops / ms / 1e9 : 0.0);
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
@@ -1100,10 +1166,7 @@ int vd_profile_end(double* out, int cap) {
 }
 
 int vd_profile_classes(void) { return PC_COUNT; }
-const char* vd_profile_class_name(int i) {
-    if (i == PC_CONV_WINO && split_conv()) return "conv3x3_wino_s64_kernel";      // the kernel that class runs on
-    return i >= 0 && i < PC_COUNT ? kProfNames[i] : "";
-}
+const char* vd_profile_class_name(int i) { return prof_name(i); }
 
 // ---- single-operator entry points ---------------------------------------------------------------
 int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, int ups, int stride,

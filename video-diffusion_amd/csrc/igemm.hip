@@ -17,6 +17,8 @@
 //   Pipeline: global loads of step s+1 are issued before the MFMAs of step s (register staging:
 //   the operand transform needs VALU anyway), written to the other LDS buffer after them; one
 //   barrier per K-step.
+#include <algorithm>
+
 #include "vd_common.h"
 
 namespace vd {
@@ -196,17 +198,10 @@ static int launch_t(const IgemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-int launch_igemm(const IgemmArgs& a, hipStream_t s) {
-    VD_REQUIRE(a.Cin % BK == 0, "Cin must be a multiple of 32 (pad the operand)");
-    VD_REQUIRE(a.C0 % BK == 0 && a.C0 <= a.Cin, "concat split must be a multiple of 32");
-    VD_REQUIRE(a.src1 != nullptr || a.C0 == a.Cin, "second source missing");
-    VD_REQUIRE(a.ksz == 1 || a.ksz == 3, "kernel size 1 or 3");
-    VD_REQUIRE(a.M > 0 && a.Cout > 0, "empty problem");
-    VD_REQUIRE(a.M == a.nfr * a.Ho * a.Wo, "M != nfr*Ho*Wo");
-    if (gemm_wave_supported(a)) return launch_gemm_wave(a, s);
+// One launch: every operand of `a` is small enough for the 32-bit byte offsets the kernels address with.
+static int launch_igemm_one(const IgemmArgs& a, hipStream_t s) {
     if (gemm_split_supported(a) || conv_split_supported(a)) return launch_gemm_split(a, igemm_tile_class(a.M, a.Cout), s);
     if (conv_wino_s64_supported(a)) return launch_conv_wino_s64(a, s);
-    if (conv_wino_split_supported(a)) return launch_conv_wino_split(a, s);
     VD_REQUIRE(!a.wsplit, "bf16-split weights given for a shape the split kernels do not cover");
     if (gemm_frag_supported(a)) return launch_gemm_frag(a, igemm_tile_class(a.M, a.Cout), s);
     if (conv_wino_supported(a)) return launch_conv_wino(a, s);
@@ -222,6 +217,54 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
         case 2: return launch_t<64, 128>(a, s);
         default: return launch_t<64, 64>(a, s);
     }
+}
+
+// Frames (rows, for a linear layer) per launch.  The fast kernels reach their operands through buffer descriptors with
+// 32-bit byte offsets and bound each operand to 2^28 elements (*_supported); a window that is merely BIG -- 160 frames of
+// 128x128x128 channels, BASELINE configs[4] -- is cut along the frame dimension into equal launches with the base
+// pointers advanced.  Frames are independent in every one of these kernels (per-frame affine / bias / statistics rows
+// move with them), so the results are those of one launch, bit for bit.
+int igemm_frames_per_launch(const IgemmArgs& a) {
+    const size_t lim = ((size_t)1 << 28) - 1;
+    const size_t in_pf = (size_t)a.Hs * a.Ws * std::max(a.C0, a.Cin - a.C0);
+    const size_t out_pf = (size_t)a.Ho * a.Wo * std::max(a.ldo, a.res ? a.res_ld : 0);
+    const size_t pf = std::max(in_pf, out_pf);
+    if (pf == 0 || (size_t)a.nfr * pf <= lim || a.zcount > 1) return a.nfr;
+    const size_t align = (a.Hs == 1 && a.Ws == 1) ? 256 : 4;       // whole 128-row tiles / whole 4-frame groups (conv_wino_s64 TF4)
+    size_t maxfr = lim / pf / align * align;
+    if (maxfr == 0) return 0;
+    const size_t nl = ((size_t)a.nfr + maxfr - 1) / maxfr;
+    size_t per = ((size_t)a.nfr + nl - 1) / nl;                       // equal launches
+    per = (per + align - 1) / align * align;
+    return (int)std::min(per, maxfr);
+}
+
+int launch_igemm(const IgemmArgs& a, hipStream_t s) {
+    VD_REQUIRE(a.Cin % BK == 0, "Cin must be a multiple of 32 (pad the operand)");
+    VD_REQUIRE(a.C0 % BK == 0 && a.C0 <= a.Cin, "concat split must be a multiple of 32");
+    VD_REQUIRE(a.src1 != nullptr || a.C0 == a.Cin, "second source missing");
+    VD_REQUIRE(a.ksz == 1 || a.ksz == 3, "kernel size 1 or 3");
+    VD_REQUIRE(a.M > 0 && a.Cout > 0, "empty problem");
+    VD_REQUIRE(a.M == a.nfr * a.Ho * a.Wo, "M != nfr*Ho*Wo");
+    const int per = igemm_frames_per_launch(a);
+    VD_REQUIRE(per > 0, "one frame of this layer exceeds 2^28 elements");
+    if (per >= a.nfr) return launch_igemm_one(a, s);
+    const size_t HWi = (size_t)a.Hs * a.Ws, HWo = (size_t)a.Ho * a.Wo;
+    for (int f0 = 0; f0 < a.nfr; f0 += per) {
+        IgemmArgs b = a;
+        b.nfr = std::min(per, a.nfr - f0);
+        b.M = b.nfr * a.Ho * a.Wo;
+        b.src0 = a.src0 + (size_t)f0 * HWi * a.C0;
+        if (a.src1) b.src1 = a.src1 + (size_t)f0 * HWi * (a.Cin - a.C0);
+        if (a.res) b.res = a.res + (size_t)f0 * HWo * a.res_ld;
+        b.out = a.out + (size_t)f0 * HWo * a.ldo;
+        if (a.affA) { b.affA = a.affA + (size_t)f0 * a.Cin; b.affB = a.affB + (size_t)f0 * a.Cin; }
+        if (a.fbias) b.fbias = a.fbias + (size_t)f0 * a.fbias_ld;
+        if (a.stats) b.stats = a.stats + (size_t)f0 * a.stats_split * a.Cout * 2;
+        const int rc = launch_igemm_one(b, s);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // Tile choice: big tiles when the grid still fills 256 CUs x 2 blocks, smaller ones otherwise.

@@ -271,9 +271,15 @@ __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
     const size_t total = (size_t)a.B * a.per;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int b = (int)(i / a.per);
-        const int t = (int)a.t[b];
-        const float* tb = a.tab + t;
+        const long long tl = a.t[b];
         const int NT = a.num_timesteps;
+        if (tl < 0 || tl >= NT) {                // the reference raises IndexError (_extract_into_tensor); no table read here:
+            a.sample[i] = __builtin_nanf("");    // the element is poisoned and map_t_kernel has set the engine's error flag
+            if (a.xstart) a.xstart[i] = __builtin_nanf("");
+            continue;
+        }
+        const int t = (int)tl;
+        const float* tb = a.tab + t;
         const float x = a.x[i], e = a.eps[i];
         float x0 = tb[TAB_SQRT_RECIP * NT] * x - tb[TAB_SQRT_RECIPM1 * NT] * e;
         if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
@@ -309,6 +315,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* x0, const fl
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         long long tt = t[i / per];
         if (tt < 0) tt += NT;                   // t-1 at t=0 wraps like numpy/torch indexing (gaussian_diffusion.py:565-568)
+        if (tt < 0 || tt >= NT) { out[i] = __builtin_nanf(""); continue; }       // IndexError in the reference
         out[i] = tab[TAB_SQRT_ACP * NT + tt] * x0[i] + tab[TAB_SQRT_1M_ACP * NT + tt] * noise[i];
     }
 }

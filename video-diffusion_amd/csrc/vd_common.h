@@ -90,6 +90,7 @@ struct AttnTemporalArgs {
 };
 
 int launch_igemm(const IgemmArgs& a, hipStream_t s);
+int igemm_frames_per_launch(const IgemmArgs& a);   // frames (rows) per launch: big windows are cut along the frame dimension
 int igemm_tile_class(int M, int Cout);   // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
 // 3x3 stride-1 path with an LDS-staged, once-transformed input halo tile (conv_halo.hip)
 bool conv_halo_supported(const IgemmArgs& a);
@@ -102,12 +103,7 @@ void pack_conv3_frag(const float* oihw, float* out, int O, int I);
 // Winograd F(2x2,3x3) path (conv_wino.hip): 2.25x fewer MFMAs than the direct 3x3 kernels
 bool conv_wino_supported(const IgemmArgs& a);
 int conv_wino_stats_split(int Hout);
-// fp32-accurate Winograd conv on the bf16 matrix cores (conv_wino_split.hip); weights: [Cin/16][16][Cout/32][3][64][8] bf16
-bool conv_wino_split_supported(const IgemmArgs& a);
-int launch_conv_wino_split(const IgemmArgs& a, hipStream_t s);
-void pack_conv3_wino_split(const float* oihw, unsigned short* out, int O, int I);
-// fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
-// ---- exact three-way bf16 split of a pair of fp32 values (conv_wino_s64.hip, gemm_wave.hip), plain VALU only: v_pk_*_f32
+// ---- exact three-way bf16 split of a pair of fp32 values (conv_wino_s64.hip), plain VALU only: v_pk_*_f32
 // and v_dot2c_f32_bf16 do not overlap the bf16 MFMA (tools/mfma_bf16_coissue.hip)
 // first half: p1 = top halves (a bf16 pair), r = x - p1 (exact)
 __device__ __forceinline__ void split_a(float x0, float x1, unsigned& p1, float& r0, float& r1, unsigned sel) {
@@ -133,12 +129,11 @@ __device__ __forceinline__ void split_b(float r0, float r1, unsigned& p2, unsign
         : "v"(r0), "v"(r1), "s"(sel));
 }
 
-bool conv_wino_s64_supported(const IgemmArgs& a);        // conv_wino_s64.hip: wsplit == 2 (its own weight image)
+// fp32-accurate Winograd conv on the bf16 matrix cores (conv_wino_s64.hip); weights: [Cin/16][16][Cout/32][3][64][8] bf16
+bool conv_wino_s64_supported(const IgemmArgs& a);        // wsplit == 2
 int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino_s64(const float* oihw, unsigned short* out, int O, int I);
-bool gemm_split_supported(const IgemmArgs& a);
-bool gemm_wave_supported(const IgemmArgs& a);            // gemm_wave.hip: large plain GEMMs, one wave per 128 x 32*NT tile
-int launch_gemm_wave(const IgemmArgs& a, hipStream_t s);
+bool gemm_split_supported(const IgemmArgs& a);            // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
 bool conv_split_supported(const IgemmArgs& a);          // 3x3, stride 1|2: the same kernel over an implicit im2col A
 void pack_conv3_split(const float* w_oihw, unsigned short* out, int Cout, int Cin);
 int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s);

@@ -146,6 +146,9 @@ class GaussianDiffusion:
         model = self._bind(model)
         B = x.shape[0]
         assert t.shape == (B,)                                   # gaussian_diffusion.py:273
+        if t.device.type == "cpu" and B and (int(t.min()) < 0 or int(t.max()) >= self.num_timesteps):
+            raise IndexError(f"index {int(t.max())} is out of bounds for dimension 0 with size {self.num_timesteps}")
+        # (a device-resident t is range-checked by the kernels: NaN output + model.check_device_errors())
         dev = model.device
         xs = _f32(x, dev)
         kw = model._pack_kwargs(xs, model_kwargs)

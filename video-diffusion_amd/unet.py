@@ -126,6 +126,13 @@ class CondMargVideoModel:
             self._wbuf = th.zeros(nbytes // 4, dtype=th.float32, device=self.device)
             _lib.check(_lib.lib().vd_set_weight_storage(self._handle, _lib.ptr(self._wbuf), nbytes))
             self._upload_freqs()
+        elif self._wbuf.device.type == "cpu" and self.device.type == "cuda":
+            # a host-packed image (pack_on_host / a received broadcast): one H2D copy, nothing is re-packed
+            nbytes = _lib.lib().vd_weights_bytes(self._handle)
+            self._wbuf = self._wbuf.to(self.device)
+            _lib.check(_lib.lib().vd_set_weight_storage(self._handle, _lib.ptr(self._wbuf), nbytes))
+            self._upload_freqs()
+            self._packed_on_device = True
 
     def _upload(self):
         L = _lib.lib()
@@ -145,17 +152,18 @@ class CondMargVideoModel:
     def to(self, device):
         device = th.device(device)
         if device.type != "cuda":
-            if device.type == "cpu" and self._wbuf is None:
+            if device.type == "cpu" and (self._wbuf is None or self._wbuf.device.type == "cpu"):
                 return self
             raise RuntimeError("the HIP engine runs on a GPU only (no CPU fallback in the product path)")
         if device.index is None:
             device = th.device("cuda", th.cuda.current_device())
-        if self._wbuf is not None and self.device != device:
+        if self._wbuf is not None and self._wbuf.device.type == "cuda" and self.device != device:
             raise RuntimeError("engine weights are already resident on " + str(self.device))
         self.device = device
         with th.cuda.device(device):
+            was_host_packed = self._wbuf is not None and self._wbuf.device.type == "cpu"
             self._ensure_storage()
-            if self._host_sd is not None:
+            if self._host_sd is not None and not was_host_packed:
                 self._upload()
         return self
 
@@ -173,7 +181,7 @@ class CondMargVideoModel:
 
     def parameters(self):
         """Callers only use `next(model.parameters()).device` (video_sample.py:155)."""
-        if self._wbuf is None:
+        if self._wbuf is None or self._wbuf.device.type == "cpu":
             return iter([th.zeros(1)])
         return iter([self._wbuf])
 
@@ -183,12 +191,41 @@ class CondMargVideoModel:
         return OrderedDict(self._host_sd)
 
     def packed_weights(self):
-        """The single device buffer holding every parameter (for one RCCL broadcast)."""
+        """The single buffer holding every parameter (for one RCCL broadcast): device memory once the
+        model is on a GPU, a host image (pack_on_host) before that."""
+        if self.device.type != "cuda":
+            return self.pack_on_host()
         self._ensure_storage()
+        return self._wbuf
+
+    def pack_on_host(self):
+        """Assemble the packed image in HOST memory (a CPU tensor; needs no GPU): what rank 0 would broadcast.  The
+        model cannot compute in this state; `.to('cuda')` afterwards uploads the image in one copy."""
+        if self._wbuf is not None and self._wbuf.device.type != "cpu":
+            raise RuntimeError("weights already live on " + str(self._wbuf.device))
+        if self._wbuf is None:
+            nbytes = _lib.lib().vd_weights_bytes(self._handle)
+            self._wbuf = th.zeros(nbytes // 4, dtype=th.float32)
+            _lib.check(_lib.lib().vd_set_weight_storage_host(self._handle, _lib.ptr(self._wbuf), nbytes))
+        if self._host_sd is not None:
+            self._upload()
         return self._wbuf
 
     def mark_weights_received(self):
         _lib.check(_lib.lib().vd_mark_weights_loaded(self._handle))
+
+    def weights_layout_id(self):
+        """Identifies the packed layout (parameter table + arithmetic mode): ranks compare it before a broadcast."""
+        return int(_lib.lib().vd_weights_layout_id(self._handle))
+
+    def check_device_errors(self):
+        """Synchronise and raise what the reference would have raised eagerly: an out-of-range timestep index is an
+        IndexError in `_extract_into_tensor` (gaussian_diffusion.py:1019-1031); the asynchronous HIP step poisons the
+        output with NaN and records it in a sticky device flag instead."""
+        flags = ctypes.c_int(0)
+        _lib.check(_lib.lib().vd_device_errors(self._handle, ctypes.byref(flags)))
+        if flags.value & 1:
+            raise IndexError("timestep index out of range for the diffusion schedule (device flag set by an earlier step)")
 
     # -- forward ---------------------------------------------------------------------------------------
     def _pack_kwargs(self, x, kw):
@@ -213,7 +250,7 @@ class CondMargVideoModel:
         """model(x, timesteps, **model_kwargs) -> (eps, None)   (unet.py:949-1026)."""
         if return_attn_weights:
             raise NotImplementedError("return_attn_weights")
-        if self._wbuf is None:
+        if self._wbuf is None or self._wbuf.device.type != "cuda":
             raise RuntimeError("model.to('cuda') first: the HIP engine has no CPU path")
         B, T, C, H, W = x.shape
         assert H == self.image_size and W == self.image_size and C == 3
