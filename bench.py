@@ -1,50 +1,100 @@
 #!/usr/bin/env python3
-"""Headline benchmark: denoise-steps/sec of the HIP engine on BASELINE.json config 2.
+"""Headline benchmark: denoise-steps/sec of the HIP engine on BASELINE.json configs[1].
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+                  [--image-size 64|128 --batch B --frames T --respacing ddim250 --executor eager|graph]
 
-Workload (BASELINE.json configs[1]): default 64x64 video model (116 M parameters,
-closed-form synthetic weights: no checkpoints exist), window (B=8, T=16 = 4 observed + 12 latent,
-3x64x64), timestep_respacing='ddim250', sampler = the ancestral `p_sample` that
-scripts/video_sample.py actually calls.  One "step" = one `diffusion.p_sample` on that
-window = UNet forward + posterior update, inputs resident in HBM, noise drawn in-kernel (Philox) so
-the timed region contains nothing but the step.  N GPUs: every rank runs its own B=8 window (the
-test-set batch shard of video_sample.py:577-582; no collective inside the step) -> weak scaling;
-the weights reach ranks > 0 through ONE RCCL broadcast of the packed buffer.
+N > 1 with no WORLD_SIZE in the environment: this process starts N children (one per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set) BEFORE it touches a GPU and exits with the worst child's code; under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it is one of the ranks.
+
+Workload (BASELINE.json configs[1]): default 64x64 video model (116 M parameters, closed-form synthetic
+weights: no checkpoints exist), window (B=8, T=16 = 4 observed + 12 latent, 3x64x64), timestep_respacing='ddim250',
+sampler = the ancestral `p_sample` that scripts/video_sample.py actually calls.  One "step" = one
+`diffusion.p_sample` on that window = UNet forward + posterior update, inputs resident in HBM, noise drawn in-kernel
+(Philox) so the timed region contains nothing but the step.  N GPUs: the test-set batch shard of
+video_sample.py:577-582, no collective inside the step; `--scaling weak` (default) gives every rank its own B-clip
+window, `--scaling strong` splits ONE B-clip window into B/N clips per rank.  The weights reach ranks > 0 through ONE
+RCCL broadcast of the packed buffer.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel class (implicit-GEMM conv on fp32 MFMA): algorithmic FLOPs of its
-                launches / their HIP-event durations measured in a separate profiled step
-  cpu_baseline  the CPU oracle (torch fp32, all host cores) timed on the same window, 1 step
+  roofline      dominant kernel class: algorithmic FLOPs of its launches / their HIP-event durations, measured live in a
+                separate profiled step on the launch stream; `traffic` comes from the committed rocprofv3 PMC passes
+                (PMC cannot be read from inside the process) and says so in `traffic_source`
+  dropin        the same K steps timed through `diffusion.p_sample(model, x, t, model_kwargs=...)`, the call
+                scripts/video_sample.py:151 makes (per-step torch.randn_like, fresh output tensors, kwargs marshalling)
+  cpu_baseline  the CPU oracle (torch fp32, the node's host cores) on the same window: 1 warm-up + median of 3 steps
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-import video_diffusion_amd as vda  # noqa: E402
-from video_diffusion_amd import _lib, dist as vdist  # noqa: E402
-
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2516.6    # v_mfma_f32_32x32x16_bf16: 32 cycles per 32x32x16, 1024 SIMDs, 2.4 GHz (dense, no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
-def headline_cfg():
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--batch", type=int, default=8, help="clips per window (per GPU when weak, in total when strong)")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--obs", type=int, default=4, help="observed frames of the window")
+    ap.add_argument("--image-size", type=int, default=64)
+    ap.add_argument("--respacing", default="ddim250")
+    ap.add_argument("--num-res-blocks", type=int, default=2)
+    ap.add_argument("--executor", choices=["eager", "graph"], default="eager",
+                    help="graph: the window executor (one captured hipGraph per window shape, device-resident step counter)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32-ref", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` by itself: one child per GPU, started before this process has made any GPU call
+    (a process that has initialised the GPU must not start other programs on these boxes).  No exec: children are
+    ordinary subprocesses, rank 0's stdout is ours, and we leave with the worst return code."""
+    from video_diffusion_amd import _lib
+    _lib.build()                                  # hipcc only; the ranks then find the library fresh
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = {**os.environ, "RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    for p in procs:
+        rc = p.wait()
+        if rc != 0:
+            worst = rc if worst == 0 or abs(rc) > abs(worst) else worst
+    return worst
+
+
+def bench_cfg(vda, args):
     cfg = vda.video_model_and_diffusion_defaults()
-    cfg.update(T=16, image_size=64, rp_alpha=16, rp_beta=16, rp_gamma=16, timestep_respacing="ddim250")
+    cfg.update(T=args.frames, image_size=args.image_size, num_res_blocks=args.num_res_blocks, rp_alpha=args.frames, rp_beta=args.frames,
+               rp_gamma=args.frames, timestep_respacing=args.respacing)
     return cfg
 
 
 def make_window(B, T, S, n_obs, seed, device):
+    import torch
     g = torch.Generator().manual_seed(seed)
     video = torch.rand(B, T, 3, S, S, generator=g) * 2 - 1
     x0 = video.clone()
@@ -57,9 +107,12 @@ def make_window(B, T, S, n_obs, seed, device):
 
 
 class Stepper:
-    """The hot loop of video_sample.py:150-168 with every per-step host allocation hoisted out."""
+    """The hot loop of video_sample.py:150-168 on the C ABI with every per-step host allocation hoisted out."""
 
     def __init__(self, model, diff, kw, seed):
+        import torch
+        from video_diffusion_amd import _lib
+        self._lib = _lib
         self.model, self.diff, self.seed = diff._bind(model), diff, seed
         x = kw["x0"].clone().float().contiguous()
         self.B, self.T = x.shape[:2]
@@ -71,6 +124,7 @@ class Stepper:
         self.count = 0
 
     def step(self, t_index):
+        _lib = self._lib
         src, dst = self.bufs[self.count & 1], self.bufs[(self.count + 1) & 1]
         k = self.k
         rc = _lib.lib().vd_p_sample(self.model._handle, self.B, self.T, _lib.ptr(src), _lib.ptr(k["obs_src"]),
@@ -81,8 +135,77 @@ class Stepper:
         self.count += 1
         return dst
 
+    def result(self):
+        return self.bufs[self.count & 1]
+
+
+class DropInStepper:
+    """The reference's own call: `diffusion.p_sample(model, x, t, clip_denoised=True, model_kwargs=kw)['sample']`
+    (scripts/video_sample.py:151-168), nothing hoisted."""
+
+    def __init__(self, model, diff, kw):
+        import torch
+        self.model, self.diff = model, diff
+        self.kw = {**kw, "x_t_minus_1": kw["x0"], "observed_frames": "x_0"}
+        self.x = kw["x0"].clone()
+        self.B = self.x.shape[0]
+        self.torch = torch
+
+    def step(self, t_index):
+        t = self.torch.tensor([t_index] * self.B, device=self.x.device)
+        self.x = self.diff.p_sample(self.model, self.x, t, clip_denoised=True, model_kwargs=self.kw)["sample"]
+        return self.x
+
+    def result(self):
+        return self.x
+
+
+class GraphStepper:
+    """The window executor (vd_window_*): one hipGraph per window shape, step index and Philox counter on the device."""
+
+    def __init__(self, model, diff, kw, seed):
+        from video_diffusion_amd.executor import WindowExecutor
+        self.ex = WindowExecutor(model, diff)
+        self.kw = {**kw, "x_t_minus_1": kw["x0"], "observed_frames": "x_0"}
+        self.x = kw["x0"].clone().float().contiguous()
+        self.seed = seed
+        self.started = False
+        self.nts = diff.num_timesteps
+
+    def step(self, t_index):
+        if not self.started or t_index != self.next_t:
+            self.ex.begin(self.x, self.kw, t_start=t_index, seed=self.seed, sampler="p_sample")
+            self.started = True
+        self.ex.run(1)
+        self.next_t = t_index - 1
+        return None
+
+    def result(self):
+        return self.ex.x
+
+
+def timed(stepper, order, warmup, steps, vdist, device):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+    import torch
+    nts = len(order)
+    for i in range(warmup):
+        stepper.step(order[i % nts])
+    torch.cuda.synchronize()
+    vdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        stepper.step(order[(warmup + i) % nts])
+    torch.cuda.synchronize()
+    vdist.barrier()
+    torch.cuda.synchronize()
+    return vdist.max_over_ranks(time.perf_counter() - t0, device=device)
+
 
 def profile_step(stepper, t_index):
+    import ctypes
+    import torch
+    from video_diffusion_amd import _lib
     L = _lib.lib()
     n = L.vd_profile_classes()
     out = (ctypes.c_double * (4 * n))()
@@ -117,8 +240,10 @@ def host_cores():
     return min(n, int(os.environ.get("VD_CPU_BASELINE_CORES", "16")))
 
 
-def cpu_baseline(cfg, sd, B, T, n_obs, t_index):
-    """The oracle (a torch-CPU fp32 restatement of the reference; kind 'port') on the node's host cores."""
+def cpu_baseline(cfg, sd, B, T, n_obs, t_index, nts):
+    """The oracle (a torch-CPU fp32 restatement of the reference; kind 'port') on the node's host cores:
+    1 warm-up + the median of 3 timed steps, bounded to ~1 minute by VD_CPU_BASELINE_BUDGET_S."""
+    import torch
     from oracle.sampler_ref import SamplerRef
     from oracle.schedule_ref import ScheduleRef
     from oracle.unet_ref import UNetRef
@@ -130,53 +255,67 @@ def cpu_baseline(cfg, sd, B, T, n_obs, t_index):
     x = kw["x0"].clone()
     noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
     t = torch.tensor([t_index] * B)
-    t0 = time.perf_counter()
-    ora.p_sample(x, t, kw, noise)
-    dt = time.perf_counter() - t0
+    budget = float(os.environ.get("VD_CPU_BASELINE_BUDGET_S", "75"))
+    t_all = time.perf_counter()
+    times = []
+    for i in range(4):                                            # step 0 = warm-up (allocator, thread pool, oneDNN primitives)
+        t0 = time.perf_counter()
+        ora.p_sample(x, t, kw, noise)
+        times.append(time.perf_counter() - t0)
+        if i >= 1 and time.perf_counter() - t_all + times[-1] > budget:
+            break
+    timed_ = sorted(times[1:]) if len(times) > 1 else times
+    dt = timed_[len(timed_) // 2]
     return dict(value=1.0 / dt, unit="denoise-steps/sec", cores=cores, kind="port",
-                sample=f"1 p_sample step of the same (B={B},T={T},64x64) window, no warm-up, {dt:.1f} s",
-                s_per_clip_batch=250 * dt)
+                sample=f"p_sample steps of the same (B={B},T={T},{cfg['image_size']}x{cfg['image_size']}) window: 1 warm-up "
+                       f"({times[0]:.1f} s) + median of {len(timed_)} timed ({', '.join(f'{v:.1f}' for v in times[1:])} s)",
+                s_per_clip_batch=nts * dt)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--frames", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-fp32-ref", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
-    # The linear layers run as six bf16 piece products of exactly split fp32 operands (csrc/gemm_split.hip; as accurate
-    # as the fp32 MFMA).  For a reader who wants the number with EVERY matrix product on the fp32 MFMA, the
-    # same benchmark is run first in a child process with VD_MATH=fp32 -- started before this process touches the GPU.
+    import torch
+    import video_diffusion_amd as vda
+    from video_diffusion_amd import dist as vdist
+
+    # The matrix products run as six bf16 piece products of exactly split fp32 operands (as accurate as the fp32 MFMA,
+    # DESIGN.md 3).  For a reader who wants the number with EVERY matrix product on the fp32 MFMA, the same benchmark is
+    # run first in a child process with VD_MATH=fp32 -- started before this process touches the GPU.
     fp32_ref = None
     # (never under a profiler: its preloaded library has already initialised the GPU in this process, and starting
     # another program from such a process is not allowed on the GPU boxes)
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(
         k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ)
     if args.gpus == 1 and not args.no_fp32_ref and not profiled and os.environ.get("VD_MATH") != "fp32":
-        import subprocess
-        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup",
-                                str(args.warmup), "--batch", str(args.batch), "--frames", str(args.frames), "--no-cpu-baseline",
-                                "--no-roofline", "--no-fp32-ref"], env={**os.environ, "VD_MATH": "fp32"}, capture_output=True, text=True)
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--no-cpu-baseline",
+                                "--no-roofline", "--no-fp32-ref", "--no-dropin"], env={**os.environ, "VD_MATH": "fp32"},
+                               capture_output=True, text=True)
         try:
             ref = json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1])
             fp32_ref = {"value": ref["value"], "ms_per_step": ref["ms_per_step"], "note": "VD_MATH=fp32: every matrix product on v_mfma_f32_32x32x2_f32"}
         except Exception:                                            # noqa: BLE001 - the headline run must not depend on it
             fp32_ref = {"error": (child.stderr or child.stdout)[-300:]}
 
-    rank, local_rank, world = vdist.init()
+    # rehearsal knobs for a one-GPU box (the N > 1 path is the driver's to run on an 8-GPU node): VD_BENCH_BACKEND=gloo
+    # and VD_BENCH_ALL_ON_DEVICE0=1 put every rank on device 0 (RCCL refuses two ranks on one GPU, gloo does not)
+    rank, local_rank, world = vdist.init(backend=os.environ.get("VD_BENCH_BACKEND"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py measures the HIP engine: it needs a GPU (no CPU fallback)"
+    if os.environ.get("VD_BENCH_ALL_ON_DEVICE0"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    cfg = headline_cfg()
-    B, T, n_obs = args.batch, args.frames, 4
+    cfg = bench_cfg(vda, args)
+    S, T, n_obs = args.image_size, args.frames, args.obs
+    if args.scaling == "strong":
+        assert args.batch % world == 0, "--scaling strong splits the B-clip window evenly: batch % gpus == 0"
+        B = args.batch // world
+    else:
+        B = args.batch
     model, diff = vda.create_video_model_and_diffusion(**cfg)
     model.to(device).eval()
     specs = model.param_specs()
@@ -188,49 +327,48 @@ def main():
 
     vdist.share_weights(model, make_sd, rank)           # one RCCL broadcast of the packed buffer
 
-    kw = make_window(B, T, cfg["image_size"], n_obs, seed=1234 + rank, device=device)
-    stepper = Stepper(model, diff, kw, seed=5 + rank)
+    kw = make_window(B, T, S, n_obs, seed=1234 + rank, device=device)
+    stepper = (GraphStepper if args.executor == "graph" else Stepper)(model, diff, kw, seed=5 + rank)
     nts = diff.num_timesteps
     order = list(range(nts))[::-1]
 
-    for i in range(args.warmup):
-        stepper.step(order[i % nts])
-    torch.cuda.synchronize()
-    vdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        stepper.step(order[(args.warmup + i) % nts])
-    torch.cuda.synchronize()
-    vdist.barrier()
-    torch.cuda.synchronize()
-    elapsed = vdist.max_over_ranks(time.perf_counter() - t0, device=device)
-    assert torch.isfinite(stepper.bufs[stepper.count & 1]).all()
+    elapsed = timed(stepper, order, args.warmup, args.steps, vdist, device)
+    assert torch.isfinite(stepper.result()).all()
+
+    dropin = None
+    if not args.no_dropin:
+        elapsed_d = timed(DropInStepper(model, diff, kw), order, args.warmup, args.steps, vdist, device)
+        dropin = elapsed_d
 
     roofline, classes = None, None
     if not args.no_roofline:
-        classes = profile_step(stepper, order[0])
+        prof_stepper = stepper if args.executor == "eager" else Stepper(model, diff, kw, seed=5 + rank)
+        classes = profile_step(prof_stepper, order[0])
         if rank == 0:
-            name = max((k for k in classes if k.startswith(("igemm", "conv3x3"))), key=lambda k: classes[k]["ms"])
+            name = max((k for k in classes if k.startswith(("gemm_", "igemm", "conv3x3"))), key=lambda k: classes[k]["ms"])
             c = classes[name]
             achieved = c["gflop"] / c["ms"]                                   # GFLOP/ms = TFLOP/s
             # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
             # runs, gfx950 x2 correction on FETCH_SIZE; tools/profile_bench.sh): PMC cannot be read inside this process
-            traffic = None
+            traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
-            if os.path.exists(pmc):
+            headline = (S, args.batch, T, args.num_res_blocks) == (64, 8, 16, 2) and B == 8
+            if os.path.exists(pmc) and headline:
                 rec = json.load(open(pmc))
                 if rec.get("kernel") == name:
                     traffic = round(rec["hbm_bytes_per_launch"])
+                    traffic_source = "profiles/pmc_dominant.json (rocprofv3 --pmc passes of this workload, not this run)"
             split_conv = name == "conv3x3_wino_s64_kernel"
             # the dominant kernel runs on the bf16 matrix pipe (fp32 operands split exactly into three bf16 pieces) unless
             # VD_CONV_SPLIT=0 / VD_MATH=fp32 keep it on the fp32 MFMA: `peak` is the dense peak of the pipe it uses
-            peak = PEAK_BF16_MFMA_TFLOPS if split_conv else PEAK_FP32_MFMA_TFLOPS
+            peak = PEAK_BF16_MFMA_TFLOPS if split_conv or name.startswith("gemm_split") else PEAK_FP32_MFMA_TFLOPS
             roofline = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=peak,
-                            unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
+                            unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
                             launches_per_step=c["launches"], avg_launch_us=round(1e3 * c["ms"] / c["launches"], 1),
                             alg_gflop_per_launch=round(c["gflop"] / c["launches"], 3),
-                            alg_mb_per_launch=round(c["mb"] / c["launches"], 2))
+                            alg_mb_per_launch=round(c["mb"] / c["launches"], 2),
+                            frac_note="achieved = ALGORITHMIC direct-form fp32 FLOPs / time; the share of the matrix pipe "
+                                      "kept busy is mfma_executed_frac")
             if name.startswith("conv3x3_wino"):
                 # `achieved` counts the ALGORITHMIC flops of a direct fp32 3x3 convolution (2*M*Cout*Cin*9).  Winograd
                 # F(2x2,3x3) executes 16/36 of the multiplications; the split kernel spends six bf16 piece products
@@ -244,24 +382,37 @@ def main():
 
     if rank != 0:
         return
-    value = world * args.steps / elapsed
+    # weak: every rank denoises its own window -> windows/s add up; strong: the ranks share ONE window
+    windows_per_step = world if args.scaling == "weak" else 1
+    value = windows_per_step * args.steps / elapsed
+    headline = (S, args.batch, T, args.respacing, args.num_res_blocks, n_obs) == (64, 8, 16, "ddim250", 2, 4)
+    nparam = sum(int(torch.tensor(s).prod()) for _, s in specs)
+    workload = ("BASELINE configs[1]: BAIR-shaped 64x64, T=16 (4 obs + 12 latent), batch 8 per GPU, ddim250 respacing, "
+                "p_sample, independent mode, default 116M-param video UNet") if headline and args.scaling == "weak" else \
+        (f"{S}x{S}, T={T} ({n_obs} obs + {T - n_obs} latent), batch {args.batch} {'per GPU' if args.scaling == 'weak' else 'in total'}, "
+         f"{args.respacing} respacing, p_sample, default video UNet (num_res_blocks={args.num_res_blocks}, {nparam / 1e6:.0f}M params)")
     line = {
         "metric": "denoise-steps/sec", "value": round(value, 4), "unit": "denoise-steps/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "arithmetic": "every matrix product on the fp32 MFMA" if os.environ.get("VD_MATH") == "fp32" else
                       "fp32 operands and fp32 accumulation throughout; matrix products (3x3 convs as Winograd F(2x2,3x3), "
                       "linear layers, 1x1 and stride-2 convs): fp32 operands split EXACTLY into three bf16 pieces, six piece "
                       "products on the bf16 MFMA with fp32 accumulation (error vs fp64 <= that of the fp32 MFMA; "
                       "tests/test_gpu_ops.py)" + ("; VD_CONV_SPLIT=0: 3x3 convs on the fp32 MFMA"
                                                   if os.environ.get("VD_CONV_SPLIT") == "0" else ""),
-        "sec_per_clip_batch": round(250 * elapsed / args.steps, 2),
-        "config": {"workload": "BASELINE configs[1]: BAIR-shaped 64x64, T=16 (4 obs + 12 latent), batch 8 per GPU, "
-                               "ddim250 respacing, p_sample, independent mode, default 116M-param video UNet",
-                   "batch_per_gpu": B, "frames": T, "image_size": 64, "respaced_steps": nts,
-                   "parallelism": f"batch-shard x{world} (no collective in the step)"},
+        "sec_per_clip_batch": round(nts * elapsed / args.steps, 2),
+        "config": {"workload": workload, "batch_per_gpu": B, "frames": T, "image_size": S, "respaced_steps": nts,
+                   "parallelism": f"batch-shard x{world} (no collective in the step)", "rccl_ranks": world,
+                   "executor": args.executor},
         "roofline": roofline,
     }
+    if dropin is not None:
+        v = windows_per_step * args.steps / dropin
+        line["dropin"] = {"value": round(v, 4), "ms_per_step": round(1e3 * dropin / args.steps, 3),
+                          "ratio_to_value": round(v / value, 4),
+                          "what": "the same steps through diffusion.p_sample(model, x, t, clip_denoised=True, model_kwargs=kw) "
+                                  "(scripts/video_sample.py:151), torch.randn_like noise, fresh tensors per step"}
     if fp32_ref is not None:
         line["fp32_mfma_only"] = fp32_ref
     if classes is not None:
@@ -270,9 +421,9 @@ def main():
                                       "gbs": round(v["mb"] / v["ms"], 1)} for k, v in classes.items()}
     if world == 1 and not args.no_cpu_baseline:
         sd = sd_holder.get("sd") or make_sd()
-        line["cpu_baseline"] = cpu_baseline(cfg, sd, B, T, n_obs, order[0])
+        line["cpu_baseline"] = cpu_baseline(cfg, sd, B, T, n_obs, order[0], nts)
         line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -391,3 +391,97 @@ def test_step_is_hipgraph_capturable_and_replays_bit_exact():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, two_steps(x * 0.5))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] / configs[4] at size: the DEFAULT 128x128 model (channel_mult (1,1,2,3,4), 119 M parameters,
+# script_util.py:255-264).  Round 1 only ran miniatures of this topology; a (B=8, Tw=20) window at 128x128 exceeds the
+# 32-bit addressing of the fast kernels and is cut along the frame dimension (csrc/igemm.hip).
+def _cfg128(T=20, respacing="ddim50", **over):
+    return {**vda.video_model_and_diffusion_defaults(), **dict(T=T, image_size=128, rp_alpha=T, rp_beta=T, rp_gamma=T,
+                                                               timestep_respacing=respacing), **over}
+
+
+@pytest.mark.parametrize("T,n_obs", [(16, 4), (8, 4), (14, 10)])
+def test_default_128_model_one_clip_vs_oracle(T, n_obs):
+    """One clip of the default 128x128 model against the CPU oracle at the tier tolerance: Tw = 16 (UCF101 window of
+    configs[3]), Tw = 8 (first exp-past window) and Tw = 14 (CARLA's last autoreg window, configs[4])."""
+    cfg = _cfg128()
+    model, diff, ora = _oracle(cfg)
+    assert sum(int(np.prod(s)) for _, s in model.param_specs()) > 118_000_000
+    c = _rand_window(1, T, 128, n_obs, seed=1280 + T)
+    if T == 8:                                                        # exp-past order: observed frames newest first
+        c["frame_indices"] = torch.tensor([[3, 2, 1, 0, 4, 5, 6, 7]])
+    if T == 14:                                                       # autoreg(500, 36, 20, 10): ([486..495], [496..499])
+        c["frame_indices"] = torch.arange(486, 500).view(1, 14)
+    t = torch.tensor([37])
+    kw = {k: v for k, v in c.items() if k not in ("x", "observed_frames")}
+    want = ora.eps(c["x"], t, kw)
+    got, _ = diff._wrap_model(model)(c["x"].cuda(), t.cuda(), **kwargs_of(c))
+    close(got.cpu(), want, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,n_obs", [(4, 16, 4), (8, 20, 10), (2, 12, 8), (2, 18, 13)])
+def test_128_baseline_windows_properties(B, T, n_obs):
+    """configs[3] (B=4, T=16) and configs[4] (B=8, Tw=20 = 160 frames of 128x128: every full-resolution layer is cut into
+    frame ranges) on the default 128x128 model, plus the Tw=12 / Tw=18 windows of exp-past / MineRL's tail, through
+    size-independent properties: bit-identical reruns, finite and clamped outputs, and clip b of the batch == the same
+    clip denoised alone (which for B=8, Tw=20 also compares a cut launch sequence with an uncut one)."""
+    from video_diffusion_amd import _lib
+    cfg = _cfg128()
+    model, diff = engine(cfg)
+    c = _rand_window(B, T, 128, n_obs, seed=7 * B + T)
+    t = torch.tensor([23] * B, device="cuda")
+    noise = torch.randn(c["x"].shape, generator=torch.Generator().manual_seed(5))
+    a, xa = diff._step(0, model, c["x"], t, True, None, kwargs_of(c), 0.0, noise)
+    b, _ = diff._step(0, model, c["x"], t, True, None, kwargs_of(c), 0.0, noise)
+    assert torch.equal(a, b)
+    assert torch.isfinite(a).all() and xa.abs().max().item() <= 1.0
+    pick = B - 1
+    one = {k: (v[pick:pick + 1] if torch.is_tensor(v) else v) for k, v in c.items()}
+    s1, _ = diff._step(0, model, one["x"], t[:1], True, None, kwargs_of(one), 0.0, noise[pick:pick + 1])
+    close(a[pick:pick + 1].cpu(), s1.cpu(), atol=2e-5, rtol=2e-5)
+    model.check_device_errors()
+    if B * T >= 128:                                               # the cut really happened on this window
+        nbytes = __import__("ctypes").c_longlong()
+        _lib.check(_lib.lib().vd_workspace_bytes(model._handle, B, T, __import__("ctypes").byref(nbytes)))
+        assert nbytes.value > 30 * 2 ** 30                          # tens of GB of activations: the 288 GB part earns its keep
+
+
+def test_unrespaced_1000_step_schedule_vs_oracle():
+    """configs[0] / configs[3] use timestep_respacing='' (all 1000 DDPM steps, rescale off: t_model = t).  Bind that
+    schedule and check single p_sample steps at t = 999, 500, 1, 0 against the oracle, whose float64 tables are pinned
+    to the reference by tests/golden/schedule_linear1000_full.json (tests/test_oracle_golden.py)."""
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=4, rp_beta=4, rp_gamma=4, timestep_respacing="")}
+    model, diff, ora = _oracle(cfg)
+    assert diff.num_timesteps == 1000 and list(diff.timestep_map[:3]) == [0, 1, 2]
+    c = _rand_window(2, 4, 32, 2, seed=31)
+    kw = {k: v for k, v in c.items() if k not in ("x", "observed_frames")}
+    noise = torch.randn(c["x"].shape, generator=torch.Generator().manual_seed(6))
+    for tv in (999, 500, 1, 0):
+        t = torch.tensor([tv, tv])
+        want = ora.p_sample(c["x"], t, kw, noise)
+        s, xs = diff._step(0, model, c["x"].cuda(), t.cuda(), True, None, kwargs_of(c), 0.0, noise)
+        gain = 1.0 + float(diff.sqrt_recipm1_alphas_cumprod[tv])
+        close(xs.cpu(), want["pred_xstart"], atol=2e-5 * gain, rtol=1e-4)
+        close(s.cpu(), want["sample"], atol=1e-4, rtol=1e-4)
+
+
+def test_out_of_range_timestep_is_loud():
+    """ADVICE r1 / the reference's IndexError: a CPU `t` is refused on the host; a device `t` poisons that batch
+    element with NaN (no out-of-bounds table read) and raises at the next check_device_errors()."""
+    cfg = json.loads(str(load_npz("unet_tiny.npz")["cfg_json"]))
+    model, diff = engine(cfg)
+    c = case_inputs(load_npz("unet_tiny.npz"), 0)
+    x = c["x"].cuda()
+    with pytest.raises(IndexError):
+        diff.p_sample(model, x, torch.tensor([250, 3]), model_kwargs=kwargs_of(c))
+    model.check_device_errors()                                          # clean so far
+    out = diff.p_sample(model, x, torch.tensor([3, 250], device="cuda"), model_kwargs=kwargs_of(c))
+    assert torch.isfinite(out["sample"][0]).all() and torch.isnan(out["sample"][1]).all()
+    with pytest.raises(IndexError):
+        model.check_device_errors()
+    model.check_device_errors()                                          # the flag is sticky until read, then cleared
+    good = diff.p_sample(model, x, torch.tensor([3, 3], device="cuda"), model_kwargs=kwargs_of(c))
+    assert torch.isfinite(good["sample"]).all()
