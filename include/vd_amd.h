@@ -81,8 +81,9 @@ int vd_set_freqs(vd_engine* e, const float* host_time_freqs, int n_time, const f
  * host_tab: VD_NTAB rows of num_timesteps float32 (float64 tables cast like _extract_into_tensor,
  * gaussian_diffusion.py:1019-1031), row order VD_TAB_*.  timestep_map + rescale = _WrappedModel
  * (respace.py:111-119): t_model = map[t] * rescale (rescale = 1000/original_steps, or 1 with rescale off). */
-enum { VD_TAB_SQRT_RECIP = 0, VD_TAB_SQRT_RECIPM1, VD_TAB_COEF1, VD_TAB_COEF2, VD_TAB_LOGVAR, VD_TAB_ACP,
-       VD_TAB_ACP_PREV, VD_TAB_SQRT_ACP, VD_TAB_SQRT_1M_ACP, VD_NTAB };
+enum { VD_TAB_SQRT_RECIP = 0, VD_TAB_SQRT_RECIPM1, VD_TAB_COEF1, VD_TAB_COEF2, VD_TAB_LOGVAR /* model log variance */,
+       VD_TAB_ACP, VD_TAB_ACP_PREV, VD_TAB_SQRT_ACP, VD_TAB_SQRT_1M_ACP,
+       VD_TAB_POST_LOGVAR /* posterior_log_variance_clipped */, VD_TAB_LOG_1M_ACP /* log_one_minus_alphas_cumprod */, VD_NTAB };
 int vd_set_schedule(vd_engine* e, int num_timesteps, const float* host_tab, const int* host_timestep_map,
                     float rescale);
 
@@ -120,6 +121,42 @@ int vd_ddim_sample(vd_engine* e, int B, int T, const float* x, const float* obs_
                    const long long* t, int observed_frames, int clip_denoised, float eta, const float* noise,
                    unsigned long long seed, unsigned long long offset, float* sample, float* pred_xstart, float* eps,
                    void* stream);
+
+/* diffusion.p_mean_variance(model, x, t, clip_denoised, model_kwargs) (gaussian_diffusion.py:229-372): one UNet forward,
+ * then 'pred_xstart' (clipped) and 'mean' = posterior mean of it; 'variance' / 'log_variance' are the schedule rows
+ * VD_TAB_LOGVAR at t (the host mirror broadcasts them).  Any of mean / pred_xstart / eps may be NULL. */
+int vd_p_mean_variance(vd_engine* e, int B, int T, const float* x, const float* obs_src, const float* obs_mask,
+                       const float* latent_mask, const float* kinda_marg_mask, const long long* frame_indices,
+                       const long long* t, int observed_frames, int clip_denoised, float* mean, float* pred_xstart,
+                       float* eps, void* stream);
+
+/* The NLL path of scripts/video_nll.py.  vd_vb_terms = GaussianDiffusion._vb_terms_bpd (gaussian_diffusion.py:750-790;
+ * losses.py normal_kl / discretized_gaussian_log_likelihood) plus the two per-step MSEs of calc_bpd_loop_subsampled
+ * (:975-990), given the eps of a forward pass at x_t: vb[B] = KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) in bits per dim,
+ * or the discretised decoder NLL where t == 0; xstart_mse[B] = mean((pred_xstart - x_start)^2); mse[B] =
+ * mean((eps_from_xstart - noise)^2) (needs `noise`).  latent_mask: [B*T] or NULL; as in the reference's
+ * mean_flat(tensor, mask) the mask multiplies and the mean still runs over all elements.  vd_prior_bpd = _prior_bpd (:909-926). */
+int vd_vb_terms(vd_engine* e, int B, int T, const float* x_start, const float* x_t, const float* eps, const float* noise,
+                const long long* t, int clip_denoised, const float* latent_mask, float* vb, float* xstart_mse, float* mse,
+                float* pred_xstart, void* stream);
+int vd_prior_bpd(vd_engine* e, int B, int T, const float* x_start, const float* latent_mask, float* out, void* stream);
+
+/* Window executor -- the loop of scripts/video_sample.py:149-168 (`for timestep in reversed(range(num_timesteps)):
+ * local = diffusion.p_sample(model, local, t, ...)['sample']`) with the loop state on the device: the respaced index
+ * t[B] and the Philox {seed, offset} live in engine-owned device memory, ONE hipGraph holds a whole step (t -> t_model,
+ * UNet forward, posterior update of x IN PLACE, t -= 1, offset += B*T*3*H*W) and is captured once per window signature
+ * (B, T, the six tensor addresses, observed_frames, sampler, clip, eta), so a window costs num_timesteps graph launches
+ * instead of ~330 kernel launches per step from the host (BASELINE configs[4]: two signatures, Tw = 20 and Tw = 14).
+ * vd_window_begin arms the counters (and captures if the signature is new: one eager forward, then the capture; `stream`
+ * must not be the default stream); vd_window_run replays n_steps steps t_start, t_start-1, ...; x holds the result.
+ * observed_frames: x_0 or x_t only.  Noise is always the in-kernel Philox stream (seed, offset + step*B*per + i):
+ * identical to vd_p_sample(noise = NULL, seed, offset + step*B*per). */
+int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, const float* obs_mask,
+                    const float* latent_mask, const float* kinda_marg_mask, const long long* frame_indices,
+                    int observed_frames, int sampler, int clip_denoised, float eta, unsigned long long seed,
+                    unsigned long long offset, long long t_start, void* stream);
+int vd_window_run(vd_engine* e, int n_steps, void* stream);
+int vd_window_graphs(vd_engine* e);            /* captured graphs held by the engine */
 
 /* The posterior arithmetic alone, given eps (same formulas; mode 0 p_sample, 1 ddim). */
 int vd_posterior_update(vd_engine* e, int mode, int B, long long per_sample, const float* x, const float* eps,

@@ -17,9 +17,20 @@ Follows (reference file:line, relative to /root/reference/improved_diffusion):
   - p_sample_loop_progressive (side draws)              gaussian_diffusion.py:528-595
   - ddim_sample_loop_progressive                        gaussian_diffusion.py:702-748
   - _WrappedModel.__call__                              respace.py:111-119
+  - q_mean_variance / _prior_bpd                        gaussian_diffusion.py:174-188, 909-926
+  - _vb_terms_bpd                                       gaussian_diffusion.py:750-790
+  - calc_bpd_loop_subsampled                            gaussian_diffusion.py:928-1002
+
+The loops draw from torch's global CPU generator in the reference's ORDER (p_sample_loop_progressive: the initial image,
+then per step x_t_minus_1's noise, random_t's uniform, x_random's noise, p_sample's noise); tests/golden/loops_tiny.npz
+holds what the imported reference produced from the same seeds.
 """
+import math
+
 import numpy as np
 import torch
+
+from .losses_ref import discretized_gaussian_log_likelihood, mean_flat, normal_kl
 
 
 def _coef(table, t, like):
@@ -72,6 +83,74 @@ class SamplerRef:
     def q_sample(self, x0, t, noise):
         s = self.s
         return _coef(s.sqrt_alphas_cumprod, t, x0) * x0 + _coef(s.sqrt_one_minus_alphas_cumprod, t, x0) * noise
+
+    def p_sample_loop_progressive(self, shape, kw, observed_frames):
+        """gaussian_diffusion.py:528-595 with noise=None: every draw comes from the global generator, in this order."""
+        kw = dict(kw, observed_frames=observed_frames)
+        img = torch.randn(*shape)
+        B = shape[0]
+        for i in range(self.num_timesteps)[::-1]:
+            t = torch.tensor([i] * B)
+            tm1 = torch.where(t - 1 < 0, t - 1 + self.num_timesteps, t - 1)          # table[-1] wraps (:565-568)
+            kw["x_t_minus_1"] = self.q_sample(kw["x0"], tm1, torch.randn_like(kw["x0"]))
+            kw["random_t"] = torch.floor(t * torch.rand(t.shape)).long()
+            torch.randn_like(kw["x0"])                                            # x_random: drawn, unused in eval (unet.py:962)
+            out = self.p_sample(img, t, kw, torch.randn_like(img))
+            yield out, kw
+            img = out["sample"]
+
+    def ddim_sample_loop_progressive(self, shape, kw, eta=0.0):
+        """gaussian_diffusion.py:702-748 with noise=None."""
+        img = torch.randn(*shape)
+        B = shape[0]
+        for i in range(self.num_timesteps)[::-1]:
+            out = self.ddim_sample(img, torch.tensor([i] * B), kw, torch.randn_like(img), eta=eta)
+            yield out
+            img = out["sample"]
+
+    # ---- NLL path -------------------------------------------------------------------------------------------------
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        s = self.s
+        mean = _coef(s.posterior_mean_coef1, t, x_t) * x_start + _coef(s.posterior_mean_coef2, t, x_t) * x_t
+        return mean, _coef(s.posterior_variance, t, x_t).expand(x_t.shape), \
+            _coef(s.posterior_log_variance_clipped, t, x_t).expand(x_t.shape)
+
+    def vb_terms_bpd(self, x_start, x_t, t, kw, clip=True, latent_mask=None):
+        true_mean, _, true_logvar = self.q_posterior_mean_variance(x_start, x_t, t)
+        out = self.mean_variance(x_t, t, kw, clip)
+        kl = mean_flat(normal_kl(true_mean, true_logvar, out["mean"], out["log_variance"]), latent_mask) / math.log(2.0)
+        nll = -discretized_gaussian_log_likelihood(x_start, means=out["mean"], log_scales=0.5 * out["log_variance"])
+        nll = mean_flat(nll, latent_mask) / math.log(2.0)
+        return dict(output=torch.where(t == 0, nll, kl), pred_xstart=out["pred_xstart"])
+
+    def prior_bpd(self, x_start, latent_mask=None):
+        s = self.s
+        t = torch.tensor([self.num_timesteps - 1] * x_start.shape[0])
+        mean = _coef(s.sqrt_alphas_cumprod, t, x_start) * x_start
+        logvar = _coef(np.log(1.0 - s.alphas_cumprod), t, x_start).expand(x_start.shape)
+        return mean_flat(normal_kl(mean, logvar, 0.0, 0.0), latent_mask) / math.log(2.0)
+
+    def calc_bpd_loop_subsampled(self, x_start, kw, clip=True, latent_mask=None, t_seq=None):
+        s = self.s
+        B = x_start.shape[0]
+        if t_seq is None:
+            t_seq = list(range(self.num_timesteps))[::-1]
+        two_d = isinstance(t_seq, np.ndarray) and t_seq.ndim == 2
+        if two_d:
+            t_seq = t_seq.transpose()
+        vb, xmse, mse = [], [], []
+        for t in t_seq:
+            tb = torch.tensor(t) if two_d else torch.tensor([t] * B)
+            noise = torch.randn_like(x_start)
+            x_t = self.q_sample(x_start, tb, noise)
+            out = self.vb_terms_bpd(x_start, x_t, tb, kw, clip, latent_mask)
+            vb.append(out["output"])
+            xmse.append(mean_flat((out["pred_xstart"] - x_start) ** 2, latent_mask))
+            eps = (_coef(s.sqrt_recip_alphas_cumprod, tb, x_t) * x_t - out["pred_xstart"]) / _coef(s.sqrt_recipm1_alphas_cumprod, tb, x_t)
+            mse.append(mean_flat((eps - noise) ** 2, latent_mask))
+        vb, xmse, mse = torch.stack(vb, 1), torch.stack(xmse, 1), torch.stack(mse, 1)
+        prior = self.prior_bpd(x_start, latent_mask)
+        return dict(total_bpd=vb.sum(1) + prior, prior_bpd=prior, vb=vb, xstart_mse=xmse, mse=mse)
 
     def window_loop(self, x_init, kw, noises, sampler="p", eta=0.0):
         """scripts/video_sample.py:149-168 -- the loop the drop-in target runs:

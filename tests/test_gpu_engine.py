@@ -235,7 +235,7 @@ def test_infer_video_autoreg_vs_oracle(monkeypatch):
         return z.to(x.device)
 
     monkeypatch.setattr(gdm.th, "randn_like", fake_randn_like)
-    got, _ = infer_video("autoreg", model, diff, batch.cuda(), max_frames, obs_len, step)
+    got, _ = infer_video("autoreg", model, diff, batch.cuda(), max_frames, obs_len, step, executor="eager")
     monkeypatch.undo()
 
     samples = torch.zeros_like(batch)
@@ -485,3 +485,180 @@ def test_out_of_range_timestep_is_loud():
     model.check_device_errors()                                          # the flag is sticky until read, then cleared
     good = diff.p_sample(model, x, torch.tensor([3, 3], device="cuda"), model_kwargs=kwargs_of(c))
     assert torch.isfinite(good["sample"]).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# a10 / a12: the two loops against what the imported reference produced (tools/gen_golden_loops.py)
+def _cpu_draws(monkeypatch):
+    """The reference draws everything from torch's global CPU generator; route the mirror's draws there too (the engine
+    lives on the GPU, whose generator is a different stream)."""
+    from video_diffusion_amd import gaussian_diffusion as gdm
+    o_randn, o_rand = torch.randn, torch.rand
+    monkeypatch.setattr(gdm.th, "randn", lambda *s, device=None, **k: o_randn(*s).to(device or "cpu"))
+    monkeypatch.setattr(gdm.th, "randn_like", lambda x, *a, **k: o_randn(x.shape).to(x.device))
+    monkeypatch.setattr(gdm.th, "rand", lambda *s, **k: o_rand(*s))
+
+
+def _loops_rec():
+    rec = load_npz("loops_tiny.npz")
+    cfg = json.loads(str(rec["cfg_json"]))
+    model, diff = engine(cfg)
+    c = {k: torch.from_numpy(rec[k]) for k in ["x0", "obs_mask", "latent_mask", "kinda_marg_mask", "frame_indices"]}
+    return rec, model, diff, c
+
+
+@pytest.mark.parametrize("obsf", ["x_0", "x_t_minus_1", "x_t"])
+def test_p_sample_loop_matches_reference_golden(monkeypatch, obsf):
+    """GaussianDiffusion.p_sample_loop (gaussian_diffusion.py:450-595) from a seeded global generator: the mirror must walk
+    the generator like the reference (initial image; per step x_t_minus_1's noise, random_t's uniform, x_random's noise,
+    p_sample's noise) and land on the reference's trajectory."""
+    rec, model, diff, c = _loops_rec()
+    _cpu_draws(monkeypatch)
+    kw = {k: v.cuda() for k, v in c.items()}
+    kw["observed_frames"] = obsf
+    torch.manual_seed(int(rec[f"p_{obsf}_seed"]))
+    outs = [o["sample"].cpu() for o in diff.p_sample_loop_progressive(model, tuple(rec["x0"].shape), model_kwargs=kw)]
+    assert len(outs) == 5
+    close(outs[0], rec[f"p_{obsf}_step0"], atol=1e-4, rtol=1e-4)
+    assert np.array_equal(kw["random_t"].cpu().numpy(), rec[f"p_{obsf}_random_t"])
+    close(kw["x_t_minus_1"].cpu(), rec[f"p_{obsf}_x_t_minus_1"], atol=1e-6, rtol=1e-6)
+    assert np.abs(outs[-1].numpy() - rec[f"p_{obsf}_final"]).mean() < 1e-4          # 5 chained ddim5 steps: drift bound
+    close(outs[-1], rec[f"p_{obsf}_final"], atol=1e-2, rtol=1e-2)
+    torch.manual_seed(int(rec[f"p_{obsf}_seed"]))
+    kw2 = {k: v.cuda() for k, v in c.items()}
+    kw2["observed_frames"] = obsf
+    final, attns = diff.p_sample_loop(model, tuple(rec["x0"].shape), model_kwargs=kw2)
+    assert attns == {} and torch.equal(final.cpu(), outs[-1])
+
+
+@pytest.mark.parametrize("eta", [0, 1])
+def test_ddim_sample_loop_matches_reference_golden(monkeypatch, eta):
+    """GaussianDiffusion.ddim_sample_loop (gaussian_diffusion.py:670-748), eta = 0 and 1."""
+    rec, model, diff, c = _loops_rec()
+    _cpu_draws(monkeypatch)
+    kw = kwargs_of(c)
+    torch.manual_seed(int(rec[f"ddim_eta{eta}_seed"]))
+    outs = [o["sample"].cpu() for o in diff.ddim_sample_loop_progressive(model, tuple(rec["x0"].shape), model_kwargs=kw,
+                                                                       eta=float(eta))]
+    close(outs[0], rec[f"ddim_eta{eta}_step0"], atol=2e-4, rtol=2e-4)
+    assert np.abs(outs[-1].numpy() - rec[f"ddim_eta{eta}_final"]).mean() < 1e-4
+    close(outs[-1], rec[f"ddim_eta{eta}_final"], atol=1e-2, rtol=1e-2)
+    torch.manual_seed(int(rec[f"ddim_eta{eta}_seed"]))
+    final = diff.ddim_sample_loop(model, tuple(rec["x0"].shape), model_kwargs=kwargs_of(c), eta=float(eta))
+    assert torch.is_tensor(final) and torch.equal(final.cpu(), outs[-1])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# f4 (forward-only half): p_mean_variance and the NLL path on the engine vs the imported reference
+def test_p_mean_variance_and_nll_match_reference_golden(monkeypatch):
+    """p_mean_variance (gaussian_diffusion.py:229-372), _vb_terms_bpd (:750-790; losses.py), _prior_bpd (:909-926),
+    calc_bpd_loop_subsampled (:928-1002; list and 2-D t_seq) against tests/golden/nll_tiny.npz."""
+    rec = load_npz("nll_tiny.npz")
+    cfg = json.loads(str(rec["cfg_json"]))
+    model, diff = engine(cfg)
+    c = {k: torch.from_numpy(rec[k]) for k in ["x0", "obs_mask", "latent_mask", "kinda_marg_mask", "frame_indices"]}
+    x0, lm = c["x0"].cuda(), c["latent_mask"].cuda()
+    B = x0.shape[0]
+    for tv in (4, 2, 0):
+        t = torch.tensor([tv] * B, device="cuda")
+        x_t = torch.from_numpy(rec[f"t{tv}_x_t"]).cuda()
+        mv = diff.p_mean_variance(model, x_t, t, clip_denoised=True, model_kwargs=kwargs_of(c))
+        assert {"mean", "variance", "log_variance", "pred_xstart", "attn"} <= set(mv) and mv["attn"] is None
+        gain = 1.0 + float(diff.sqrt_recipm1_alphas_cumprod[tv])
+        close(mv["pred_xstart"].cpu(), rec[f"t{tv}_pred_xstart"], atol=2e-5 * gain, rtol=1e-4)
+        close(mv["mean"].cpu(), rec[f"t{tv}_mean"], atol=1e-4, rtol=1e-4)
+        assert np.array_equal(mv["variance"].cpu().numpy(), rec[f"t{tv}_variance"])
+        assert np.array_equal(mv["log_variance"].cpu().numpy(), rec[f"t{tv}_log_variance"])
+        for clip in (1, 0):
+            vb = diff._vb_terms_bpd(model, x_start=x0, x_t=x_t, t=t, clip_denoised=bool(clip), model_kwargs=kwargs_of(c),
+                                    latent_mask=lm)
+            close(vb["output"].cpu(), rec[f"t{tv}_vb_clip{clip}"], atol=2e-5, rtol=1e-3)
+        vbn = diff._vb_terms_bpd(model, x_start=x0, x_t=x_t, t=t, model_kwargs=kwargs_of(c))
+        close(vbn["output"].cpu(), rec[f"t{tv}_vb_nomask"], atol=2e-5, rtol=1e-3)
+    close(diff._prior_bpd(x0, latent_mask=lm, model=model).cpu(), rec["prior_bpd"], atol=1e-7, rtol=1e-4)
+    close(diff._prior_bpd(x0, model=model).cpu(), rec["prior_bpd_nomask"], atol=1e-7, rtol=1e-4)
+    _cpu_draws(monkeypatch)
+    torch.manual_seed(int(rec["bpd_seed"]))
+    m = diff.calc_bpd_loop_subsampled(model, x0, clip_denoised=True, model_kwargs=kwargs_of(c), latent_mask=lm)
+    for k in ("total_bpd", "prior_bpd", "vb", "xstart_mse", "mse"):
+        close(m[k].cpu(), rec[f"bpd_{k}"], atol=2e-5, rtol=1e-3)
+    torch.manual_seed(int(rec["bpd2_seed"]))
+    m2 = diff.calc_bpd_loop_subsampled(model, x0, clip_denoised=True, model_kwargs=kwargs_of(c), latent_mask=lm,
+                                       t_seq=rec["bpd2_t_seq"])
+    for k in ("total_bpd", "vb", "mse"):
+        close(m2[k].cpu(), rec[f"bpd2_{k}"], atol=2e-5, rtol=1e-3)
+    from video_diffusion_amd.video_nll import run_bpd_evaluation
+    torch.manual_seed(1)
+    out = run_bpd_evaluation(model, diff, c["x0"], True, [[0, 1], [0, 1]], [[2, 3], [3]])
+    assert set(out) == {"total_bpd", "prior_bpd", "vb", "xstart_mse", "mse"} and all(v.shape == (2,) for v in out.values())
+    assert np.isfinite(out["total_bpd"]).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# G1: the window executor
+def test_window_executor_equals_eager_steps_bit_for_bit():
+    """vd_window_begin / vd_window_run: device-resident step index and Philox counter, one captured graph per window
+    signature.  Its trajectory must be the eager one: step k of the window == vd_p_sample(noise=NULL, seed, offset =
+    k*B*per) applied to the previous result, to the bit (same kernels, same addresses for the activations), for
+    p_sample and DDIM; a second window of the same shape reuses the graph, another shape adds one."""
+    from video_diffusion_amd import _lib
+    from video_diffusion_amd.executor import WindowExecutor
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=6, image_size=32, num_channels=64, num_res_blocks=1,
+                                                              rp_alpha=6, rp_beta=6, rp_gamma=6, timestep_respacing="ddim10")}
+    model, diff = engine(cfg)
+    diff._bind(model)
+    L = _lib.lib()
+    ex = WindowExecutor(model, diff)
+    g0 = ex.graphs
+    for wi, (B, T, n_obs, sampler, obsf) in enumerate([(2, 6, 2, "p_sample", "x_0"), (2, 6, 3, "p_sample", "x_0"),
+                                                       (1, 4, 1, "ddim", "x_0"), (2, 6, 2, "p_sample", "x_t")]):
+        c = _rand_window(B, T, 32, n_obs, seed=40 + wi)
+        kw = kwargs_of(c, observed_frames=obsf)
+        x_init = c["x0"].cuda().clone()
+        seed = 1234 + wi
+        ex.begin(x_init, kw, seed=seed, sampler=sampler, eta=0.5)
+        got_mid = ex.run(3).clone()
+        got = ex.run(7).clone()
+        with pytest.raises(_lib.VdError):
+            ex.run(1)                                                  # t would pass 0
+        # eager replay with the same counter-based noise
+        cur = x_init.clone()
+        per = cur[0].numel()
+        k = model._pack_kwargs(cur, kw)
+        for step, ti in enumerate(range(diff.num_timesteps)[::-1]):
+            t = torch.full((B,), ti, dtype=torch.int64, device="cuda")
+            nxt = torch.empty_like(cur)
+            obs_src = cur if obsf == "x_t" else k["obs_src"]
+            args = (model._handle, B, T, _lib.ptr(cur), _lib.ptr(obs_src), _lib.ptr(k["obs_mask"]), _lib.ptr(k["latent_mask"]),
+                    _lib.ptr(k["kinda_marg_mask"]), _lib.ptr(k["frame_indices"]), _lib.ptr(t), k["obs_mode"], 1)
+            if sampler == "p_sample":
+                _lib.check(L.vd_p_sample(*args, None, seed, step * B * per, _lib.ptr(nxt), None, None, _lib.current_stream()))
+            else:
+                _lib.check(L.vd_ddim_sample(*args, 0.5, None, seed, step * B * per, _lib.ptr(nxt), None, None, _lib.current_stream()))
+            cur = nxt
+            if step == 2:
+                assert torch.equal(cur, got_mid)
+        assert torch.equal(cur, got) and torch.isfinite(got).all()
+    assert ex.graphs - g0 == 4 - 1                                      # windows 0 and 1 share a signature
+    model.check_device_errors()
+
+
+def test_infer_video_graph_executor_statistics_and_reproducibility():
+    """infer_video's default path (executor='graph'): reproducible under torch.manual_seed, observed frames pass through,
+    and on a window of identical noise-free structure its output distribution matches the eager path's (same mean / std
+    of the generated frames to a few percent: different random streams, same sampler)."""
+    from video_diffusion_amd.video_sample import infer_video
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=4, rp_beta=4, rp_gamma=4, timestep_respacing="ddim5")}
+    model, diff = engine(cfg)
+    batch = torch.rand(2, 8, 3, 32, 32, generator=torch.Generator().manual_seed(8)) * 2 - 1
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(77)
+        outs.append(infer_video("autoreg", model, diff, batch.cuda(), 4, 2, 2)[0])
+    assert np.array_equal(outs[0], outs[1]) and np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0][:, :2], batch[:, :2].numpy())
+    torch.manual_seed(78)
+    eager = infer_video("autoreg", model, diff, batch.cuda(), 4, 2, 2, executor="eager")[0]
+    assert not np.array_equal(eager, outs[0])
+    assert abs(eager[:, 2:].mean() - outs[0][:, 2:].mean()) < 0.05 and abs(eager[:, 2:].std() / outs[0][:, 2:].std() - 1) < 0.1

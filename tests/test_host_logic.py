@@ -40,7 +40,7 @@ def test_schedule_tables_bit_exact(tag):
         want = np.array([float.fromhex(h) for h in rec[name]])
         assert np.array_equal(getattr(d, name), want), name
     tab = d._device_tables()
-    assert tab.shape == (9, d.num_timesteps) and tab.dtype == np.float32
+    assert tab.shape == (11, d.num_timesteps) and tab.dtype == np.float32
 
 
 def test_schedulers_match_reference_sequences():

@@ -162,3 +162,72 @@ def test_full_sampler_matches_reference(tag, vertical, obs_frames):
     assert err.mean() < 5e-5, err.mean()                  # 20 chained ddim5 steps: drift, not a per-step bound
     close(out, ref, atol=2e-2, rtol=1e-2)
     assert np.array_equal(out.numpy()[:, :obs_len], rec["batch"][:, :obs_len])
+
+
+def _loops_setup(name):
+    rec = load_npz(name)
+    cfg = json.loads(str(rec["cfg_json"]))
+    s = SamplerRef(ScheduleRef(timestep_respacing=cfg["timestep_respacing"]), _build(cfg))
+    kw = {k: torch.from_numpy(rec[k]) for k in ["x0", "obs_mask", "latent_mask", "kinda_marg_mask", "frame_indices"]}
+    return rec, s, kw
+
+
+@pytest.mark.parametrize("obsf", ["x_0", "x_t_minus_1", "x_t"])
+def test_p_sample_loop_matches_reference(obsf):
+    """gaussian_diffusion.py:450-595 run by the reference from a seeded global generator (tools/gen_golden_loops.py):
+    the restatement must consume the generator in the same order (initial image; per step x_t_minus_1's noise, random_t's
+    uniform, x_random's noise, p_sample's noise) to land on the same trajectory."""
+    rec, s, kw = _loops_setup("loops_tiny.npz")
+    torch.manual_seed(int(rec[f"p_{obsf}_seed"]))
+    outs = list(s.p_sample_loop_progressive(tuple(rec["x0"].shape), kw, obsf))
+    assert len(outs) == 5
+    close(outs[0][0]["sample"], rec[f"p_{obsf}_step0"], atol=5e-5, rtol=5e-5)
+    last_kw = outs[-1][1]
+    assert np.array_equal(last_kw["random_t"].numpy(), rec[f"p_{obsf}_random_t"])
+    close(last_kw["x_t_minus_1"], rec[f"p_{obsf}_x_t_minus_1"], atol=1e-6, rtol=1e-6)
+    final = outs[-1][0]["sample"].numpy()
+    assert np.abs(final - rec[f"p_{obsf}_final"]).mean() < 5e-5           # 5 chained ddim5 steps: drift bound
+    close(final, rec[f"p_{obsf}_final"], atol=5e-3, rtol=5e-3)
+
+
+@pytest.mark.parametrize("eta", [0, 1])
+def test_ddim_sample_loop_matches_reference(eta):
+    """gaussian_diffusion.py:670-748, eta = 0 and 1."""
+    rec, s, kw = _loops_setup("loops_tiny.npz")
+    torch.manual_seed(int(rec[f"ddim_eta{eta}_seed"]))
+    outs = list(s.ddim_sample_loop_progressive(tuple(rec["x0"].shape), kw, eta=float(eta)))
+    close(outs[0]["sample"], rec[f"ddim_eta{eta}_step0"], atol=1e-4, rtol=1e-4)
+    final = outs[-1]["sample"].numpy()
+    assert np.abs(final - rec[f"ddim_eta{eta}_final"]).mean() < 5e-5
+    close(final, rec[f"ddim_eta{eta}_final"], atol=5e-3, rtol=5e-3)
+
+
+def test_nll_terms_match_reference():
+    """p_mean_variance / _vb_terms_bpd / _prior_bpd / calc_bpd_loop_subsampled (gaussian_diffusion.py:229-372,750-790,
+    909-1002; losses.py) against what the imported reference computed."""
+    rec, s, kw = _loops_setup("nll_tiny.npz")
+    x0, lm = kw["x0"], kw["latent_mask"]
+    B = x0.shape[0]
+    for tv in (4, 2, 0):
+        t = torch.tensor([tv] * B)
+        x_t = torch.from_numpy(rec[f"t{tv}_x_t"])
+        mv = s.mean_variance(x_t, t, kw, clip=True)
+        gain = 1.0 + float(s.s.sqrt_recipm1_alphas_cumprod[tv])
+        close(mv["pred_xstart"], rec[f"t{tv}_pred_xstart"], atol=1e-5 * gain, rtol=5e-5)
+        close(mv["mean"], rec[f"t{tv}_mean"], atol=5e-5, rtol=5e-5)
+        assert np.array_equal(mv["variance"].numpy(), rec[f"t{tv}_variance"])
+        assert np.array_equal(mv["log_variance"].numpy(), rec[f"t{tv}_log_variance"])
+        for clip in (1, 0):
+            vb = s.vb_terms_bpd(x0, x_t, t, kw, clip=bool(clip), latent_mask=lm)
+            close(vb["output"], rec[f"t{tv}_vb_clip{clip}"], atol=1e-5, rtol=2e-4)
+        close(s.vb_terms_bpd(x0, x_t, t, kw)["output"], rec[f"t{tv}_vb_nomask"], atol=1e-5, rtol=2e-4)
+    close(s.prior_bpd(x0, lm), rec["prior_bpd"], atol=1e-7, rtol=1e-5)
+    close(s.prior_bpd(x0), rec["prior_bpd_nomask"], atol=1e-7, rtol=1e-5)
+    torch.manual_seed(int(rec["bpd_seed"]))
+    m = s.calc_bpd_loop_subsampled(x0, kw, clip=True, latent_mask=lm)
+    for k in ("total_bpd", "prior_bpd", "vb", "xstart_mse", "mse"):
+        close(m[k], rec[f"bpd_{k}"], atol=1e-5, rtol=5e-4)
+    torch.manual_seed(int(rec["bpd2_seed"]))
+    m2 = s.calc_bpd_loop_subsampled(x0, kw, clip=True, latent_mask=lm, t_seq=rec["bpd2_t_seq"])
+    for k in ("total_bpd", "vb", "mse"):
+        close(m2[k], rec[f"bpd2_{k}"], atol=1e-5, rtol=5e-4)

@@ -114,6 +114,12 @@ SIGNATURES = {
     "vd_unet_forward": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "vd_p_sample": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _U, _P, _P, _P, _P]),
     "vd_ddim_sample": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _U, _U, _P, _P, _P, _P]),
+    "vd_p_mean_variance": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "vd_vb_terms": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "vd_prior_bpd": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "vd_window_begin": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _U, _L, _P]),
+    "vd_window_run": (_I, [_P, _I, _P]),
+    "vd_window_graphs": (_I, [_P]),
     "vd_posterior_update": (_I, [_P, _I, _I, _L, _P, _P, _P, _I, _F, _P, _U, _U, _P, _P, _P]),
     "vd_q_sample": (_I, [_P, _I, _L, _P, _P, _P, _P, _P]),
     "vd_randn": (_I, [_P, _L, _U, _U, _P]),

@@ -201,6 +201,19 @@ struct vd_engine {
     std::unordered_map<long long, size_t> ws_peaks;  // (B << 32 | T) -> arena peak
     int* d_err = nullptr;                            // sticky device flags: bit 0 = timestep index out of range
     int device = -1;
+    double* d_part = nullptr; size_t part_cap = 0;   // NLL partial sums
+    // ---- window executor (vd_window_*): device-resident step state + one captured graph per window signature
+    struct WinKey {
+        int B, T, obs_mode, sampler, clip; float eta;
+        const void *x, *obs_src, *obs, *lat, *km, *fidx;
+        bool operator==(const WinKey& o) const { return std::memcmp(this, &o, sizeof(WinKey)) == 0; }
+    };
+    struct WinGraph { WinKey key; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<WinGraph> win_graphs;
+    int win_cur = -1;
+    long long win_left = 0;                              // steps the current window still has (t + 1)
+    long long* d_win_t = nullptr; int win_t_cap = 0;     // [B] current respaced index of the window
+    unsigned long long* d_win_rng = nullptr;             // {seed, Philox offset}
 
     ~vd_engine() {
         if (d_freq_time) (void)hipFree(d_freq_time);
@@ -209,6 +222,10 @@ struct vd_engine {
         if (d_tmap) (void)hipFree(d_tmap);
         if (ws) (void)hipFree(ws);
         if (d_err) (void)hipFree(d_err);
+        if (d_part) (void)hipFree(d_part);
+        if (d_win_t) (void)hipFree(d_win_t);
+        if (d_win_rng) (void)hipFree(d_win_rng);
+        for (auto& g : win_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     }
 
     const float* W(int p) const { return wbuf + params[p].off; }
@@ -1004,6 +1021,29 @@ __global__ void map_t_kernel(const int64_t* t, const float* tmap, float rescale,
     }
 }
 
+// One denoise step on `st`: t -> t_model, UNet forward, posterior update.  `t` and (when rng != null) the Philox
+// {seed, offset} are read from device memory, so the same launch sequence serves every step of a window (executor).
+static int step_launches(vd_engine* e, int mode, int B, int T, const float* x, const float* obs_src, const float* obs,
+                         const float* lat, const float* km, const long long* fidx, const long long* t, int obs_mode,
+                         int clip, float eta, const float* noise, unsigned long long seed, unsigned long long offset,
+                         const unsigned long long* rng, float* sample, float* xstart, float* mean, float* eps_out,
+                         hipStream_t st) {
+    int rc;
+    const size_t per = (size_t)T * 3 * e->cfg.image_size * e->cfg.image_size;
+    // tail of the workspace: t_model [B] + eps scratch (sized by ensure_ws for this B)
+    float* tm = reinterpret_cast<float*>(e->ws + e->ws_tail);
+    float* eps = eps_out ? eps_out : reinterpret_cast<float*>(e->ws + e->ws_tail + (((size_t)B * sizeof(float) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(t), e->d_tmap,
+                       e->rescale, B, e->num_timesteps, tm, e->d_err);
+    Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
+    FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
+    if ((rc = e->forward(fi, st, ar))) return rc;
+    PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
+                     mode, eta, seed, offset, sample, xstart, mean, rng};
+    ProfScope ps(PC_POSTERIOR, 0.0, 4.0 * B * per * 5.0, st);
+    return launch_posterior(pa, st);
+}
+
 static int sample_impl(vd_engine* e, int mode, int B, int T, const float* x, const float* obs_src, const float* obs,
                        const float* lat, const float* km, const long long* fidx, const long long* t, int obs_mode,
                        int clip, float eta, const float* noise, unsigned long long seed, unsigned long long offset,
@@ -1015,21 +1055,154 @@ static int sample_impl(vd_engine* e, int mode, int B, int T, const float* x, con
     VD_REQUIRE(obs_mode >= 0 && obs_mode <= 2, "observed_frames must be x_0 / x_t / x_t_minus_1");
     VD_REQUIRE(mode == 0 || eta >= 0.f, "eta");
     if ((rc = e->ensure_ws(B, T))) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t per = (size_t)T * 3 * e->cfg.image_size * e->cfg.image_size;
-    // tail of the workspace: t_model [B] + eps scratch (sized by ensure_ws for this B)
-    float* tm = reinterpret_cast<float*>(e->ws + e->ws_tail);
-    float* eps = eps_out ? eps_out : reinterpret_cast<float*>(e->ws + e->ws_tail + (((size_t)B * sizeof(float) + 255) & ~(size_t)255));
-    hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(t), e->d_tmap,
-                       e->rescale, B, e->num_timesteps, tm, e->d_err);
-    Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
-    FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
-    if ((rc = e->forward(fi, st, ar))) return rc;
-    PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
-                     mode, eta, seed, offset, sample, xstart};
-    ProfScope ps(PC_POSTERIOR, 0.0, 4.0 * B * per * 5.0, st);
-    return launch_posterior(pa, st);
+    return step_launches(e, mode, B, T, x, obs_src, obs, lat, km, fidx, t, obs_mode, clip, eta, noise, seed, offset, nullptr,
+                         sample, xstart, nullptr, eps_out, static_cast<hipStream_t>(stream));
 }
+
+int vd_p_mean_variance(vd_engine* e, int B, int T, const float* x, const float* obs_src, const float* obs, const float* lat,
+                       const float* km, const long long* fidx, const long long* t, int obs_mode, int clip, float* mean,
+                       float* xstart, float* eps, void* stream) {
+    int rc = check_ready(e, B, T);
+    if (rc) return rc;
+    VD_REQUIRE(e->d_tab, "vd_set_schedule not called");
+    VD_REQUIRE(x && obs_src && obs && lat && km && fidx && t && (mean || xstart || eps), "null tensor");
+    VD_REQUIRE(obs_mode >= 0 && obs_mode <= 2, "observed_frames must be x_0 / x_t / x_t_minus_1");
+    if ((rc = e->ensure_ws(B, T))) return rc;
+    return step_launches(e, 0, B, T, x, obs_src, obs, lat, km, fidx, t, obs_mode, clip, 0.f, nullptr, 0, 0, nullptr, nullptr,
+                         xstart, mean, eps, static_cast<hipStream_t>(stream));
+}
+
+static int ensure_part(vd_engine* e, size_t doubles) {
+    if (doubles <= e->part_cap) return 0;
+    if (e->d_part) VD_HIP(hipFree(e->d_part));
+    e->d_part = nullptr; e->part_cap = 0;
+    VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_part), doubles * sizeof(double)));
+    e->part_cap = doubles;
+    return 0;
+}
+
+int vd_vb_terms(vd_engine* e, int B, int T, const float* x_start, const float* x_t, const float* eps, const float* noise,
+                const long long* t, int clip, const float* latent_mask, float* vb, float* xstart_mse, float* mse,
+                float* pred_xstart, void* stream) {
+    VD_REQUIRE(e && e->d_tab, "vd_set_schedule not called");
+    VD_REQUIRE(B > 0 && T > 0 && x_start && x_t && eps && t && vb, "arguments");
+    VD_REQUIRE(mse == nullptr || noise != nullptr, "mse needs the noise x_t was drawn with");
+    const long per = (long)T * 3 * e->cfg.image_size * e->cfg.image_size;
+    const int nblk = vb_terms_blocks(per);
+    int rc = ensure_part(e, (size_t)B * nblk * 3);
+    if (rc) return rc;
+    VbArgs a{x_start, x_t, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, latent_mask, B, T, per,
+             clip, pred_xstart, e->d_part, nblk, vb, xstart_mse, mse};
+    return launch_vb_terms(a, static_cast<hipStream_t>(stream));
+}
+
+int vd_prior_bpd(vd_engine* e, int B, int T, const float* x_start, const float* latent_mask, float* out, void* stream) {
+    VD_REQUIRE(e && e->d_tab, "vd_set_schedule not called");
+    VD_REQUIRE(B > 0 && T > 0 && x_start && out, "arguments");
+    const long per = (long)T * 3 * e->cfg.image_size * e->cfg.image_size;
+    const int nblk = vb_terms_blocks(per);
+    int rc = ensure_part(e, (size_t)B * nblk * 3);
+    if (rc) return rc;
+    return launch_prior_bpd(x_start, latent_mask, e->d_tab, e->num_timesteps, B, T, per, e->d_part, nblk, out,
+                            static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------------ window executor
+// scripts/video_sample.py:149-168 runs `for timestep in reversed(range(num_timesteps)): local = p_sample(...)` from the
+// host, ~330 launches per step.  Here the window's step index and Philox counter live in device memory, a step is ONE
+// captured hipGraph (map_t -> UNet forward -> in-place posterior update -> advance the counters), cached per window
+// signature, and a window is num_timesteps replays of it (BASELINE configs[4]).
+__global__ void win_set_kernel(long long* t, unsigned long long* rng, int B, long long t_start, unsigned long long seed,
+                               unsigned long long offset) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) t[b] = t_start;
+    if (b == 0) { rng[0] = seed; rng[1] = offset; }
+}
+
+__global__ void win_advance_kernel(long long* t, unsigned long long* rng, int B, unsigned long long draws) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) t[b] -= 1;
+    if (b == 0) rng[1] += draws;
+}
+
+int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, const float* obs, const float* lat,
+                    const float* km, const long long* fidx, int obs_mode, int sampler, int clip, float eta,
+                    unsigned long long seed, unsigned long long offset, long long t_start, void* stream) {
+    int rc = check_ready(e, B, T);
+    if (rc) return rc;
+    VD_REQUIRE(e->d_tab, "vd_set_schedule not called");
+    VD_REQUIRE(x && obs_src && obs && lat && km && fidx, "null tensor");
+    VD_REQUIRE(obs_mode == 0 || obs_mode == 1, "the window executor keeps observed frames fixed (x_0) or reads them from x (x_t); "
+               "x_t_minus_1 is re-drawn by the host every step");
+    VD_REQUIRE(sampler == 0 || sampler == 1, "sampler: 0 p_sample, 1 ddim_sample");
+    VD_REQUIRE(t_start >= 0 && t_start < e->num_timesteps, "t_start outside the schedule");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VD_REQUIRE(st != nullptr, "the window executor captures a hipGraph: it needs a non-default stream");
+    if ((rc = e->ensure_ws(B, T))) return rc;
+    if (B > e->win_t_cap) {
+        if (e->d_win_t) VD_HIP(hipFree(e->d_win_t));
+        e->d_win_t = nullptr; e->win_t_cap = 0;
+        VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_win_t), (size_t)B * sizeof(long long)));
+        e->win_t_cap = B;
+        for (auto& g : e->win_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+        e->win_graphs.clear();                                  // captured graphs hold the old counter address
+    }
+    if (!e->d_win_rng) VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_win_rng), 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(win_set_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->d_win_t, e->d_win_rng, B, t_start, seed, offset);
+    VD_HIP(hipGetLastError());
+    vd_engine::WinKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.B = B; key.T = T; key.obs_mode = obs_mode; key.sampler = sampler; key.clip = clip; key.eta = eta;
+    key.x = x; key.obs_src = obs_src; key.obs = obs; key.lat = lat; key.km = km; key.fidx = fidx;
+    e->win_cur = -1;
+    e->win_left = t_start + 1;
+    for (size_t i = 0; i < e->win_graphs.size(); ++i)
+        if (e->win_graphs[i].key == key) { e->win_cur = (int)i; return 0; }
+    // A new signature.  Everything a launch needs lazily (kernel attributes, CU count, the workspace) is set up by one
+    // eager forward into the eps scratch before the capture; x is not touched by it.
+    {
+        float* tm = reinterpret_cast<float*>(e->ws + e->ws_tail);
+        float* eps = reinterpret_cast<float*>(e->ws + e->ws_tail + (((size_t)B * sizeof(float) + 255) & ~(size_t)255));
+        hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(e->d_win_t),
+                           e->d_tmap, e->rescale, B, e->num_timesteps, tm, e->d_err);
+        Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
+        FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
+        if ((rc = e->forward(fi, st, ar))) return rc;
+        VD_HIP(hipStreamSynchronize(st));
+    }
+    const bool prof = g_prof.on;
+    g_prof.on = false;                                          // no event records inside a capture
+    const size_t per = (size_t)T * 3 * e->cfg.image_size * e->cfg.image_size;
+    VD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    rc = step_launches(e, sampler, B, T, x, obs_src, obs, lat, km, fidx, e->d_win_t, obs_mode, clip, eta, nullptr, 0, 0,
+                       e->d_win_rng, x, nullptr, nullptr, nullptr, st);
+    if (!rc) {
+        hipLaunchKernelGGL(win_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->d_win_t, e->d_win_rng, B,
+                           (unsigned long long)B * per);
+        if (hipGetLastError() != hipSuccess) { set_error("win_advance_kernel launch"); rc = -2; }
+    }
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(st, &graph);
+    g_prof.on = prof;
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) { set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); return -2; }
+    hipGraphExec_t exec = nullptr;
+    VD_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    e->win_graphs.push_back(vd_engine::WinGraph{key, graph, exec});
+    e->win_cur = (int)e->win_graphs.size() - 1;
+    return 0;
+}
+
+int vd_window_run(vd_engine* e, int n_steps, void* stream) {
+    VD_REQUIRE(e && e->win_cur >= 0, "vd_window_begin first");
+    VD_REQUIRE(n_steps >= 0 && n_steps <= e->win_left, "more steps than the window has left (t would pass 0)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < n_steps; ++i) VD_HIP(hipGraphLaunch(e->win_graphs[e->win_cur].exec, st));
+    e->win_left -= n_steps;
+    return 0;
+}
+
+int vd_window_graphs(vd_engine* e) { return e ? (int)e->win_graphs.size() : -1; }
 
 int vd_p_sample(vd_engine* e, int B, int T, const float* x, const float* obs_src, const float* obs, const float* lat,
                 const float* km, const long long* fidx, const long long* t, int obs_mode, int clip, const float* noise,
@@ -1052,7 +1225,7 @@ int vd_posterior_update(vd_engine* e, int mode, int B, long long per, const floa
     VD_REQUIRE(e && e->d_tab, "vd_set_schedule not called");
     VD_REQUIRE(x && eps && t && sample && (mode == 0 || mode == 1), "arguments");
     PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
-                     mode, eta, seed, offset, sample, xstart};
+                     mode, eta, seed, offset, sample, xstart, nullptr, nullptr};
     return launch_posterior(pa, static_cast<hipStream_t>(stream));
 }
 

@@ -1,4 +1,6 @@
 // Small HBM-bound kernels around the UNet torso and the per-step posterior update, gfx950.
+#include <algorithm>
+
 #include "vd_common.h"
 
 namespace vd {
@@ -269,13 +271,15 @@ int launch_randn(float* out, long n, unsigned long long seed, unsigned long long
 // Coefficients are float32 casts of the float64 tables, exactly what _extract_into_tensor yields.
 __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
     const size_t total = (size_t)a.B * a.per;
+    if (a.dstate) { a.seed = a.dstate[0]; a.offset = a.dstate[1]; }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int b = (int)(i / a.per);
         const long long tl = a.t[b];
         const int NT = a.num_timesteps;
         if (tl < 0 || tl >= NT) {                // the reference raises IndexError (_extract_into_tensor); no table read here:
-            a.sample[i] = __builtin_nanf("");    // the element is poisoned and map_t_kernel has set the engine's error flag
+            if (a.sample) a.sample[i] = __builtin_nanf("");   // the element is poisoned and map_t_kernel has set the error flag
             if (a.xstart) a.xstart[i] = __builtin_nanf("");
+            if (a.mean) a.mean[i] = __builtin_nanf("");
             continue;
         }
         const int t = (int)tl;
@@ -283,6 +287,9 @@ __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
         const float x = a.x[i], e = a.eps[i];
         float x0 = tb[TAB_SQRT_RECIP * NT] * x - tb[TAB_SQRT_RECIPM1 * NT] * e;
         if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        if (a.xstart) a.xstart[i] = x0;
+        if (a.mean) a.mean[i] = tb[TAB_COEF1 * NT] * x0 + tb[TAB_COEF2 * NT] * x;
+        if (!a.sample) continue;                 // p_mean_variance only
         const float z = a.noise ? a.noise[i] : normal_at(a.seed, a.offset, i);
         const float nz = t != 0 ? 1.0f : 0.0f;
         float smp;
@@ -297,7 +304,6 @@ __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
             smp = mean + nz * sigma * z;
         }
         a.sample[i] = smp;
-        if (a.xstart) a.xstart[i] = x0;
     }
 }
 
@@ -326,6 +332,120 @@ int launch_q_sample(const float* x0, const float* noise, const int64_t* t, const
     const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(q_sample_kernel, dim3(grid), dim3(256), 0, s, x0, noise, t, tab, num_timesteps, (size_t)per,
                        total, out);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ NLL terms (gaussian_diffusion.py:750-790, losses.py)
+__device__ __forceinline__ float approx_std_normal_cdf(float x) {          // losses.py:38-43
+    return 0.5f * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+
+// grid (nblk, B): block (k, b) sums its slice of batch element b; thread-local and cross-thread sums in fp64, one partial
+// triple per block (deterministic: no atomics), folded by vb_final_kernel.
+__global__ __launch_bounds__(256) void vb_terms_kernel(VbArgs a) {
+    const int b = blockIdx.y;
+    const long long tl = a.t[b];
+    const int NT = a.num_timesteps;
+    const bool ok = tl >= 0 && tl < NT;
+    const int t = ok ? (int)tl : 0;
+    const float* tb = a.tab + t;
+    const float sr = tb[TAB_SQRT_RECIP * NT], srm1 = tb[TAB_SQRT_RECIPM1 * NT], c1 = tb[TAB_COEF1 * NT], c2 = tb[TAB_COEF2 * NT];
+    const float lv = tb[TAB_LOGVAR * NT], tlv = tb[TAB_POST_LOGVAR * NT];
+    const float inv_stdv = expf(-0.5f * lv), e_dlv = expf(tlv - lv), e_mlv = expf(-lv);
+    const long fsz = a.per / a.T;
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < a.per; j += (long)gridDim.x * 256) {
+        const size_t i = (size_t)b * a.per + j;
+        const float xs = a.x_start[i], xt = a.x_t[i];
+        float x0 = sr * xt - srm1 * a.eps[i];
+        if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        if (a.pred_xstart) a.pred_xstart[i] = ok ? x0 : __builtin_nanf("");
+        const float mean = c1 * x0 + c2 * xt, tmean = c1 * xs + c2 * xt;
+        const float m = a.mask ? a.mask[(size_t)b * a.T + j / fsz] : 1.0f;
+        float term;
+        if (t == 0) {                                                      // decoder NLL (losses.py:46-76)
+            const float cx = xs - mean;
+            const float cdf_plus = approx_std_normal_cdf(inv_stdv * (cx + 1.0f / 255.0f));
+            const float cdf_min = approx_std_normal_cdf(inv_stdv * (cx - 1.0f / 255.0f));
+            const float lp = xs < -0.999f ? logf(fmaxf(cdf_plus, 1e-12f))
+                           : xs > 0.999f ? logf(fmaxf(1.0f - cdf_min, 1e-12f)) : logf(fmaxf(cdf_plus - cdf_min, 1e-12f));
+            term = -lp;
+        } else {                                                           // KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) (losses.py:13-35)
+            const float d = tmean - mean;
+            term = 0.5f * (-1.0f + lv - tlv + e_dlv + d * d * e_mlv);
+        }
+        s0 += (double)(term * m);
+        const float dx = x0 - xs;
+        s1 += (double)(dx * dx * m);
+        if (a.noise) {
+            const float e2 = (sr * xt - x0) / srm1 - a.noise[i];           // _predict_eps_from_xstart (gaussian_diffusion.py:392-396)
+            s2 += (double)(e2 * e2 * m);
+        }
+    }
+    __shared__ double red[3][256];
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) a.part[((size_t)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = ok ? red[threadIdx.x][0] : __builtin_nan("");
+}
+
+__global__ void vb_final_kernel(const double* part, int nblk, double per, float* vb, float* xstart_mse, float* mse, float scale0) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (int)gridDim.x * (int)blockDim.x) return;
+    double s[3] = {0, 0, 0};
+    for (int k = 0; k < nblk; ++k)
+        for (int q = 0; q < 3; ++q) s[q] += part[((size_t)b * nblk + k) * 3 + q];
+    if (vb) vb[b] = (float)(s[0] / per) * scale0;                           // mean_flat(...) / ln 2
+    if (xstart_mse) xstart_mse[b] = (float)(s[1] / per);
+    if (mse) mse[b] = (float)(s[2] / per);
+}
+
+int vb_terms_blocks(long per) { return (int)std::max<long>(1, std::min<long>(64, (per + 256 * 16 - 1) / (256 * 16))); }
+
+int launch_vb_terms(const VbArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(vb_terms_kernel, dim3(a.nblk, a.B), dim3(256), 0, s, a);
+    VD_HIP(hipGetLastError());
+    hipLaunchKernelGGL(vb_final_kernel, dim3(a.B), dim3(1), 0, s, a.part, a.nblk, (double)a.per, a.vb, a.xstart_mse,
+                       a.noise ? a.mse : nullptr, 1.4426950408889634f);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void prior_bpd_kernel(const float* x_start, const float* mask, const float* tab, int NT, int T,
+                                                        long per, double* part) {
+    const int b = blockIdx.y;
+    const float sa = tab[TAB_SQRT_ACP * NT + NT - 1], lv = tab[TAB_LOG_1M_ACP * NT + NT - 1];
+    const float ev = expf(lv);
+    const long fsz = per / T;
+    double s0 = 0;
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < per; j += (long)gridDim.x * 256) {
+        const float mu = sa * x_start[(size_t)b * per + j];
+        const float m = mask ? mask[(size_t)b * T + j / fsz] : 1.0f;
+        s0 += (double)(0.5f * (-1.0f - lv + ev + mu * mu) * m);              // normal_kl(mean, logvar, 0, 0)
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = s0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* p = part + ((size_t)b * gridDim.x + blockIdx.x) * 3;
+        p[0] = red[0]; p[1] = 0; p[2] = 0;
+    }
+}
+
+int launch_prior_bpd(const float* x_start, const float* mask, const float* tab, int num_timesteps, int B, int T, long per,
+                     double* part, int nblk, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(prior_bpd_kernel, dim3(nblk, B), dim3(256), 0, s, x_start, mask, tab, num_timesteps, T, per, part);
+    VD_HIP(hipGetLastError());
+    hipLaunchKernelGGL(vb_final_kernel, dim3(B), dim3(1), 0, s, part, nblk, (double)per, out, nullptr, nullptr, 1.4426950408889634f);
     VD_HIP(hipGetLastError());
     return 0;
 }

@@ -205,7 +205,9 @@ struct PosteriorArgs {
     int mode;            // 0: p_sample, 1: ddim
     float eta;
     unsigned long long seed, offset;
-    float* sample; float* xstart;   // outputs (xstart may be null)
+    float* sample; float* xstart;   // outputs (either may be null; sample may alias x: the update is elementwise)
+    float* mean;                    // p_mean_variance's 'mean' (posterior mean of the clipped x0 prediction), or null
+    const unsigned long long* dstate;   // window executor: {seed, offset} read from device memory instead of the arguments
 };
 int launch_posterior(const PosteriorArgs& a, hipStream_t s);
 int launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab, int num_timesteps, int B,
@@ -213,7 +215,27 @@ int launch_q_sample(const float* x0, const float* noise, const int64_t* t, const
 int launch_randn(float* out, long n, unsigned long long seed, unsigned long long offset, hipStream_t s);
 
 enum { TAB_SQRT_RECIP = 0, TAB_SQRT_RECIPM1, TAB_COEF1, TAB_COEF2, TAB_LOGVAR, TAB_ACP, TAB_ACP_PREV,
-       TAB_SQRT_ACP, TAB_SQRT_1M_ACP, NTAB };
+       TAB_SQRT_ACP, TAB_SQRT_1M_ACP, TAB_POST_LOGVAR, TAB_LOG_1M_ACP, NTAB };
+
+// _vb_terms_bpd + the two MSEs of calc_bpd_loop_subsampled's loop body (gaussian_diffusion.py:750-790, 975-990), given eps
+struct VbArgs {
+    const float* x_start; const float* x_t; const float* eps;
+    const float* noise;          // for mse = mean((eps_from_xstart - noise)^2); null: not computed
+    const int64_t* t;            // [B]
+    const float* tab; int num_timesteps;
+    const float* mask;           // [B*T] latent_mask or null (mean_flat(..., mask): multiply, then mean over ALL elements)
+    int B, T; long per;          // per = T*3*H*W
+    int clip;
+    float* pred_xstart;          // optional output
+    double* part;                // [B][nblk][3] partial sums
+    int nblk;
+    float* vb; float* xstart_mse; float* mse;      // [B] outputs (the last two may be null)
+};
+int launch_vb_terms(const VbArgs& a, hipStream_t s);
+int vb_terms_blocks(long per);
+// _prior_bpd (gaussian_diffusion.py:909-926): KL(q(x_T | x_0) || N(0, I)) in bits per dim, masked mean
+int launch_prior_bpd(const float* x_start, const float* mask, const float* tab, int num_timesteps, int B, int T, long per,
+                     double* part, int nblk, float* out, hipStream_t s);
 
 // x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (each <= 1 ulp): 5 VALU instructions instead of the ~15 of an IEEE
 // division.  The operand transform of the conv kernels runs this on every staged input element.

@@ -6,7 +6,10 @@ method); the float64 schedule tables are built here with numpy exactly as the
 reference does and uploaded once (as their float32 casts, which is what
 `_extract_into_tensor`, gaussian_diffusion.py:1019-1031, feeds the arithmetic),
 and every tensor operation of a step runs in the HIP engine behind the C ABI.
-Training losses / bpd / gradient guidance are out of scope.
+The NLL path (`p_mean_variance`, `_vb_terms_bpd`, `_prior_bpd`, `calc_bpd_loop_subsampled`) runs on
+the engine as well: one UNet forward per timestep plus one fused likelihood kernel (csrc/misc.hip: vb_terms_kernel
+restates losses.py's normal_kl / discretized_gaussian_log_likelihood).  Training losses and gradient guidance
+(`use_gradient_method`: a UNet backward w.r.t. the input) are out of scope.
 """
 import enum
 import math
@@ -108,7 +111,8 @@ class GaussianDiffusion:
     def _device_tables(self):
         rows = [self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
                 self.posterior_mean_coef2, self._model_log_variance(), self.alphas_cumprod,
-                self.alphas_cumprod_prev, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod]
+                self.alphas_cumprod_prev, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod,
+                self.posterior_log_variance_clipped, self.log_one_minus_alphas_cumprod]
         return np.ascontiguousarray(np.stack(rows).astype(np.float32))
 
     def _timestep_map_and_scale(self):
@@ -173,6 +177,121 @@ class GaussianDiffusion:
                                   _lib.current_stream())
         _lib.check(rc)
         return sample, xstart
+
+    def _extract(self, arr, t, shape):
+        """_extract_into_tensor (gaussian_diffusion.py:1019-1031): float64 table gathered at t, cast to float32,
+        broadcast to `shape` (tensor plumbing: a gather and a view)."""
+        res = th.from_numpy(np.asarray(arr)).to(device=t.device)[t].float()
+        while len(res.shape) < len(shape):
+            res = res[..., None]
+        return res.expand(shape)
+
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None,
+                        return_attn_weights=False, use_gradient_method=False):
+        """gaussian_diffusion.py:229-372 -> {'mean', 'variance', 'log_variance', 'pred_xstart', 'attn'} (+ 'eps', the raw
+        model output, which the NLL loop reuses)."""
+        if denoised_fn is not None:
+            raise NotImplementedError("denoised_fn is not supported by the fused HIP step")
+        if use_gradient_method:
+            raise NotImplementedError("use_gradient_method needs a UNet backward pass (out of scope, SURVEY.md 8f-4)")
+        if return_attn_weights:
+            raise NotImplementedError("return_attn_weights (wandb visualisation) is not supported")
+        model = self._bind(model)
+        B = x.shape[0]
+        assert t.shape == (B,)
+        if t.device.type == "cpu" and B and (int(t.min()) < 0 or int(t.max()) >= self.num_timesteps):
+            raise IndexError(f"index {int(t.max())} is out of bounds for dimension 0 with size {self.num_timesteps}")
+        dev = model.device
+        xs = _f32(x, dev)
+        kw = model._pack_kwargs(xs, model_kwargs or {})
+        tt = t.to(device=dev, dtype=th.int64).contiguous()
+        mean, xstart, eps = th.empty_like(xs), th.empty_like(xs), th.empty_like(xs)
+        _lib.check(_lib.lib().vd_p_mean_variance(
+            model._handle, B, xs.shape[1], _lib.ptr(xs), _lib.ptr(kw["obs_src"]), _lib.ptr(kw["obs_mask"]),
+            _lib.ptr(kw["latent_mask"]), _lib.ptr(kw["kinda_marg_mask"]), _lib.ptr(kw["frame_indices"]), _lib.ptr(tt),
+            kw["obs_mode"], 1 if clip_denoised else 0, _lib.ptr(mean), _lib.ptr(xstart), _lib.ptr(eps), _lib.current_stream()))
+        logvar = self._model_log_variance()
+        variance = self.posterior_variance if self.model_var_type == ModelVarType.FIXED_SMALL \
+            else np.append(self.posterior_variance[1], self.betas[1:])             # gaussian_diffusion.py:299-317
+        return {"mean": mean, "variance": self._extract(variance, tt, xs.shape),
+                "log_variance": self._extract(logvar, tt, xs.shape), "pred_xstart": xstart, "attn": None, "eps": eps}
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        """gaussian_diffusion.py:208-227 (host composition of schedule rows; the samplers fuse it in posterior_kernel)."""
+        assert x_start.shape == x_t.shape
+        mean = self._extract(self.posterior_mean_coef1, t, x_t.shape) * x_start + self._extract(self.posterior_mean_coef2, t, x_t.shape) * x_t
+        return mean, self._extract(self.posterior_variance, t, x_t.shape), self._extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    # -- NLL path (scripts/video_nll.py) -------------------------------------------------------------
+    def _nll_mask(self, latent_mask, B, T, dev):
+        if latent_mask is None:
+            return None
+        m = _f32(latent_mask, dev).reshape(B, -1)
+        assert m.shape[1] == T, "latent_mask is per frame: (B, T, 1, 1, 1)"
+        return m.contiguous()
+
+    def _vb_terms_bpd(self, model, x_start, x_t, t, clip_denoised=True, model_kwargs=None, latent_mask=None, _noise=None):
+        """gaussian_diffusion.py:750-790 -> {'output': [N] bits/dim, 'pred_xstart'} (+ the two MSEs of
+        calc_bpd_loop_subsampled when the noise x_t was drawn with is passed)."""
+        model = self._bind(model)
+        dev = model.device
+        xs, xt = _f32(x_start, dev), _f32(x_t, dev)
+        B, T = xs.shape[:2]
+        out = self.p_mean_variance(model, xt, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs)
+        tt = t.to(device=dev, dtype=th.int64).contiguous()
+        m = self._nll_mask(latent_mask, B, T, dev)
+        nz = _f32(_noise, dev) if _noise is not None else None
+        vb, xmse, mse = (th.empty(B, device=dev, dtype=th.float32) for _ in range(3))
+        _lib.check(_lib.lib().vd_vb_terms(model._handle, B, T, _lib.ptr(xs), _lib.ptr(xt), _lib.ptr(out["eps"]), _lib.ptr(nz),
+                                          _lib.ptr(tt), 1 if clip_denoised else 0, _lib.ptr(m), _lib.ptr(vb), _lib.ptr(xmse),
+                                          _lib.ptr(mse) if nz is not None else None, None, _lib.current_stream()))
+        res = {"output": vb, "pred_xstart": out["pred_xstart"], "xstart_mse": xmse}
+        if nz is not None:
+            res["mse"] = mse
+        return res
+
+    def _prior_bpd(self, x_start, latent_mask=None, model=None):
+        """gaussian_diffusion.py:909-926."""
+        model = self._bind(model if model is not None else self._last_model())
+        dev = model.device
+        xs = _f32(x_start, dev)
+        B, T = xs.shape[:2]
+        m = self._nll_mask(latent_mask, B, T, dev)
+        out = th.empty(B, device=dev, dtype=th.float32)
+        _lib.check(_lib.lib().vd_prior_bpd(model._handle, B, T, _lib.ptr(xs), _lib.ptr(m), _lib.ptr(out), _lib.current_stream()))
+        return out
+
+    def calc_bpd_loop_subsampled(self, model, x_start, clip_denoised=True, model_kwargs=None, latent_mask=None, t_seq=None):
+        """gaussian_diffusion.py:928-1002 -> {'total_bpd','prior_bpd','vb','xstart_mse','mse'}; t_seq may be a list of
+        timesteps or a 2-D array with one row of timesteps per batch item."""
+        base = self._bind(model)
+        self._model_hint = base
+        dev = base.device
+        xs = _f32(x_start, dev)
+        B = xs.shape[0]
+        if t_seq is None:
+            t_seq = list(range(self.num_timesteps))[::-1]
+        two_d = isinstance(t_seq, np.ndarray) and t_seq.ndim == 2
+        if two_d:
+            t_seq = t_seq.transpose()
+        vb, xstart_mse, mse = [], [], []
+        for t in t_seq:
+            t_batch = th.tensor(t, device=dev) if two_d else th.tensor([t] * B, device=dev)
+            noise = th.randn_like(xs)
+            x_t = self.q_sample(xs, t_batch, noise=noise, model=base)
+            out = self._vb_terms_bpd(model, x_start=xs, x_t=x_t, t=t_batch, clip_denoised=clip_denoised,
+                                     model_kwargs=model_kwargs, latent_mask=latent_mask, _noise=noise)
+            vb.append(out["output"])
+            xstart_mse.append(out["xstart_mse"])
+            mse.append(out["mse"])
+        vb, xstart_mse, mse = th.stack(vb, dim=1), th.stack(xstart_mse, dim=1), th.stack(mse, dim=1)
+        prior_bpd = self._prior_bpd(xs, latent_mask=latent_mask, model=base)
+        return {"total_bpd": vb.sum(dim=1) + prior_bpd, "prior_bpd": prior_bpd, "vb": vb, "xstart_mse": xstart_mse, "mse": mse}
+
+    def calc_bpd_loop(self, model, x_start, clip_denoised=True, model_kwargs=None, latent_mask=None):
+        """gaussian_diffusion.py:1004-1016."""
+        return self.calc_bpd_loop_subsampled(model, x_start, clip_denoised=clip_denoised, model_kwargs=model_kwargs,
+                                             latent_mask=latent_mask)
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                  return_attn_weights=False, use_gradient_method=False):

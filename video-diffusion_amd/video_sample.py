@@ -39,8 +39,13 @@ def get_masks(x0, num_obs):
 
 @torch.no_grad()
 def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size=1, optimal_schedule_path=None, *,
-                use_gradient_method=False, observed_frames="x_0", sampler="p_sample", eta=0.0):
-    """video_sample.py:50-190 (non-adaptive modes).  Returns (samples ndarray (B,T,C,H,W), None)."""
+                use_gradient_method=False, observed_frames="x_0", sampler="p_sample", eta=0.0, executor="graph"):
+    """video_sample.py:50-190 (non-adaptive modes).  Returns (samples ndarray (B,T,C,H,W), None).
+
+    executor='graph' (default): each window's step loop runs on the window executor -- one captured hipGraph per window
+    shape, step index and noise counter on the device (executor.py).  executor='eager': one `diffusion.p_sample` call
+    per step from the host with `th.randn_like` noise, the reference's own loop (needed to replay a recorded noise
+    sequence, and for observed_frames='x_t_minus_1')."""
     if "adaptive" in mode:
         raise NotImplementedError(f"inference mode {mode!r} needs the LPIPS network (out of scope)")
     B, T, C, H, W = batch.shape
@@ -54,6 +59,12 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
         optimal_schedule_path=optimal_schedule_path))
     timesteps = list(range(diffusion.num_timesteps))[::-1]
     t_tensors = None
+    use_graph = executor == "graph" and observed_frames in ("x_0", "x_t") and not use_gradient_method
+    if use_graph:
+        from .executor import WindowExecutor
+        wex = getattr(model, "_window_executor", None)
+        if wex is None or wex.diffusion is not diffusion:
+            wex = model._window_executor = WindowExecutor(model, diffusion)
     for obs_frame_indices, latent_frame_indices in schedule:
         logger.info(f"Conditioning on {sorted(obs_frame_indices)} frames, predicting {sorted(latent_frame_indices)}.")
         x0 = torch.cat([samples[:, obs_frame_indices], samples[:, latent_frame_indices]], dim=1).clone()
@@ -67,6 +78,10 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
                             kinda_marg_mask=kinda_marg_mask, x_t_minus_1=x0, observed_frames=observed_frames)
         if t_tensors is None:          # the reference re-creates this tensor every step (video_sample.py:154-155)
             t_tensors = [torch.tensor([ts] * B, device=device) for ts in range(diffusion.num_timesteps)]
+        if use_graph:
+            local_samples = wex.sample_window(x0, model_kwargs, sampler=sampler, eta=eta)
+            samples[:, latent_frame_indices] = local_samples[:, -n_latent:].cpu()
+            continue
         local_samples = x0.clone()
         for timestep in timesteps:
             if sampler == "p_sample":
@@ -140,6 +155,8 @@ def main(argv=None):
     ap.add_argument("--num_channels", type=int, default=128)
     ap.add_argument("--num_res_blocks", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--executor", default="graph", choices=["graph", "eager"],
+                    help="graph: one captured hipGraph per window shape (executor.py); eager: one p_sample call per step")
     ap.add_argument("--out_dir", default="results/synthetic")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
@@ -155,7 +172,7 @@ def main(argv=None):
         g = torch.Generator().manual_seed(1234 + task)
         batch = torch.rand(len(idx), args.T, 3, args.image_size, args.image_size, generator=g) * 2 - 1
         recon, _ = infer_video(args.inference_mode, model, diffusion, batch, args.max_frames, args.obs_length,
-                               args.step_size, observed_frames=args.observed_frames)
+                               args.step_size, observed_frames=args.observed_frames, executor=args.executor)
         for p in save_samples(recon, args.out_dir, first_index=idx[0]):
             logger.info(f"*** Saved {p} ***")
     vdist.barrier()
