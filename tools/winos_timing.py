@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from video_diffusion_amd import _lib  # noqa: E402
 
-SHAPES = [(128, 128, 128, 64), (128, 256, 256, 32), (128, 640, 256, 32), (128, 384, 384, 16), (128, 512, 512, 8), (128, 1024, 512, 8)]
+SHAPES = [(128, 128, 128, 64), (128, 256, 128, 64), (128, 384, 128, 64), (128, 256, 256, 32), (128, 640, 256, 32), (128, 384, 384, 16), (128, 512, 512, 8), (128, 1024, 512, 8)]
 L = _lib.lib()
 S64 = True
 stamps = L.vd_debug_s64_stamps

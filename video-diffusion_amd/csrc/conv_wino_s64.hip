@@ -43,7 +43,7 @@ struct WinoS64Geom { int TF, tiles_x, tiles_y, nbx, ncb, nitems, cob_inner; };
 __device__ unsigned long long g_s64_stamp[10];
 #define S64_STAMP(i)                                                                                                   \
     do {                                                                                                               \
-        if (threadIdx.x == 0 && blockIdx.x == 0 && s64_first) {                                                        \
+        if (threadIdx.x == 0 && blockIdx.x == 7 && s64_first) {                                                        \
             g_s64_stamp[i] = __builtin_readcyclecounter();                                                             \
             if (i == 0) g_s64_stamp[8] = __builtin_amdgcn_s_memrealtime();                                             \
             if (i == 3) g_s64_stamp[9] = __builtin_amdgcn_s_memrealtime();                                             \
@@ -88,8 +88,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
     const int tid = threadIdx.x, lane = tid & 63;
     const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);          // Winograd row owned by this wave (scalar)
     const int lr = lane & 31, lh = lane >> 5;
-    [[maybe_unused]] bool s64_first = true;
-    S64_STAMP(0);
+    // timing builds stamp the phases of ONE steady-state item: the (VD_S64_STAMP_ITEM+1)-th item of block 7
+#ifndef VD_S64_STAMP_ITEM
+#define VD_S64_STAMP_ITEM 3
+#endif
+    [[maybe_unused]] bool s64_first = false;
+    [[maybe_unused]] int s64_item = 0;
     const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
     const int nchunk = a.Cin >> 4, ncoblk = a.Cout >> 5;
     // work items: (tile block, frame group) fastest, cout block slowest; a block walks items blockIdx.x, +gridDim.x, ...
@@ -295,6 +299,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
         (void)nj; (void)nm;
     };
     for (int it = blockIdx.x; it < g.nitems; it += gridDim.x) {
+#ifdef VD_WINO_TIMING
+        s64_first = s64_item++ == VD_S64_STAMP_ITEM;
+        S64_STAMP(0);
+#endif
         const int itn = it + (int)gridDim.x < g.nitems ? it + (int)gridDim.x : it;   // no next item: its own again (unused)
         // weights of chunk 0: requested here, not under the previous item's output transform -- 96 live registers there
         // made the compiler spill; they come from L2
@@ -467,7 +475,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_s64_kernel(IgemmArgs a, W
             if (n == 0) S64_STAMP(6);
         }
         S64_STAMP(3);
-        s64_first = false;
     }
 }
 
