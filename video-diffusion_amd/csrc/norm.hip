@@ -25,8 +25,23 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const float* __restrict_
     if (c < C0) { base = src0; cc = c; ld = C0; } else { base = src1; cc = c - C0; ld = C - C0; }
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     if (pl < ppi) {
-        for (int p = p_begin + pl; p < p_end; p += ppi) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((size_t)n * HW + p) * ld + cc);
+        // four independent 16-byte loads in flight per thread (one per iteration left the kernel latency-bound at
+        // ~3 TB/s); every term goes through fp64 (a common offset 1e4 times the spread must not destroy
+        // E[x^2] - E[x]^2: tests/test_gpu_ops.py::test_groupnorm_fold_large_mean)
+        const float* src = base + (size_t)n * HW * ld + cc;
+        int p = p_begin + pl;
+        for (; p + 3 * ppi < p_end; p += 4 * ppi) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(p + u * ppi) * ld);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const double d = (double)v[u][e]; s[e] += d; ss[e] += d * d; }
+            }
+        }
+        for (; p < p_end; p += ppi) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * ld);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s[e] += v[e]; ss[e] += (double)v[e] * v[e]; }
         }
@@ -185,6 +200,56 @@ template <int TMAX>
 __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int T, int HW, int C,
                                                           float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) double sred[];   // [thread][2]: per-thread (4 channels x T) partial sums
+    const int tpp = C >> 2, ppb = 256 / tpp;
+    const int tid = threadIdx.x;
+    const int pl = tid / tpp, q = tid - pl * tpp;
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * ppb + pl;
+    const bool active = pl < ppb && p < HW;
+    f32x4 v[TMAX];
+    double ps = 0, pss = 0;                       // this thread's share of its group: 4 channels x T frames
+    const int cg = C / 32, tpg = cg >> 2;        // channels per group (a multiple of 4), threads per group
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) v[t] = *reinterpret_cast<const f32x4*>(x + (((size_t)b * T + t) * HW + p) * C + q * 4);
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double d = (double)v[t][e]; ps += d; pss += d * d; }
+            }
+        sred[(size_t)tid * 2] = ps;
+        sred[(size_t)tid * 2 + 1] = pss;
+    }
+    __syncthreads();
+    if (!active) return;
+    const double cnt = (double)cg * T;
+    double gs = 0, gss = 0;
+    const int g0 = tid - (q % tpg);              // first thread of this thread's group (same pixel slot)
+    for (int k = 0; k < tpg; ++k) { gs += sred[(size_t)(g0 + k) * 2]; gss += sred[(size_t)(g0 + k) * 2 + 1]; }
+    const double mean = gs / cnt;
+    double var = gss / cnt - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    f32x4 A, Bv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = q * 4 + e;
+        A[e] = rstd * gamma[c];
+        Bv[e] = beta[c] - (float)mean * A[e];
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+        if (t < T) *reinterpret_cast<f32x4*>(y + (((size_t)b * T + t) * HW + p) * C + q * 4) = v[t] * A + Bv;
+}
+
+// any channels-per-group count (the tiny test models have 2): every thread folds its channels' groups from a per-channel table
+template <int TMAX>
+__global__ __launch_bounds__(256) void gn_temporal_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int T, int HW, int C,
+                                                          float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) double sred[];   // [ppb][C][2]
     const int tpp = C >> 2, ppb = 256 / tpp;
     const int tid = threadIdx.x;
@@ -239,12 +304,20 @@ int launch_gn_temporal(const float* x, const float* gamma, const float* beta, in
     VD_REQUIRE(C % 32 == 0 && C <= 1024, "GroupNorm32 channel constraints");
     VD_REQUIRE(T >= 1 && T <= 32, "temporal window of 1..32 frames");
     const int ppb = 256 / (C / 4);
-    const size_t lds = (size_t)ppb * C * 2 * sizeof(double);
     dim3 grid((HW + ppb - 1) / ppb, B);
-    if (T <= 16)
-        hipLaunchKernelGGL(gn_temporal_kernel<16>, grid, dim3(256), lds, s, x, gamma, beta, T, HW, C, y);
-    else
-        hipLaunchKernelGGL(gn_temporal_kernel<32>, grid, dim3(256), lds, s, x, gamma, beta, T, HW, C, y);
+    if ((C / 32) % 4 == 0) {                      // a thread's channel quad lies in one group: the fast kernel
+        const size_t lds = (size_t)256 * 2 * sizeof(double);
+        if (T <= 16)
+            hipLaunchKernelGGL(gn_temporal_kernel<16>, grid, dim3(256), lds, s, x, gamma, beta, T, HW, C, y);
+        else
+            hipLaunchKernelGGL(gn_temporal_kernel<32>, grid, dim3(256), lds, s, x, gamma, beta, T, HW, C, y);
+    } else {
+        const size_t lds = (size_t)ppb * C * 2 * sizeof(double);
+        if (T <= 16)
+            hipLaunchKernelGGL(gn_temporal_generic_kernel<16>, grid, dim3(256), lds, s, x, gamma, beta, T, HW, C, y);
+        else
+            hipLaunchKernelGGL(gn_temporal_generic_kernel<32>, grid, dim3(256), lds, s, x, gamma, beta, T, HW, C, y);
+    }
     VD_HIP(hipGetLastError());
     return 0;
 }
