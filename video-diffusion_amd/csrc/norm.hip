@@ -140,57 +140,58 @@ int launch_gn_affine(const double* part0, int split0, int C0, const double* part
 // GroupNorm(+FiLM)+SiLU materialised once for the 3x3 convs.  The conv kernels can apply the same affine + SiLU in their
 // operand load, but every block that touches a pixel then repeats it (Cout/64 column blocks x the halo overlap: 2.5x to
 // 12x), and on gfx950 VALU work does not hide behind fp32 MFMAs (tools/mfma_peak.hip): one HBM-bound pass is cheaper.
+// grid (pixel ranges, frames); thread -> a fixed channel quad of the (virtually concatenated) tensor and every ppi-th pixel
+// of its block's range, so the source pointer, the concat side and the (A, B) pair are per-thread constants: the loop is
+// one 16-byte load, 4 fma + 4 SiLU, one 16-byte store.  (The first version walked a flat index with two 64-bit divisions
+// per element: ~108 VALU per 16 bytes, which rocprofv3 showed to be the bound -- 5.3 TB/s -- not the memory.)
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ src0, const float* __restrict__ src1,
-                                                         int C0_4, int C4, const float* __restrict__ affA,
-                                                         const float* __restrict__ affB, int HW, size_t total4, int act,
+                                                         int C0, int C, const float* __restrict__ affA,
+                                                         const float* __restrict__ affB, int HW, int per, int act,
                                                          float* __restrict__ y) {
-    const int C1_4 = C4 - C0_4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const size_t pix = i / (unsigned)C4;
-        const int c4 = (int)(i - pix * C4);
-        const size_t n = pix / (unsigned)HW;
-        const f32x4 v = c4 < C0_4 ? reinterpret_cast<const f32x4*>(src0)[pix * C0_4 + c4]
-                                  : reinterpret_cast<const f32x4*>(src1)[pix * C1_4 + (c4 - C0_4)];
-        const f32x4 A = reinterpret_cast<const f32x4*>(affA)[n * C4 + c4];
-        const f32x4 B = reinterpret_cast<const f32x4*>(affB)[n * C4 + c4];
+    const int n = blockIdx.y;
+    const int tpp = C >> 2, ppi = blockDim.x / tpp;       // blockDim.x is a multiple of tpp (launch_affine_act)
+    const int tid = threadIdx.x;
+    const int pl = tid / tpp, c = (tid - pl * tpp) * 4;
+    const int p_begin = blockIdx.x * per, p_end = min(HW, p_begin + per);
+    const float* src; int ld;
+    if (c < C0) { src = src0 + (size_t)n * HW * C0 + c; ld = C0; } else { src = src1 + (size_t)n * HW * (C - C0) + (c - C0); ld = C - C0; }
+    float* dst = y + (size_t)n * HW * C + c;
+    const f32x4 A = *reinterpret_cast<const f32x4*>(affA + (size_t)n * C + c);
+    const f32x4 B = *reinterpret_cast<const f32x4*>(affB + (size_t)n * C + c);
+    auto one = [&](f32x4 v) {
         f32x4 r = v * A + B;
         if (act) { r.x = silu_f(r.x); r.y = silu_f(r.y); r.z = silu_f(r.z); r.w = silu_f(r.w); }
-        reinterpret_cast<f32x4*>(y)[i] = r;
+        return r;
+    };
+    int p = p_begin + pl;
+    for (; p + 3 * ppi < p_end; p += 4 * ppi) {           // four loads in flight
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(p + u * ppi) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(dst + (size_t)(p + u * ppi) * C) = one(v[u]);
     }
+    for (; p < p_end; p += ppi) *reinterpret_cast<f32x4*>(dst + (size_t)p * C) = one(*reinterpret_cast<const f32x4*>(src + (size_t)p * ld));
 }
 
 int launch_affine_act(const float* src0, const float* src1, int C0, int C, const float* affA, const float* affB, int nfr,
                       int HW, int act, float* y, hipStream_t s) {
-    VD_REQUIRE(C % 4 == 0 && C0 % 4 == 0 && (src1 != nullptr || C0 == C), "affine_act: channel counts");
-    const size_t total4 = (size_t)nfr * HW * C / 4;
-    const int grid = (int)std::min<size_t>((total4 + 255) / 256, 16384);
-    hipLaunchKernelGGL(affine_act_kernel, dim3(grid), dim3(256), 0, s, src0, src1, C0 / 4, C / 4, affA, affB, HW, total4, act, y);
+    VD_REQUIRE(C % 4 == 0 && C0 % 4 == 0 && C <= 1024 && (src1 != nullptr || C0 == C), "affine_act: channel counts");
+    const int tpp = C / 4, ppi = 256 / tpp, threads = ppi * tpp;
+    // pixel ranges: enough blocks to fill the chip (>= 2048), at least 4 iterations of 4 loads per block where the frame allows
+    int split = 1;
+    while (nfr * split < 2048 && HW / (split * 2) >= ppi * 16) split *= 2;
+    const int per = (HW + split - 1) / split;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(split, nfr), dim3(threads), 0, s, src0, src1, C0, C, affA, affB, HW, per, act, y);
     VD_HIP(hipGetLastError());
     return 0;
 }
 
 // ------------------------------------------------------------------ y = x*A[n][c] + B[n][c]
-__global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ x, const float* __restrict__ affA,
-                                                           const float* __restrict__ affB, size_t per_frame4, int C4,
-                                                           size_t total4, float* __restrict__ y) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const size_t n = i / per_frame4;
-        const int c4 = (int)(i % C4);
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-        const f32x4 A = reinterpret_cast<const f32x4*>(affA)[n * C4 + c4];
-        const f32x4 B = reinterpret_cast<const f32x4*>(affB)[n * C4 + c4];
-        reinterpret_cast<f32x4*>(y)[i] = v * A + B;
-    }
-}
-
+// the same pass without the activation (attention blocks: the normalised tensor is also the residual, unet.py:474,538)
 int launch_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y,
                         hipStream_t s) {
-    const size_t total4 = (size_t)nfr * HW * C / 4;
-    const int grid = (int)std::min<size_t>((total4 + 255) / 256, 4096);
-    hipLaunchKernelGGL(affine_apply_kernel, dim3(grid), dim3(256), 0, s, x, affA, affB, (size_t)HW * C / 4, C / 4,
-                       total4, y);
-    VD_HIP(hipGetLastError());
-    return 0;
+    return launch_affine_act(x, nullptr, C, C, affA, affB, nfr, HW, 0, y, s);
 }
 
 // ------------------------------------------------------------------ temporal GroupNorm (unet.py:472-475 on (B*HW, C, T))
