@@ -741,6 +741,9 @@ int vd_engine::ensure_ws(int B, int T) {
     const size_t tm_bytes = ((size_t)B * sizeof(float) + 255) & ~(size_t)255;
     const size_t need = tail + tm_bytes + (size_t)B * T * 3 * cfg.image_size * cfg.image_size * sizeof(float);
     if (need > ws_cap) {
+        // captured window graphs hold addresses inside the old workspace: they die with it
+        for (auto& g : win_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+        win_graphs.clear(); win_cur = -1;
         if (ws) VD_HIP(hipFree(ws));
         ws = nullptr; ws_cap = 0; ws_B = ws_T = 0;
         VD_HIP(hipMalloc(reinterpret_cast<void**>(&ws), need));
