@@ -715,3 +715,56 @@ def test_minerl_windows_default_64_model_properties(Tw, n_obs):
     close(ex.run(1)[0].cpu(), first[0].cpu(), atol=5e-5, rtol=5e-5)
     assert ex.graphs >= 2                                                      # one graph per window shape
     model.check_device_errors()
+
+
+def test_infer_video_adaptive_autoreg_vs_oracle(monkeypatch):
+    """The adaptive branch of scripts/video_sample.py:94-118,176-183: `adaptive-autoreg` with distance='l2' picks the
+    observed frames of every window PER BATCH ITEM from the samples so far, so window tensors are gathered per item and
+    the generated frames scattered back per item.  Against the same loop on the CPU oracle with identical noise draws
+    (the index choices depend on the sampled frames: both sides must make the same ones)."""
+    from video_diffusion_amd import gaussian_diffusion as gdm
+    from video_diffusion_amd import inference_util as iu
+    from video_diffusion_amd.video_sample import get_masks, infer_video
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=4, rp_beta=4, rp_gamma=4, timestep_respacing="ddim5")}
+    model, diff, ora = _oracle(cfg)
+    B, T, obs_len, max_frames, step = 2, 7, 3, 4, 2
+    batch = torch.rand(B, T, 3, 32, 32, generator=torch.Generator().manual_seed(14)) * 2 - 1
+    draws, gen = [], torch.Generator().manual_seed(15)
+
+    def fake_randn_like(x, *a, **k):
+        z = torch.randn(x.shape, generator=gen)
+        draws.append(z)
+        return z.to(x.device)
+
+    monkeypatch.setattr(gdm.th, "randn_like", fake_randn_like)
+    got, _ = infer_video("adaptive-autoreg", model, diff, batch.cuda(), max_frames, obs_len, step, executor="eager",
+                         adaptive_distance="l2")
+    monkeypatch.undo()
+
+    samples = torch.zeros_like(batch)
+    samples[:, :obs_len] = batch[:, :obs_len]
+    sched = iter(iu.inference_strategies["adaptive-autoreg"](distance="l2", video_length=T, num_obs=obs_len,
+                                                             max_frames=max_frames, step_size=step))
+    it, windows = iter(draws), 0
+    while True:
+        sched.set_videos(samples)
+        try:
+            obs_idx, lat_idx = next(sched)
+        except StopIteration:
+            break
+        fi = torch.cat([torch.tensor(obs_idx).reshape(B, -1), torch.tensor(lat_idx).reshape(B, -1)], dim=1)
+        x0 = torch.stack([samples[i, f] for i, f in enumerate(fi)]).clone()
+        om, lm, km = get_masks(x0, len(obs_idx[0]))
+        kw = dict(x0=x0, obs_mask=om, latent_mask=lm, kinda_marg_mask=km, frame_indices=fi)
+        local = x0.clone()
+        for ts in range(diff.num_timesteps)[::-1]:
+            local = ora.p_sample(local, torch.tensor([ts] * B), kw, next(it))["sample"]
+        for i, li in enumerate(lat_idx):
+            samples[i, li] = local[i, len(obs_idx[0]):]
+        windows += 1
+    assert windows == 2 and len(draws) == 2 * 5
+    err = np.abs(got - samples.numpy())
+    assert err.mean() < 2e-4, err.mean()
+    close(got, samples.numpy(), atol=3e-2, rtol=1e-2)
+    assert np.array_equal(got[:, :obs_len], batch[:, :obs_len].numpy())

@@ -214,3 +214,39 @@ def test_remaining_schedulers_match_reference():
     # every non-adaptive mode of the reference registry exists here
     missing = [m for m in rec["modes"] if not m.startswith("adaptive") and m not in iu.inference_strategies]
     assert not missing, missing
+
+
+def test_adaptive_schedulers_match_reference_sequences():
+    """adaptive-autoreg / adaptive-hierarchy-N with distance='l2' (inference_util.py:137-229,421-531): per-item observed
+    lists picked by farthest-point selection on the frames themselves, against what the imported reference produced on
+    the same seeded videos (tools/gen_golden_adaptive.py).  Where the reference never terminates (hierarchy with no
+    observed frames: its backwards search for a finished frame runs below index 0 forever) the mirror raises."""
+    import torch
+    rec = load_json("schedulers_adaptive.json")
+    seen = 0
+    for c in rec["cases"]:
+        T, n_obs, max_frames, step = c["args"]
+        g = torch.Generator().manual_seed(c["seed"])
+        v = torch.rand(c["B"], T, 3, 4, 4, generator=g) * 2 - 1
+        it = iter(inference_strategies[c["mode"]](distance="l2", video_length=T, num_obs=n_obs, max_frames=max_frames,
+                                                  step_size=step, optimal_schedule_path=None))
+        want = c.get("seq", c.get("seq_before_error"))
+        got = []
+        try:
+            while len(got) < 200:
+                it.set_videos(v)
+                try:
+                    obs, lat = next(it)
+                except StopIteration:
+                    break
+                got.append([[[int(i) for i in o] for o in obs], [[int(i) for i in l] for l in lat]])
+            assert "error" not in c, (c["mode"], c["args"])
+        except RuntimeError:
+            assert c.get("error") == "TimeoutError", (c["mode"], c["args"])
+        assert got == want, (c["mode"], c["args"], got[:2], want[:2])
+        seen += 1
+    assert seen == 7
+    with pytest.raises(NotImplementedError):
+        it = iter(inference_strategies["adaptive-autoreg"](distance="lpips", video_length=8, num_obs=2, max_frames=4, step_size=2))
+        it.set_videos(torch.zeros(1, 8, 3, 4, 4))
+        next(it)

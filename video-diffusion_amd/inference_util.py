@@ -7,10 +7,21 @@ bit-exactly by tests/golden/schedulers.json.  A strategy is an iterator of
 drives it with `iter()` / `next()`.
 
 The goal-directed, visualisation and frameskip ("google") strategies (:534-776) are
-pinned by tests/golden/schedulers_more.json; the adaptive (LPIPS-driven) ones need a perceptual
-network and are not provided.
+pinned by tests/golden/schedulers_more.json.  The adaptive strategies (:137-229, :421-531) choose the
+observed frames per batch item by farthest-point selection on frame embeddings; with distance='l2' (raw
+frames) they are pinned by tests/golden/schedulers_adaptive.json, distance='lpips' needs the pretrained
+LPIPS network, which does not ship: register one with `set_lpips_embedder`.
 """
 import numpy as np
+
+_lpips_embedder = None
+
+
+def set_lpips_embedder(fn):
+    """`fn(frames (B,C,H,W)) -> embedding tensor`: what `LpipsEmbedder(net='alex', spatial=False)` is to the reference
+    (inference_util.py:14-31,146-148).  The pretrained network is not available offline, so none is built in."""
+    global _lpips_embedder
+    _lpips_embedder = fn
 
 
 class InferenceStrategyBase:
@@ -147,11 +158,13 @@ class HierarchyNLevel(InferenceStrategyBase):
         level1 = (self._video_length - len(self._obs_frames)) / (self._step_size - 1)
         return int(level1 ** ((self.N - self.current_level) / (self.N - 1)))
 
-    def next_indices(self):
+    def _latents_and_between(self):
+        """First half of a hierarchy step (:340-388): the latent grid of the current level and the finished frames that
+        lie between its ends.  Returns (first_window_latents, None, None) for the unconditional start."""
         L, done = self._video_length, self._done_frames
         if not done:
             self._start_level_one(L - 1)
-            return [], [int(i) for i in np.linspace(0, L - 1, self._max_frames)]
+            return [int(i) for i in np.linspace(0, L - 1, self._max_frames)], None, None
         if len(done) == len(self._obs_frames):
             self._start_level_one(max(self._obs_frames))
         n_cond, n_new = self._max_frames - self._step_size, self._step_size
@@ -171,17 +184,27 @@ class HierarchyNLevel(InferenceStrategyBase):
                 else:
                     latent.append(idx)
                     idx += self.sample_every
-
         obs = [i for i in range(min(latent), max(latent)) if i in done]      # anything finished in between
-        room = n_cond - len(obs)
-        if room < 2:                                                # need one frame before AND after: shrink the step
-            if self._step_size == 1:
-                raise Exception("Cannot condition before and after even with step size of 1")
-            self._step_size -= 1
-            try:
-                return self.next_indices()
-            finally:
-                self._step_size += 1
+        return latent, obs, n_cond - len(obs)
+
+    def _with_smaller_step(self):
+        """Not enough room to condition before AND after the latents: the same step with one latent fewer (:390-400)."""
+        if self._step_size == 1:
+            raise Exception("Cannot condition before and after even with step size of 1")
+        self._step_size -= 1
+        try:
+            return self.next_indices()
+        finally:
+            self._step_size += 1
+
+    def next_indices(self):
+        L, done = self._video_length, self._done_frames
+        latent, obs, room = self._latents_and_between()
+        if obs is None:
+            return [], latent
+        if room < 2:
+            return self._with_smaller_step()
+        n_cond = self._max_frames - self._step_size
         obs.extend([i for i in range(max(latent) + 1, L) if i in done][:room // 2])
         n_before = n_cond - len(obs)
         if self.current_level == 1:
@@ -198,6 +221,114 @@ class HierarchyNLevel(InferenceStrategyBase):
 
 def get_hierarchy_n_level(n):
     return type(f"Hierarchy{n}Level", (HierarchyNLevel,), {"N": n})
+
+
+class AdaptiveInferenceStrategyBase(InferenceStrategyBase):
+    """:137-211 -- per batch item, the observed frames of a window are chosen from the finished frames by
+    farthest-point selection: start from the `always_selected` ones, then repeatedly take the candidate whose smallest
+    squared distance to the frames chosen so far is largest.  `set_videos(samples)` hands over the current state of the
+    videos before every step (scripts/video_sample.py:94-95); indices come back as one list per batch item."""
+
+    def __init__(self, distance, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.distance = distance
+
+    def set_videos(self, videos):
+        self.videos = videos
+
+    def embed(self, indices):
+        import torch
+        if self.distance == "l2":
+            embs = [self.videos[:, i] for i in indices]
+        elif self.distance == "lpips":
+            if _lpips_embedder is None:
+                raise NotImplementedError("distance='lpips' needs the pretrained LPIPS network (not available offline): "
+                                          "inference_util.set_lpips_embedder(fn), or use distance='l2'")
+            embs = [_lpips_embedder(self.videos[:, i]) for i in indices]
+        else:
+            raise NotImplementedError
+        return torch.stack(embs, dim=1)
+
+    def select_obs_indices(self, possible_next_indices, n, always_selected=(0,)):
+        embs = self.embed(possible_next_indices)
+        picked_per_item = []
+        for b in range(len(self.videos)):
+            nearest = [np.inf] * len(possible_next_indices)      # squared distance to the closest frame picked so far
+            newest = always_selected[0]
+            picked = [possible_next_indices[newest]]
+            for i in range(1, n):
+                for f in range(len(nearest)):
+                    d = ((embs[b, newest] - embs[b][f]) ** 2).sum().cpu().item()
+                    nearest[f] = min(nearest[f], d)
+                newest = always_selected[i] if i < len(always_selected) else int(np.argmax(nearest))
+                picked.append(possible_next_indices[newest])
+            picked_per_item.append(picked)
+        return picked_per_item
+
+    def __next__(self):
+        B = len(self.videos)
+        if self._num_obs == 0 and self._current_step == 0:
+            obs, latent = InferenceStrategyBase.__next__(self)           # one unconditional window for everybody
+            return [obs for _ in range(B)], [latent for _ in range(B)]
+        if self.is_done():
+            raise StopIteration
+        obs, latent = self.next_indices()
+        assert isinstance(obs, list) and isinstance(latent, list)
+        for idx in np.array(obs).flatten():
+            assert idx in self._done_frames, (
+                f"Attempting to condition on frame {idx} while it is not generated yet.\n"
+                f"Generated frames: {self._done_frames}\nObserving: {obs}\nGenerating: {latent}")
+        assert np.all(np.array(latent) < self._video_length)
+        self._done_frames.update([idx for idx in latent if idx not in self._done_frames])
+        self._current_step += 1
+        return obs, [latent] * len(obs)
+
+
+class AdaptiveAutoregressive(AdaptiveInferenceStrategyBase):
+    """:214-229 -- the next `step_size` frames, conditioned on the newest finished frame plus the farthest-point picks."""
+
+    def next_indices(self):
+        if not self._done_frames:
+            return [[]] * len(self.videos), list(range(self._max_frames))
+        latent = self._next_chunk(max(self._done_frames) + 1, self._step_size)
+        return self.select_obs_indices(sorted(self._done_frames)[::-1], self._max_frames - self._step_size), latent
+
+
+class AdaptiveHierarchyNLevel(AdaptiveInferenceStrategyBase, HierarchyNLevel):
+    """:421-519 -- the hierarchy's latent grid; always observed: the finished frames between the latents, the two
+    nearest finished frames before them and the nearest one after; the rest of the budget by farthest-point selection."""
+
+    def next_indices(self):
+        L, done = self._video_length, self._done_frames
+        latent, obs, room = self._latents_and_between()
+        if obs is None:
+            return [], latent
+        if room < 2:
+            return self._with_smaller_step()
+
+        def back_from(i):
+            while i not in done:
+                i -= 1
+                if i < 0:      # the reference loops forever here (no finished frame on that side, e.g. num_obs = 0)
+                    raise RuntimeError("adaptive hierarchy: no finished frame before the latents to condition on")
+            return i
+        first = back_from(min(latent))
+        obs.append(first)
+        obs.append(back_from(first - 1))
+        i = max(latent)
+        while i not in done and i < L:
+            i += 1
+        if i < L:
+            obs.append(i)
+        candidates = list(done)
+        obs = self.select_obs_indices(candidates, self._max_frames - self._step_size,
+                                      always_selected=[candidates.index(i) for i in obs])
+        self.last_sampled_idx = max(latent)
+        return obs, latent
+
+
+def get_adaptive_hierarchy_n_level(n):
+    return type(f"AdaptiveHierarchy{n}Level", (AdaptiveHierarchyNLevel,), {"N": n})
 
 
 GOAL_FRAMES = 5      # the goal-directed strategies treat the last five frames of the video as given (:536-539, :566-569)
@@ -413,4 +544,7 @@ inference_strategies = {
     "baby-cond-ho-et-al-for-vis": BabyCondHoEtAlForVis,
     "google": Google,
     "like-google": LikeGoogle,
+    "adaptive-autoreg": AdaptiveAutoregressive,
+    "adaptive-hierarchy-2": get_adaptive_hierarchy_n_level(2),
+    "adaptive-hierarchy-3": get_adaptive_hierarchy_n_level(3),
 }

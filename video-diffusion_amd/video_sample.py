@@ -39,15 +39,19 @@ def get_masks(x0, num_obs):
 
 @torch.no_grad()
 def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size=1, optimal_schedule_path=None, *,
-                use_gradient_method=False, observed_frames="x_0", sampler="p_sample", eta=0.0, executor="graph"):
-    """video_sample.py:50-190 (non-adaptive modes).  Returns (samples ndarray (B,T,C,H,W), None).
+                use_gradient_method=False, observed_frames="x_0", sampler="p_sample", eta=0.0, executor="graph",
+                adaptive_distance="lpips"):
+    """video_sample.py:50-190.  Returns (samples ndarray (B,T,C,H,W), None).
+
+    'adaptive-*' modes (:74,94-95,104-118,176-183): the strategy sees the current samples before every window and hands
+    back one index list per batch item.  `adaptive_distance` is the reference's `distance` ('lpips' is what its script
+    passes and needs `inference_util.set_lpips_embedder`; 'l2' works on the frames themselves).
 
     executor='graph' (default): each window's step loop runs on the window executor -- one captured hipGraph per window
     shape, step index and noise counter on the device (executor.py).  executor='eager': one `diffusion.p_sample` call
     per step from the host with `th.randn_like` noise, the reference's own loop (needed to replay a recorded noise
     sequence, and for observed_frames='x_t_minus_1')."""
-    if "adaptive" in mode:
-        raise NotImplementedError(f"inference mode {mode!r} needs the LPIPS network (out of scope)")
+    adaptive = "adaptive" in mode
     B, T, C, H, W = batch.shape
     device = model.device
     samples = torch.zeros_like(batch).cpu()
@@ -56,7 +60,7 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
         samples[:, -5] = batch[:, -5].cpu()              # the reference hands over ONE goal frame (index -5) here
     schedule = iter(inference_util.inference_strategies[mode](
         video_length=T, num_obs=obs_length, max_frames=max_frames, step_size=step_size,
-        optimal_schedule_path=optimal_schedule_path))
+        optimal_schedule_path=optimal_schedule_path, **(dict(distance=adaptive_distance) if adaptive else {})))
     timesteps = list(range(diffusion.num_timesteps))[::-1]
     t_tensors = None
     use_graph = executor == "graph" and observed_frames in ("x_0", "x_t") and not use_gradient_method
@@ -65,13 +69,32 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
         wex = getattr(model, "_window_executor", None)
         if wex is None or wex.diffusion is not diffusion:
             wex = model._window_executor = WindowExecutor(model, diffusion)
-    for obs_frame_indices, latent_frame_indices in schedule:
+    while True:
+        if adaptive:
+            schedule.set_videos(samples)
+        try:
+            obs_frame_indices, latent_frame_indices = next(schedule)
+        except StopIteration:
+            break
         logger.info(f"Conditioning on {sorted(obs_frame_indices)} frames, predicting {sorted(latent_frame_indices)}.")
-        x0 = torch.cat([samples[:, obs_frame_indices], samples[:, latent_frame_indices]], dim=1).clone()
-        frame_indices = torch.cat([torch.tensor(obs_frame_indices, dtype=torch.int64),
-                                   torch.tensor(latent_frame_indices, dtype=torch.int64)], dim=0).repeat((B, 1))
-        obs_mask, latent_mask, kinda_marg_mask = get_masks(x0, len(obs_frame_indices))
-        n_latent = len(latent_frame_indices)
+        if adaptive:                   # one (obs, latent) index row per batch item
+            frame_indices = torch.cat([torch.tensor(obs_frame_indices, dtype=torch.int64).reshape(B, -1),
+                                       torch.tensor(latent_frame_indices, dtype=torch.int64).reshape(B, -1)], dim=1)
+            x0 = torch.stack([samples[i, fi] for i, fi in enumerate(frame_indices)], dim=0).clone()
+            n_obs_w, n_latent = len(obs_frame_indices[0]), len(latent_frame_indices[0])
+        else:
+            x0 = torch.cat([samples[:, obs_frame_indices], samples[:, latent_frame_indices]], dim=1).clone()
+            frame_indices = torch.cat([torch.tensor(obs_frame_indices, dtype=torch.int64),
+                                       torch.tensor(latent_frame_indices, dtype=torch.int64)], dim=0).repeat((B, 1))
+            n_obs_w, n_latent = len(obs_frame_indices), len(latent_frame_indices)
+        obs_mask, latent_mask, kinda_marg_mask = get_masks(x0, n_obs_w)
+
+        def write_back(local):
+            if adaptive:
+                for i, li in enumerate(latent_frame_indices):
+                    samples[i, li] = local[i, n_obs_w:].cpu()
+            else:
+                samples[:, latent_frame_indices] = local[:, -n_latent:].cpu()
         x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices = [
             v.to(device) for v in (x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices)]
         model_kwargs = dict(frame_indices=frame_indices, x0=x0, obs_mask=obs_mask, latent_mask=latent_mask,
@@ -79,8 +102,7 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
         if t_tensors is None:          # the reference re-creates this tensor every step (video_sample.py:154-155)
             t_tensors = [torch.tensor([ts] * B, device=device) for ts in range(diffusion.num_timesteps)]
         if use_graph:
-            local_samples = wex.sample_window(x0, model_kwargs, sampler=sampler, eta=eta)
-            samples[:, latent_frame_indices] = local_samples[:, -n_latent:].cpu()
+            write_back(wex.sample_window(x0, model_kwargs, sampler=sampler, eta=eta))
             continue
         local_samples = x0.clone()
         for timestep in timesteps:
@@ -91,7 +113,7 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
             else:
                 local_samples = diffusion.ddim_sample(model, local_samples, t=t_tensors[timestep], clip_denoised=True,
                                                       model_kwargs=model_kwargs, eta=eta)["sample"]
-        samples[:, latent_frame_indices] = local_samples[:, -n_latent:].cpu()
+        write_back(local_samples)
     return samples.numpy(), None
 
 
@@ -155,6 +177,8 @@ def main(argv=None):
     ap.add_argument("--num_channels", type=int, default=128)
     ap.add_argument("--num_res_blocks", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--adaptive_distance", default="l2", choices=["l2", "lpips"],
+                    help="adaptive-* modes: frame embedding for the farthest-point selection (lpips needs set_lpips_embedder)")
     ap.add_argument("--executor", default="graph", choices=["graph", "eager"],
                     help="graph: one captured hipGraph per window shape (executor.py); eager: one p_sample call per step")
     ap.add_argument("--out_dir", default="results/synthetic")
@@ -172,7 +196,8 @@ def main(argv=None):
         g = torch.Generator().manual_seed(1234 + task)
         batch = torch.rand(len(idx), args.T, 3, args.image_size, args.image_size, generator=g) * 2 - 1
         recon, _ = infer_video(args.inference_mode, model, diffusion, batch, args.max_frames, args.obs_length,
-                               args.step_size, observed_frames=args.observed_frames, executor=args.executor)
+                               args.step_size, observed_frames=args.observed_frames, executor=args.executor,
+                               adaptive_distance=args.adaptive_distance)
         for p in save_samples(recon, args.out_dir, first_index=idx[0]):
             logger.info(f"*** Saved {p} ***")
     vdist.barrier()
