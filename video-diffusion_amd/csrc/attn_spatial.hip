@@ -321,13 +321,14 @@ int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s) {
     dim3 grid((a.L + 127) / 128, a.heads, a.nfr);
     static const bool fp32_mfma = [] { const char* e = getenv("VD_MATH"); return e && std::string(e) == "fp32"; }();
     switch (F) {
-    // F = 48 (three k-steps, one and a half output tiles) stays on the fp32-MFMA kernel: the split kernel instantiated
-    // for it fails the op test on a fixed lane pattern (queries 0-3, 8-11, ... of a wave) that none of the other head
-    // dims shows; no model configuration of the reference has that head dim (defaults: 96 and 128), so it is parked here
-    // rather than shipped unexplained
-#define VD_CASE(FV) case FV: if (fp32_mfma || FV == 48) hipLaunchKernelGGL((attn_spatial_kernel<FV>), grid, dim3(256), 0, s, a); \
+    // Head dims with exactly three k-steps (F = 40, 48) stay on the fp32-MFMA kernel: the split kernel instantiated for
+    // them fails the op test on a fixed lane pattern (queries 0-3, 8-11, ... of a wave; every other tested dim from 8
+    // to 128, including 5 and 7 k-steps, is clean; the K row stride and a load-after-MFMA register reuse were ruled
+    // out).  No model configuration of the reference has such a head dim (defaults: 96 and 128), so they are parked
+    // here rather than shipped unexplained
+#define VD_CASE(FV) case FV: if (fp32_mfma || (FV > 32 && FV <= 48)) hipLaunchKernelGGL((attn_spatial_kernel<FV>), grid, dim3(256), 0, s, a); \
                              else hipLaunchKernelGGL((attn_spatial_split_kernel<FV>), grid, dim3(256), 0, s, a); break;
-        VD_CASE(8) VD_CASE(16) VD_CASE(24) VD_CASE(32) VD_CASE(48) VD_CASE(64) VD_CASE(96) VD_CASE(128)
+        VD_CASE(8) VD_CASE(16) VD_CASE(24) VD_CASE(32) VD_CASE(40) VD_CASE(48) VD_CASE(56) VD_CASE(64) VD_CASE(80) VD_CASE(96) VD_CASE(112) VD_CASE(128)
 #undef VD_CASE
         default:
             set_error("spatial attention: unsupported head dim " + std::to_string(F));
