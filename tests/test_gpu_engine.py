@@ -768,3 +768,31 @@ def test_infer_video_adaptive_autoreg_vs_oracle(monkeypatch):
     assert err.mean() < 2e-4, err.mean()
     close(got, samples.numpy(), atol=3e-2, rtol=1e-2)
     assert np.array_equal(got[:, :obs_len], batch[:, :obs_len].numpy())
+
+
+def test_carla_setting_128_one_res_block_vs_oracle():
+    """The authors' CARLA configuration (train.sh:18: image_size 128, num_res_blocks 1; BASELINE configs[4]) on one
+    Tw = 20 clip with autoreg frame indices, against the CPU oracle."""
+    cfg = _cfg128(num_res_blocks=1)
+    model, diff, ora = _oracle(cfg)
+    c = _rand_window(1, 20, 128, 10, seed=4420)
+    c["frame_indices"] = torch.arange(26, 46).view(1, 20)
+    t = torch.tensor([41])
+    kw = {k: v for k, v in c.items() if k not in ("x", "observed_frames")}
+    want = ora.eps(c["x"], t, kw)
+    got, _ = diff._wrap_model(model)(c["x"].cuda(), t.cuda(), **kwargs_of(c))
+    close(got.cpu(), want, atol=1e-4, rtol=1e-4)
+
+
+def test_256_topology_miniature_vs_oracle():
+    """image_size 256 selects channel_mult (1,1,2,2,4,4), six levels (script_util.py:255-264): a 32-base-channel
+    miniature of that topology on 256x256 frames against the oracle (the Winograd kernels on 256x256 .. 8x8 maps)."""
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=2, image_size=256, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=2, rp_beta=2, rp_gamma=2, timestep_respacing="ddim50")}
+    model, diff, ora = _oracle(cfg)
+    c = _rand_window(1, 2, 256, 1, seed=256)
+    t = torch.tensor([7])
+    kw = {k: v for k, v in c.items() if k not in ("x", "observed_frames")}
+    want = ora.eps(c["x"], t, kw)
+    got, _ = diff._wrap_model(model)(c["x"].cuda(), t.cuda(), **kwargs_of(c))
+    close(got.cpu(), want, atol=1e-4, rtol=1e-4)
