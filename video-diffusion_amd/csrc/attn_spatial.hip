@@ -144,9 +144,16 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
+// gfx940-class hazard: a non-transcendental VALU instruction that reads a VGPR written by a transcendental one (v_exp_f32:
+// the softmax weights below) needs one wait state in between.  hipcc inserts it between its own instructions but does
+// not look inside inline asm, and split_a's first instruction may be scheduled right behind the v_exp_f32 that produced
+// its operand: the 16-lane passes of the transcendental unit that had not retired yet were then read stale -- a fixed
+// lane pattern, for one element, in exactly the head dims whose schedule put the two back to back (F = 40, 48: keys 24
+// and 28 of a tile counted twice for queries 0-3, 8-11, ...).  The guard below is part of the asm block's own text.
 __device__ __forceinline__ void split_f4(f32x4 v, u32x2_t& p1, u32x2_t& p2, u32x2_t& p3) {
     float r0, r1, r2, r3;
     unsigned a, b, c, d, e, f;
+    asm volatile("s_nop 1" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));     // operands pinned behind the wait states
     split_a(v.x, v.y, a, r0, r1, 0x07060302u);
     split_a(v.z, v.w, b, r2, r3, 0x07060302u);
     split_b(r0, r1, c, e, 0x07060302u);
@@ -321,12 +328,7 @@ int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s) {
     dim3 grid((a.L + 127) / 128, a.heads, a.nfr);
     static const bool fp32_mfma = [] { const char* e = getenv("VD_MATH"); return e && std::string(e) == "fp32"; }();
     switch (F) {
-    // Head dims with exactly three k-steps (F = 40, 48) stay on the fp32-MFMA kernel: the split kernel instantiated for
-    // them fails the op test on a fixed lane pattern (queries 0-3, 8-11, ... of a wave; every other tested dim from 8
-    // to 128, including 5 and 7 k-steps, is clean; the K row stride and a load-after-MFMA register reuse were ruled
-    // out).  No model configuration of the reference has such a head dim (defaults: 96 and 128), so they are parked
-    // here rather than shipped unexplained
-#define VD_CASE(FV) case FV: if (fp32_mfma || (FV > 32 && FV <= 48)) hipLaunchKernelGGL((attn_spatial_kernel<FV>), grid, dim3(256), 0, s, a); \
+#define VD_CASE(FV) case FV: if (fp32_mfma) hipLaunchKernelGGL((attn_spatial_kernel<FV>), grid, dim3(256), 0, s, a); \
                              else hipLaunchKernelGGL((attn_spatial_split_kernel<FV>), grid, dim3(256), 0, s, a); break;
         VD_CASE(8) VD_CASE(16) VD_CASE(24) VD_CASE(32) VD_CASE(40) VD_CASE(48) VD_CASE(56) VD_CASE(64) VD_CASE(80) VD_CASE(96) VD_CASE(112) VD_CASE(128)
 #undef VD_CASE
