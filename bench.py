@@ -358,7 +358,7 @@ def main():
                 if rec.get("kernel") == name:
                     traffic = round(rec["hbm_bytes_per_launch"])
                     traffic_source = "profiles/pmc_dominant.json (rocprofv3 --pmc passes of this workload, not this run)"
-            split_conv = name == "conv3x3_wino_s64_kernel"
+            split_conv = name in ("conv3x3_wino_s64_kernel", "conv3x3_wino_r64_kernel")
             # the dominant kernel runs on the bf16 matrix pipe (fp32 operands split exactly into three bf16 pieces) unless
             # VD_CONV_SPLIT=0 / VD_MATH=fp32 keep it on the fp32 MFMA: `peak` is the dense peak of the pipe it uses
             peak = PEAK_BF16_MFMA_TFLOPS if split_conv or name.startswith("gemm_split") else PEAK_FP32_MFMA_TFLOPS

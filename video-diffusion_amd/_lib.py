@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libvdamd.so")
-SOURCES = ["igemm.hip", "conv_halo.hip", "conv_wino.hip", "conv_wino_s64.hip", "gemm_frag.hip", "gemm_split.hip", "norm.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "conv_halo.hip", "conv_wino.hip", "conv_wino_s64.hip", "conv_wino_r64.hip", "gemm_frag.hip", "gemm_split.hip", "norm.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vd_amd.h")
 
 

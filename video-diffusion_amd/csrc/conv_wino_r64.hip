@@ -1,0 +1,373 @@
+// 3x3 stride-1 convolution by Winograd F(2x2,3x3) at fp32 accuracy on the bf16 matrix cores -- the input transform and the
+// split run IN THE FRAGMENT LAYOUT, in registers (gfx950).
+//
+// Same arithmetic, work split and weight image as conv_wino_s64.hip: block = 4 waves (one per SIMD) = 64 tiles x 64 couts,
+// wave i owns Winograd row i (4 positions x 2 M-tiles x 2 cout tiles = 16 accumulator tiles), V = B^T d B in fp32 split
+// exactly into three bf16 pieces, six piece products per element.  The difference is where V lives.  conv_wino_s64.hip
+// transforms block-wide (thread = tile x channel quad), stores V to LDS and reads it back as MFMA fragments; that costs
+// 16 ds_write_b128 and 16 fragment reads per thread and chunk and two block barriers per chunk, and the LDS instructions
+// are what the matrix pipe waits for (tools/mfma_lds_coissue.hip: a second LDS store per MFMA slot costs 16-20 cycles).
+// Here lane (tile r, k-half h) of wave i reads the two patch rows its Winograd row combines -- 4 columns x 8 channels,
+// sixteen ds_read_b128 per M-tile and chunk, straight from the raw patch -- and forms t = d[X] + s*d[S], the four column
+// combinations and their split in its own registers: the result IS the A fragment.  Same vector-ALU work per MFMA (5.0 per
+// slot), no V image, no stores, no fragment reads, ONE barrier per chunk (patch hand-over), and the LDS that held V now
+// holds four patches: a patch is requested four chunks ahead.
+//
+// Patch image (LDS-DMA, as conv_wino_s64.hip): [row 18][x parity 2][slot 10][64 B = 16 channels of one pixel]; the four
+// 16-byte quads of a pixel are stored at quad ^ ((row >> 1) & 3), so that the 16 lanes of a ds_read_b128 group (four tile
+// rows x four tile columns) fall on 16 different bank quads.
+#include <cstdlib>
+#include <cstring>
+
+#include "vd_common.h"
+
+namespace vd {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct WinoR64Geom { int tiles_x, tiles_y, nbx, ncb, nitems, xcd_order; };
+
+namespace r64 {
+constexpr int P = 18, SPP = 10, PLB = SPP * 64, RSB = 2 * PLB;
+constexpr int NX = 6;                       // DMA instructions per thread and patch (256 threads x 16 B x 6 >= 18 * RSB)
+constexpr int XBUF = NX * 4096;             // 24576
+constexpr int NB = 4;                       // patch buffers
+constexpr int LDS_BYTES = NB * XBUF;        // 98304; the output transform's Z image (64 KB) overlays it
+}  // namespace r64
+
+#ifdef VD_WINO_TIMING
+__device__ unsigned long long g_r64_stamp[8];
+#define R64_STAMP(i)                                                                                  \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x == 7) {                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            g_r64_stamp[i] = (i) >= 4 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+    } while (0)
+extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_r64_stamp), sizeof(g_r64_stamp));
+}
+#else
+#define R64_STAMP(i)
+#endif
+#ifndef VD_R64_SKIP
+#define VD_R64_SKIP 0      // timing-only builds (results wrong): 1 no split, 2 no transform at all, 4 no weight loads, 16 no patch DMA,
+#endif                     // 64 no MFMA, 128 no patch reads
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, WinoR64Geom g) {
+    using namespace r64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);         // Winograd row of this wave
+    const int lr = lane & 31, lh = lane >> 5;
+    const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
+    const int nchunk = a.Cin >> 4, ncoblk = a.Cout >> 5;
+
+    // ---- item: blocks are dealt to the 8 XCDs round-robin; inside an XCD the cout blocks of one patch are neighbours
+    int bx, cob0;
+    if (g.xcd_order) {
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        cob0 = (loc % g.ncb) * 2;
+        bx = (loc / g.ncb) * 8 + xcd;
+    } else {
+        bx = blockIdx.x % g.nbx;
+        cob0 = (blockIdx.x / g.nbx) * 2;
+    }
+    const int bxx = bx % g.tiles_x; bx /= g.tiles_x;
+    const int byy = bx % g.tiles_y; bx /= g.tiles_y;
+    const int f0 = bx;
+    const int ox0 = bxx * 16, oy0 = byy * 16;
+
+    // ---- patch staging: thread -> 16-byte LDS slots e*256 + tid; the slot at quad position lq of patch row py holds the
+    // pixel's quad lq ^ ((py >> 1) & 3)
+    unsigned xo[NX];
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+        const int gs = e * 256 + tid, lq = gs & 3, ps = gs >> 2;
+        const int py = ps / (2 * SPP), r = ps % (2 * SPP), pxh = r % SPP, px = 2 * pxh + r / SPP;
+        const int ly = oy0 + py - 1, lx = ox0 + px - 1;
+        const bool in = py < P && pxh < P / 2 && ly >= 0 && ly < Hl && lx >= 0 && lx < Wl;
+        xo[e] = in ? (unsigned)((f0 * a.Hs + (ly >> a.ups)) * a.Ws + (lx >> a.ups)) * (unsigned)(a.Cin * 4) + (unsigned)((lq ^ ((py >> 1) & 3)) * 16)
+                   : 0x80000000u;
+    }
+    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto x_dma = [&](int chunk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((VD_R64_SKIP & 16) || chunk >= nchunk) return;           // a late request would land in the output transform's Z image
+#pragma unroll
+        for (int e = 0; e < NX; ++e)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr)(lds + (chunk & (NB - 1)) * XBUF + e * 4096 + wi * 1024), 16, xo[e], chunk * 64, 0, 0);
+#endif
+    };
+
+    // ---- transform in the fragment layout.  Lane (tile lr of the M-tile, k-half lh): tile column lr & 7, tile row 4m + (lr >> 3);
+    // rows of B^T as d[X] + s*d[S]: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d3 - d1 (row 3 of U is negated on the host)
+    const int rowX = wi, rowS = wi < 2 ? 2 : 1;
+    const float tsg = wi == 1 ? 1.f : -1.f;
+    const int ttx = lr & 7, ttyl = lr >> 3;
+    int adr[2][2];                                                    // [X | S][quad h of the lane's eight channels]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        adr[0][h] = (2 * ttyl + rowX) * RSB + ttx * 64 + (((2 * lh + h) ^ ((ttyl + (rowX >> 1)) & 3)) * 16);
+        adr[1][h] = (2 * ttyl + rowS) * RSB + ttx * 64 + (((2 * lh + h) ^ ((ttyl + (rowS >> 1)) & 3)) * 16);
+    }
+    float t[4][8];                                                    // t[column][channel] of the group being transformed
+    f32x4 stx[2], sts[2];                                             // one column of the patch rows X and S, in flight
+    float tv[8], rr[8];
+    bf16x8 af[2][3];
+    // column c of group (chunk, m): four reads
+    auto t_read = [&](int chunk, int m, int c) {
+        if (VD_R64_SKIP & (2 | 128)) return;
+        const char* rb = lds + (chunk & (NB - 1)) * XBUF + m * (8 * RSB) + (c & 1) * PLB + (c >> 1) * 64;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            stx[h] = *reinterpret_cast<const f32x4*>(rb + adr[0][h]);
+            sts[h] = *reinterpret_cast<const f32x4*>(rb + adr[1][h]);
+        }
+    };
+    auto t_fma = [&](int c, int h) {
+        if (VD_R64_SKIP & 2) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[c][4 * h + e] = stx[h][e] + tsg * sts[h][e];
+    };
+    auto t_comb = [&](int j, int h) {                                // column combination of position j, channels 4h .. 4h+3
+        if (VD_R64_SKIP & 2) return;
+#pragma unroll
+        for (int e = 4 * h; e < 4 * h + 4; ++e)
+            tv[e] = j == 0 ? t[0][e] - t[2][e] : j == 1 ? t[1][e] + t[2][e] : j == 2 ? t[2][e] - t[1][e] : t[1][e] - t[3][e];
+    };
+    auto piece = [&](bf16x8& f, int k, unsigned v) { u32x4 w = __builtin_bit_cast(u32x4, f); w[k] = v; f = __builtin_bit_cast(bf16x8, w); };
+    auto t_split_a = [&](int buf, int pr) {                           // channels 2pr, 2pr+1
+        if (VD_R64_SKIP & 2) return;
+        if (VD_R64_SKIP & 1) { piece(af[buf][0], pr, __builtin_bit_cast(unsigned, tv[2 * pr] + tv[2 * pr + 1])); return; }
+        unsigned p1;
+        split_a(tv[2 * pr], tv[2 * pr + 1], p1, rr[2 * pr], rr[2 * pr + 1], 0x07060302u);
+        piece(af[buf][0], pr, p1);
+    };
+    auto t_split_b = [&](int buf, int pr) {
+        if (VD_R64_SKIP & 2) return;
+        if (VD_R64_SKIP & 1) { piece(af[buf][1], pr, __builtin_bit_cast(unsigned, tv[2 * pr])); piece(af[buf][2], pr, __builtin_bit_cast(unsigned, tv[2 * pr + 1])); return; }
+        unsigned p2, p3;
+        split_b(rr[2 * pr], rr[2 * pr + 1], p2, p3, 0x07060302u);
+        piece(af[buf][1], pr, p2);
+        piece(af[buf][2], pr, p3);
+    };
+
+    // ---- B fragments: U[chunk][xi = 4*wi + j][cob][piece][lane][8 bf16] = 1 KiB per (chunk, xi, cob, piece)
+    const auto usrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wwino), 0, 16 * a.Cout * a.Cin * 6, 0x00020000);
+    const int ustride = 16 * ncoblk * 3072, bstep = ncoblk * 3072;
+    const int bsb = (wi * 4 * ncoblk + cob0) * 3072;
+    const unsigned blane = lane * 16u;
+    bf16x8 bfr[4][2][3];
+    auto b_load = [&](int chunk, int j, int n) {
+        if (VD_R64_SKIP & 4) return;
+        const int so = chunk * ustride + bsb + j * bstep + n * 3072;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            bfr[j][n][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, so + p * 1024, 0));
+    };
+
+    f32x16 acc[2][4][2];                                              // [m][j][n]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][j][n][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[b][p] = bf16x8{};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bfr[j][n][p] = bf16x8{};
+
+    R64_STAMP(0); R64_STAMP(4);
+    // ---- prologue: four patches and the weights of chunk 0 requested; group (0, 0) transformed whole, position 0 split,
+    // column 0 of group (0, 1) in flight -- the state the loop expects at the top of a group
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x_dma(c);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { b_load(0, j, 0); b_load(0, j, 1); }
+    asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");  // every patch requested so far has landed; the weights may be in flight
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { t_read(0, 0, c); t_fma(c, 0); t_fma(c, 1); }
+    t_comb(0, 0); t_comb(0, 1);
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) t_split_a(0, pr);
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) t_split_b(0, pr);
+    t_read(0, 1, 0);
+
+    R64_STAMP(1);
+    // ---- main loop.  Group (chunk, m) = 4 positions x 12 slots; slot k of position j = MFMA (product q = k >> 1, cout tile
+    // n = k & 1) + at most 6 vector instructions of the NEXT position's fragment (k 0, 3: column combination; 1, 2, 4, 5:
+    // first split step of a channel pair; 6..9: second) or, k 10 and 11, of the next group's t (column ord[j], in place: its
+    // last reader ran earlier in this group) + the reads of the column after it.  Products in the order (A2,B0) (A1,B1)
+    // (A1,B0) (A0,B2) (A0,B1) (A0,B0).  Weights: one register set, fragment (j, n) reloaded in the position after its last use.
+    // Patch of chunk c: first read in position 3 of group (c - 1, 0), behind that group's barrier (the only one of a chunk);
+    // last read in position 2 of group (c, 0); its buffer is requested again, for chunk c + 4, behind the barrier of (c, 0).
+    constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
+    constexpr int ORD[4] = {0, 2, 1, 3};
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cur = j & 1, nxt = cur ^ 1;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    const int q = k >> 1, n = k & 1;
+                    if (m == 0 && j == 3 && k == 0) {
+                        // patch chunk + 1 has landed in every wave; nobody reads patch chunk any more (loads return in order:
+                        // the 18 youngest are weight loads)
+                        asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        x_dma(chunk + NB);                                    // past the last chunk: zeros / stale, never used
+                    }
+                    if (!(VD_R64_SKIP & 64))
+                        acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][PA[q]], bfr[j][n][PB[q]], acc[m][j][n], 0, 0, 0);
+                    // the next position's fragment: position j + 1 of this group, or position 0 of the next one
+                    const int jn = (j + 1) & 3;
+                    if (k == 0) t_comb(jn, 0);
+                    else if (k == 3) t_comb(jn, 1);
+                    else if (k == 1 || k == 2) t_split_a(nxt, k - 1);
+                    else if (k == 4 || k == 5) t_split_a(nxt, k - 2);
+                    else if (k >= 6 && k < 10) t_split_b(nxt, k - 6);
+                    else {
+                        // the group after this one: (chunk, 1) or (chunk + 1, 0); the one after that for the last reads
+                        t_fma(ORD[j], k - 10);
+                        if (k == 11) {
+                            if (j < 3) t_read(m == 0 ? chunk : chunk + 1, m ^ 1, ORD[j + 1]);
+                            else t_read(chunk + 1, m, ORD[0]);
+                        }
+                    }
+                    // weights: (j - 1, n) of the next chunk once its last product has issued; (3, n) in position 0 of the next group
+                    if (k == 0 || k == 3) {
+                        const int nn = k == 0 ? 0 : 1;
+                        if (m == 1 && j > 0) b_load(chunk + 1, j - 1, nn);
+                        if (m == 0 && j == 0) b_load(chunk, 3, nn);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    R64_STAMP(2);
+    // ---- output transform, one cout tile at a time: Z[q] = sum_j M[wi][j] A[j][q] is wave-local, the sum over the rows
+    // crosses the waves through LDS; wave (p, q) = (wi >> 1, wi & 1) then owns output pixel (p, q) of every tile.
+    // Z image: [plane 2*i + q 8][m 2][c4 4][lane 64][4 floats] = 64 KB over the patch buffers.
+    const int p = wi >> 1, q = wi & 1;
+    const int obytes = a.nfr * Hl * Wl * a.ldo * 4;
+    const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
+    const float sgn = p ? -1.f : 1.f;
+    float* Zs = smem;
+    unsigned oo[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tt = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int tx = tt & 7, ty = tt >> 3;
+            oo[m][r] = (unsigned)(((f0 * Hl + oy0 + 2 * ty + p) * Wl + ox0 + 2 * tx + q) * a.ldo + cob0 * 32 + lr) * 4u;
+        }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int co = (cob0 + n) * 32 + lr;
+        const float bv = (a.bias ? a.bias[co] : 0.f) + (a.fbias ? a.fbias[(size_t)f0 * a.fbias_ld + co] : 0.f);
+        f32x16 rv[2];
+        if (n) __syncthreads();                                      // the previous Z is no longer read
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], n * 128, 0));
+            const f32x16 z0 = acc[m][0][n] + acc[m][1][n] + acc[m][2][n];
+            const f32x16 z1 = acc[m][1][n] - acc[m][2][n] - acc[m][3][n];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                *reinterpret_cast<f32x4*>(Zs + ((((wi * 2 + 0) * 2 + m) * 4 + c4) * 64 + lane) * 4) = f32x4{z0[4 * c4], z0[4 * c4 + 1], z0[4 * c4 + 2], z0[4 * c4 + 3]};
+                *reinterpret_cast<f32x4*>(Zs + ((((wi * 2 + 1) * 2 + m) * 4 + c4) * 64 + lane) * 4) = f32x4{z1[4 * c4], z1[4 * c4 + 1], z1[4 * c4 + 2], z1[4 * c4 + 3]};
+            }
+        }
+        __syncthreads();
+        const float* zw = Zs + wi * 2048 + lane * 4;                 // Z[p + k][q] is plane wi + 2k
+        float gsum0 = 0.f, gsum1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f32x16 y;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float* zp = zw + (m * 4 + c4) * 256;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(zp) +
+                                (*reinterpret_cast<const f32x4*>(zp + 2 * 2048) + *reinterpret_cast<const f32x4*>(zp + 4 * 2048)) * sgn;
+                y[4 * c4] = v.x; y[4 * c4 + 1] = v.y; y[4 * c4 + 2] = v.z; y[4 * c4 + 3] = v.w;
+            }
+            y += rv[m];
+            y += bv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)y[r]), osrc, oo[m][r], n * 128, 0);
+            if (a.stats) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { gsum0 += y[r]; gsum1 += y[r] * y[r]; }
+            }
+        }
+        if (a.stats) {                                               // GroupNorm partial sums of the output (conv_wino.hip)
+            __syncthreads();
+            double* red = reinterpret_cast<double*>(smem);           // [wave 4][lh 2][lr 32][2]
+            double* d = red + (((wi * 2 + lh) * 32 + lr) * 2);
+            d[0] = (double)gsum0; d[1] = (double)gsum1;
+            __syncthreads();
+            if (tid < 32) {
+                double s = 0.0, ss = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s += red[(k * 32 + tid) * 2]; ss += red[(k * 32 + tid) * 2 + 1]; }
+                double* o = a.stats + (((size_t)f0 * a.stats_split + byy * g.tiles_x + bxx) * a.Cout + (cob0 + n) * 32 + tid) * 2;
+                o[0] = s; o[1] = ss;
+            }
+        }
+    }
+    R64_STAMP(3); R64_STAMP(5);
+}
+
+static bool r64_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+bool conv_wino_r64_supported(const IgemmArgs& a) {
+    static const bool on = [] { const char* e = getenv("VD_CONV_R64"); return !(e && e[0] == '0'); }();   // A/B switch: 0 = conv_wino_s64.hip everywhere
+    const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
+    return on && a.wsplit == 2 && a.wwino != nullptr && a.ksz == 3 && a.stride == 1 && a.pad == 1 && Hl == Wl && r64_pow2(Hl) && Hl >= 16 &&
+           a.Cout % 64 == 0 && a.Cin % 32 == 0 && a.src1 == nullptr && a.C0 == a.Cin && a.affA == nullptr && a.act == 0 &&
+           (size_t)a.nfr * a.Hs * a.Ws * a.Cin < (1u << 29) && (size_t)a.Cin * a.Cout * 96 < (1u << 31) &&
+           (size_t)a.nfr * Hl * Wl * a.ldo < (1u << 29) && (a.res == nullptr || a.res_ld == a.ldo);
+}
+
+int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
+    const int Hl = a.Hs << a.ups;
+    VD_REQUIRE(a.stats == nullptr || a.stats_split == conv_wino_stats_split(Hl), "GroupNorm partial table: split");
+    WinoR64Geom g;
+    g.tiles_x = Hl / 16; g.tiles_y = Hl / 16;
+    g.nbx = g.tiles_x * g.tiles_y * a.nfr;
+    g.ncb = a.Cout / 64;
+    g.nitems = g.nbx * g.ncb;
+    g.xcd_order = g.nbx % 8 == 0;
+    static bool attr = false;
+    if (!attr) {
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wino_r64_kernel, dim3(g.nitems), dim3(256), r64::LDS_BYTES, s, a, g);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vd

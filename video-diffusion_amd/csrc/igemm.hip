@@ -201,6 +201,7 @@ static int launch_t(const IgemmArgs& a, hipStream_t s) {
 // One launch: every operand of `a` is small enough for the 32-bit byte offsets the kernels address with.
 static int launch_igemm_one(const IgemmArgs& a, hipStream_t s) {
     if (gemm_split_supported(a) || conv_split_supported(a)) return launch_gemm_split(a, igemm_tile_class(a.M, a.Cout), s);
+    if (conv_wino_r64_supported(a)) return launch_conv_wino_r64(a, s);      // maps >= 16x16; VD_CONV_R64=0 switches it off
     if (conv_wino_s64_supported(a)) return launch_conv_wino_s64(a, s);
     VD_REQUIRE(!a.wsplit, "bf16-split weights given for a shape the split kernels do not cover");
     if (gemm_frag_supported(a)) return launch_gemm_frag(a, igemm_tile_class(a.M, a.Cout), s);

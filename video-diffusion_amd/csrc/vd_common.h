@@ -133,6 +133,8 @@ __device__ __forceinline__ void split_b(float r0, float r1, unsigned& p2, unsign
 bool conv_wino_s64_supported(const IgemmArgs& a);        // wsplit == 2
 int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino_s64(const float* oihw, unsigned short* out, int O, int I);
+bool conv_wino_r64_supported(const IgemmArgs& a);        // same weight image, transform + split in registers (conv_wino_r64.hip)
+int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s);
 bool gemm_split_supported(const IgemmArgs& a);            // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
 bool conv_split_supported(const IgemmArgs& a);          // 3x3, stride 1|2: the same kernel over an implicit im2col A
 void pack_conv3_split(const float* w_oihw, unsigned short* out, int Cout, int Cin);
