@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from video_diffusion_amd import _lib  # noqa: E402
 
-SHAPES = [(128, 384, 128, 64), (128, 640, 256, 32), (128, 896, 384, 16)]
+SHAPES = [(128, 128, 128, 64), (128, 384, 128, 64), (128, 640, 256, 32), (128, 384, 384, 16), (128, 896, 384, 16)]
 L = _lib.lib()
 op = L.vd_op_conv_wino_s64
 for nfr, Cin, Cout, H in SHAPES:
@@ -34,5 +34,14 @@ for nfr, Cin, Cout, H in SHAPES:
     us = ev[0].elapsed_time(ev[1]) * 5.0
     items = nfr * (H // 16) ** 2 * (Cout // 64)
     rounds = (items + 255) // 256
+    if hasattr(L, "vd_debug_r64_stamps") and os.environ.get("VD_CONV_R64", "1") != "0":
+        import ctypes
+        st = (ctypes.c_ulonglong * 8)()
+        L.vd_debug_r64_stamps.restype = ctypes.c_int
+        L.vd_debug_r64_stamps.argtypes = [ctypes.c_void_p]
+        assert L.vd_debug_r64_stamps(st) == 0
+        t = list(st)
+        print(f"   last item of block 7 (cycles): prologue {t[1]-t[0]}, loop {t[2]-t[1]} = {(t[2]-t[1]) / (Cin // 16):.0f}/chunk, output transform {t[3]-t[2]}; "
+              f"{(t[5]-t[4]) / 100:.2f} us -> {(t[3]-t[0]) / max(t[5]-t[4], 1) * 0.1:.2f} GHz")
     print(f"Cin {Cin:4d} Cout {Cout:4d} H {H:2d}: {us:7.1f} us, {us / rounds / (Cin // 16) * 1e3:6.0f} ns per chunk (floor 1300), "
           f"{2 * 9 * Cin * Cout * nfr * H * H / us * 1e-6:6.1f} TFLOP/s direct-equivalent", flush=True)

@@ -17,6 +17,7 @@
 // 16-byte quads of a pixel are stored at quad ^ ((row >> 1) & 3), so that the 16 lanes of a ds_read_b128 group (four tile
 // rows x four tile columns) fall on 16 different bank quads.
 #include <cstdlib>
+#include <cstdlib>
 #include <cstring>
 
 #include "vd_common.h"
