@@ -495,19 +495,25 @@ def pack_wino_split(w):
     return out
 
 
+@pytest.mark.parametrize("kernel", ["s64", "r64", "split"])
 @pytest.mark.parametrize("N,Cin,Cout,H,ups", [(3, 64, 128, 16, 0), (5, 32, 64, 8, 0), (2, 96, 160, 32, 0), (9, 64, 32, 8, 0),
                                                (1, 128, 64, 64, 0), (2, 64, 64, 8, 1), (6, 160, 192, 8, 0), (41, 32, 128, 32, 0),
-                                               (37, 64, 256, 16, 0), (1100, 32, 64, 8, 0), (8, 64, 128, 32, 0), (64, 32, 128, 32, 0)])
-def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups):
-    """csrc/conv_wino_s64.hip: Winograd F(2x2,3x3) with the element products as six bf16 piece products of exactly
-    split fp32 operands.  Held to the op tolerance against torch fp32, required to be no further from an fp64 conv than
-    the fp32-MFMA Winograd kernel, and its GroupNorm partial sums checked against the stored output.  The last three
-    shapes have more work items than the GPU has CUs: conv_wino_s64.hip walks them with a persistent grid and requests
-    the next item's first patches under the tail of the current one; the last two also take its cout-inner item order
-    (tile blocks a multiple of 8, more than one cout block, weights that fit an L2)."""
+                                               (37, 64, 256, 16, 0), (1100, 32, 64, 8, 0), (8, 64, 128, 32, 0), (64, 32, 128, 32, 0),
+                                               (3, 224, 64, 16, 1), (300, 64, 64, 16, 0), (16, 128, 192, 64, 0)])
+def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups, kernel):
+    """csrc/conv_wino_r64.hip (maps >= 16x16) and csrc/conv_wino_s64.hip (>= 8x8): Winograd F(2x2,3x3) with the element
+    products as six bf16 piece products of exactly split fp32 operands; kernel 'split' is whichever the engine takes.
+    Held to the op tolerance against torch fp32, required to be no further from an fp64 conv than the fp32-MFMA Winograd
+    kernel, and the GroupNorm partial sums checked against the stored output.  Several shapes have more work items than
+    the GPU has CUs (conv_wino_s64.hip: persistent grid, next item's patches requested under the tail of the current
+    one; conv_wino_r64.hip: one block per item) and take the cout-inner item order (tile blocks a multiple of 8, more
+    than one cout block); the r64 cases cover 2..14 channel chunks, the x2 upsampled source and all three tile grids."""
     if Cout % 64:
-        pytest.skip("conv_wino_s64.hip owns 64 couts per block (the engine sends other widths to the fragment kernels)")
+        pytest.skip("the split Winograd kernels own 64 couts per block (the engine sends other widths to the fragment kernels)")
+    if kernel == "r64" and (H << ups) < 16:
+        pytest.skip("conv_wino_r64.hip takes maps >= 16x16")
     L = _lib.lib()
+    op = {"s64": L.vd_op_conv_wino_s64, "r64": L.vd_op_conv_wino_r64, "split": L.vd_op_conv_wino_split}[kernel]
     x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, scale=(3.0 / (9 * Cin)) ** 0.5), rnd(Cout, scale=0.1)
     Ho = H << ups
     res = rnd(N, Cout, Ho, Ho, seed=4)
@@ -517,8 +523,8 @@ def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups):
     split = L.vd_conv_stats_split(Ho)
     part = torch.full((N, split, Cout, 2), float("nan"), dtype=torch.float64, device="cuda")
     ws = dev(pack_wino_split(w))
-    _lib.check(L.vd_op_conv_wino_s64(_lib.ptr(xd), Cin, N, H, H, ups, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(fd), Cout,
-                                       _lib.ptr(out_s), Cout, _lib.ptr(part), _lib.current_stream()))
+    _lib.check(op(_lib.ptr(xd), Cin, N, H, H, ups, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(fd), Cout,
+                  _lib.ptr(out_s), Cout, _lib.ptr(part), _lib.current_stream()))
     torch.cuda.synchronize()
     xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
     ref = F.conv2d(xin, w, b, padding=1) + res + fb[:, :, None, None]

@@ -77,7 +77,7 @@ def main():
             wsp = torch.randint(-2000, 2000, (48 * Cout * Cin,), device="cuda", dtype=torch.int16)  # timing only
 
             def run():
-                _lib.check(L.vd_op_conv_wino_s64(_lib.ptr(x0), Cin, nfr, H, H, ups, _lib.ptr(wsp), _lib.ptr(b), _lib.ptr(res), None, 0,
+                _lib.check(L.vd_op_conv_wino_split(_lib.ptr(x0), Cin, nfr, H, H, ups, _lib.ptr(wsp), _lib.ptr(b), _lib.ptr(res), None, 0,
                                                    _lib.ptr(out), Cout, None, _lib.current_stream()))
         else:
             run = None

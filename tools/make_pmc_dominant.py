@@ -20,7 +20,7 @@ fetch, write = tot["FETCH_SIZE"] * 1024 / n, tot["WRITE_SIZE"] * 1024 / n
 out = {
     "kernel": kernel,
     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes, tools/profile_bench.sh {tag}) on "
-              f"`bench.py --steps 5 --warmup 1`, {int(n)} dispatches of {kernel}<false|true>",
+              f"`bench.py --steps 5 --warmup 1`, {int(n)} dispatches of {kernel}",
     "fetch_size_bytes_per_launch": fetch,
     "write_size_bytes_per_launch": write,
     "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE "

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-layer timing of conv3x3_wino_s64_kernel over the 3x3 stride-1 conv census of the headline window
+"""Per-layer timing of the split Winograd kernels (conv_wino_r64.hip / conv_wino_s64.hip) over the 3x3 stride-1 conv census of the headline window
 (SURVEY appendix B x 128 frames).  python tools/s64_bench.py [--reps 10] [--frames 128]"""
 import argparse
 import os
@@ -22,8 +22,10 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--only", type=int, default=0, help="only layers with this output resolution")
+    ap.add_argument("--kernel", default="split", choices=["split", "s64", "r64"], help="split: the engine's choice per layer")
     args = ap.parse_args()
     L = _lib.lib()
+    OPS = {"split": L.vd_op_conv_wino_split, "s64": L.vd_op_conv_wino_s64, "r64": L.vd_op_conv_wino_r64}
     tot_ms = tot_fl = 0.0
     for Cin, Cout, H, ups, cnt in CENSUS:
         if args.only and H != args.only:
@@ -38,7 +40,8 @@ def main():
         part = torch.empty(nfr, split, Cout, 2, dtype=torch.float64, device="cuda")
 
         def run():
-            _lib.check(L.vd_op_conv_wino_s64(_lib.ptr(x0), Cin, nfr, Hs, Hs, ups, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(res), None, 0,
+            OP = OPS["s64" if args.kernel == "r64" and H < 16 else args.kernel]
+            _lib.check(OP(_lib.ptr(x0), Cin, nfr, Hs, Hs, ups, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(res), None, 0,
                                              _lib.ptr(out), Cout, _lib.ptr(part), _lib.current_stream()))
         for _ in range(2):
             run()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sustained timing of the 3x3 Winograd kernels on three long-K layers (VD_CONV_R64=0: conv_wino_s64.hip everywhere):
+"""Sustained timing of the 3x3 Winograd kernels on three long-K layers (VD_WINO_KERNEL=s64|r64 names the kernel; default: the engine's choice):
 kernel time over 200 back-to-back launches (clocks ramped), expressed per 16-channel chunk of one work item.
 The MFMA floor of a chunk is 96 MFMAs per SIMD x 32 cycles = 1.30 us at 2.36 GHz."""
 import os
@@ -12,7 +12,7 @@ from video_diffusion_amd import _lib  # noqa: E402
 
 SHAPES = [(128, 128, 128, 64), (128, 384, 128, 64), (128, 640, 256, 32), (128, 384, 384, 16), (128, 896, 384, 16)]
 L = _lib.lib()
-op = L.vd_op_conv_wino_s64
+op = {"s64": L.vd_op_conv_wino_s64, "r64": L.vd_op_conv_wino_r64}.get(os.environ.get("VD_WINO_KERNEL", ""), L.vd_op_conv_wino_split)
 for nfr, Cin, Cout, H in SHAPES:
     x0 = torch.rand(nfr, H, H, Cin, device="cuda") - 0.5
     ws = torch.randint(-2000, 2000, (48 * Cout * Cin,), device="cuda", dtype=torch.int16)
@@ -34,7 +34,7 @@ for nfr, Cin, Cout, H in SHAPES:
     us = ev[0].elapsed_time(ev[1]) * 5.0
     items = nfr * (H // 16) ** 2 * (Cout // 64)
     rounds = (items + 255) // 256
-    if hasattr(L, "vd_debug_r64_stamps") and os.environ.get("VD_CONV_R64", "1") != "0":
+    if hasattr(L, "vd_debug_r64_stamps") and os.environ.get("VD_WINO_KERNEL", "") != "s64":
         import ctypes
         st = (ctypes.c_ulonglong * 8)()
         L.vd_debug_r64_stamps.restype = ctypes.c_int

@@ -1257,9 +1257,9 @@ int vd_pack_conv3_wino_s64(const float* host_oihw, unsigned short* host_out, int
     return 0;
 }
 
-int vd_op_conv_wino_s64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
-                        const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
-                        void* stream) {
+static int op_conv_wino_split(int kernel, const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split,
+                              const float* bias, const float* res, const float* fbias, int fbias_ld, float* out, int Cout,
+                              double* gn_part, void* stream) {
     IgemmArgs g{};
     g.src0 = src0; g.C0 = Cin; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws; g.ups = ups;
     g.stride = 1; g.pad = 1; g.ksz = 3;
@@ -1267,8 +1267,30 @@ int vd_op_conv_wino_s64(const float* src0, int Cin, int nfr, int Hs, int Ws, int
     g.wwino = static_cast<const float*>(w_split); g.wsplit = 2; g.bias = bias; g.res = res; g.res_ld = Cout;
     g.fbias = fbias; g.fbias_ld = fbias_ld; g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
     g.stats = gn_part; g.stats_split = conv_wino_stats_split(g.Ho);
-    VD_REQUIRE(conv_wino_s64_supported(g), "vd_op_conv_wino_s64: shape not covered by the kernel");
-    return launch_igemm(g, static_cast<hipStream_t>(stream));
+    VD_REQUIRE(conv_wino_s64_supported(g), "vd_op_conv_wino_*: shape not covered by the kernels");
+    if (kernel == 0) return launch_igemm(g, static_cast<hipStream_t>(stream));       // the engine's choice
+    VD_REQUIRE(igemm_frames_per_launch(g) >= nfr, "vd_op_conv_wino_*: window too large for one launch");
+    if (kernel == 1) return launch_conv_wino_s64(g, static_cast<hipStream_t>(stream));
+    VD_REQUIRE(conv_wino_r64_supported(g), "vd_op_conv_wino_r64: maps >= 16x16 (and VD_CONV_R64 not 0)");
+    return launch_conv_wino_r64(g, static_cast<hipStream_t>(stream));
+}
+
+int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
+                          const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
+                          void* stream) {
+    return op_conv_wino_split(0, src0, Cin, nfr, Hs, Ws, ups, w_split, bias, res, fbias, fbias_ld, out, Cout, gn_part, stream);
+}
+
+int vd_op_conv_wino_s64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
+                        const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
+                        void* stream) {
+    return op_conv_wino_split(1, src0, Cin, nfr, Hs, Ws, ups, w_split, bias, res, fbias, fbias_ld, out, Cout, gn_part, stream);
+}
+
+int vd_op_conv_wino_r64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
+                        const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
+                        void* stream) {
+    return op_conv_wino_split(2, src0, Cin, nfr, Hs, Ws, ups, w_split, bias, res, fbias, fbias_ld, out, Cout, gn_part, stream);
 }
 
 int vd_pack_conv3_split(const float* host_oihw, unsigned short* host_out, int O, int I) {
