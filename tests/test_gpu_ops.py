@@ -460,7 +460,9 @@ def pack_lin_split(w):
                                            (2048, 384, 384, 0, 1), (70, 64, 128, 1, 1),
                                            # many-tile shapes (128x128 / 64x128 tile classes, ragged M)
                                            (8192, 64, 1536, 0, 1), (8135, 96, 1536, 0, 0), (8192, 128, 1536, 1, 0),
-                                           (32768, 64, 512, 0, 1), (65536, 32, 320, 0, 0)])
+                                           (32768, 64, 512, 0, 1), (65536, 32, 320, 0, 0),
+                                           # the 128x192 tile (N % 192 == 0, >= 384 of them): 2-slot weight ring, ragged M
+                                           (32768, 96, 384, 0, 1), (32700, 64, 1152, 1, 0), (8192, 160, 1536, 0, 0)])
 def test_linear_split_bf16x6_is_fp32_accurate(M, K, N, act, res):
     """csrc/gemm_split.hip: fp32 operands split exactly into three bf16 pieces, six piece products on the bf16 matrix
     cores, fp32 accumulation.  Held to the op tolerance against torch fp32 AND, against an fp64 product, required to be

@@ -95,7 +95,7 @@ struct Arena {
 // ---- per-class kernel timing with HIP events on the launch stream (bench.py's live roofline figure)
 enum ProfClass { PC_IGEMM_128x128 = 0, PC_IGEMM_128x64, PC_IGEMM_64x128, PC_IGEMM_64x64, PC_GN_STATS, PC_GN_TEMPORAL,
                  PC_ATTN_SPATIAL, PC_ATTN_TEMPORAL, PC_OUT_CONV, PC_ELEMENTWISE, PC_POSTERIOR,
-                 PC_CONV_128x128, PC_CONV_128x64, PC_CONV_64x128, PC_CONV_64x64, PC_CONV_WINO, PC_CONV_WINO_R64, PC_COUNT };
+                 PC_CONV_128x128, PC_CONV_128x64, PC_CONV_64x128, PC_CONV_64x64, PC_CONV_WINO, PC_CONV_WINO_R64, PC_IGEMM_128x192, PC_COUNT };
 // names of the kernels a class runs on: [0] default arithmetic (bf16x6 split), [1] VD_MATH=fp32 / VD_CONV_SPLIT=0
 static const char* kProfNames[PC_COUNT][2] = {
     {"gemm_split_kernel<128,128>", "gemm_frag_kernel<128,128>"}, {"gemm_split_kernel<128,64>", "gemm_frag_kernel<128,64>"},
@@ -105,7 +105,8 @@ static const char* kProfNames[PC_COUNT][2] = {
     {"out_conv_kernel", "out_conv_kernel"}, {"affine_act_kernel", "affine_act_kernel"}, {"posterior_kernel", "posterior_kernel"},
     {"conv3x3_frag_kernel<128,128>", "conv3x3_frag_kernel<128,128>"}, {"conv3x3_frag_kernel<128,64>", "conv3x3_frag_kernel<128,64>"},
     {"conv3x3_frag_kernel<64,128>", "conv3x3_frag_kernel<64,128>"}, {"conv3x3_frag_kernel<64,64>", "conv3x3_frag_kernel<64,64>"},
-    {"conv3x3_wino_s64_kernel", "conv3x3_wino_kernel"}, {"conv3x3_wino_r64_kernel", "conv3x3_wino_r64_kernel"}};
+    {"conv3x3_wino_s64_kernel", "conv3x3_wino_kernel"}, {"conv3x3_wino_r64_kernel", "conv3x3_wino_r64_kernel"},
+    {"gemm_split_kernel<128,192>", "gemm_split_kernel<128,192>"}};
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; char tag[56]; };
 struct Profiler {
     bool on = false;
@@ -139,8 +140,10 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     one.nfr = std::max(1, std::min(g.nfr, igemm_frames_per_launch(g)));
     one.M = one.nfr * g.Ho * g.Wo;
     const bool wino = conv_wino_supported(one) || conv_wino_s64_supported(one);
+    const bool split_gemm = gemm_split_supported(one) || conv_split_supported(one);
     const int cls = wino ? (int)(conv_wino_r64_supported(one) ? PC_CONV_WINO_R64 : PC_CONV_WINO)
-                         : igemm_tile_class(one.M, g.Cout) + (conv_halo_supported(one) ? (int)PC_CONV_128x128 : 0);
+                    : split_gemm && gemm_split_tile_class(one.M, g.Cout) == 4 ? (int)PC_IGEMM_128x192
+                    : igemm_tile_class(one.M, g.Cout) + (conv_halo_supported(one) ? (int)PC_CONV_128x128 : 0);
     char tag[56];
     snprintf(tag, sizeof(tag), "M=%d N=%d K=%d k%d s%d%s%s%s", g.M, g.Cout, g.Cin, g.ksz, g.stride, g.ups ? " ups" : "",
              g.affA ? " pro" : (g.act ? " act" : ""), g.res ? " res" : "");

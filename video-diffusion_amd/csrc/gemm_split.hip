@@ -42,6 +42,7 @@ __device__ __forceinline__ void split3(f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& 
 template <int BM, int BN, bool ACT, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
+    constexpr int RING = NI >= 3 ? 2 : 3;                                  // weight ring slots (k-steps ahead = RING - 1): 256 registers per wave
     constexpr int PLANE = BM * SROW, ABUF = 3 * PLANE;                    // bytes
     extern __shared__ __attribute__((aligned(16))) char smem_c[];         // [2][3 planes][BM][SROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     for (int j = 0; j < NI; ++j) bo[j] = (unsigned)min((int)blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1) * 3072u + lane * 16u;
 
     f32x4 ra[AR];
-    bf16x8 bfr[3][NI][3], afr[2][MI][3];         // [ring slot][tile][piece]
+    bf16x8 bfr[RING][NI][3], afr[2][MI][3];      // [ring slot][tile][piece]
     auto a_prefetch = [&](int chunk) {
         if constexpr (CONV) {
             const int tap = chunk / cpt, c = (chunk - tap * cpt) * 32;
@@ -175,17 +176,17 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     const int nks = 2 * nchunk;
     a_prefetch(0);
     b_load(0, 0);
-    b_load(1, min(1, nks - 1));
+    if constexpr (RING == 3) b_load(1, min(1, nks - 1));
     a_store(smem_c);
     __syncthreads();
     a_frags(0, smem_c, 0);
 
-    // k-steps in a ring of 3 weight slots (two steps ahead) and 2 fragment slots (one step ahead); the six piece
+    // k-steps in a ring of 3 weight slots (two steps ahead; 2 slots, one step ahead, for the 128x192 tile) and 2 fragment slots (one step ahead); the six piece
     // products of a tile go into its accumulator back to back, small terms first
     auto kstep = [&](int chunk, int ks, int gslot, int aslot) {          // gslot = (2*chunk + ks) % 3, compile time
         const int g = 2 * chunk + ks;
         const char* Acur = smem_c + (chunk & 1) * ABUF;
-        if (!(VD_GS_SKIP & 1)) b_load((gslot + 2) % 3, min(g + 2, nks - 1));
+        if (!(VD_GS_SKIP & 1)) b_load((gslot + RING - 1) % RING, min(g + RING - 1, nks - 1));
         if (ks == 0) a_frags(aslot ^ 1, Acur, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
             if (chunk < nchunk) {
                 const int nxt = min(chunk + 1, nchunk - 1);
                 if (!(VD_GS_SKIP & 2)) a_prefetch(nxt);
-                kstep(chunk, 0, (2 * cc) % 3, 0);
-                kstep(chunk, 1, (2 * cc + 1) % 3, 1);
+                kstep(chunk, 0, RING == 3 ? (2 * cc) % 3 : 0, 0);
+                kstep(chunk, 1, RING == 3 ? (2 * cc + 1) % 3 : 1, 1);
                 if (!(VD_GS_SKIP & 6)) a_store(smem_c + ((chunk + 1) & 1) * ABUF);
                 __syncthreads();
                 a_frags(0, smem_c + ((chunk + 1) & 1) * ABUF, 0);
@@ -261,8 +262,20 @@ static int launch_gs(const IgemmArgs& a, hipStream_t s) {
     return 0;
 }
 
+// 128x192 tile for the wide projections (qkv: N = 1152, 1536; proj: N = 384): the A tile is staged and split once per 192
+// instead of 128 columns, and their grids come out in whole rounds of 2 blocks per CU (N = 1536 at M = 8192: 512 blocks
+// instead of 768; N = 384 at M = 32768: 512 instead of 768)
+int gemm_split_tile_class(int M, int Cout) {
+    static const bool off = getenv("VD_GS_NO192") != nullptr;         // A/B switch
+    const int base = igemm_tile_class(M, Cout);
+    if (off || base != 0 || Cout % 192) return base;
+    return (long)((M + 127) / 128) * (Cout / 192) >= 384 ? 4 : base;
+}
+
 int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s) {
+    if (tile_class == 0) tile_class = gemm_split_tile_class(a.M, a.Cout);
     switch (tile_class) {
+        case 4: return launch_gs<128, 192>(a, s);
         case 0: return launch_gs<128, 128>(a, s);
         case 1: return launch_gs<128, 64>(a, s);
         case 2: return launch_gs<64, 128>(a, s);

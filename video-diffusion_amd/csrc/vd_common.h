@@ -139,6 +139,7 @@ bool gemm_split_supported(const IgemmArgs& a);            // fp32-accurate GEMM 
 bool conv_split_supported(const IgemmArgs& a);          // 3x3, stride 1|2: the same kernel over an implicit im2col A
 void pack_conv3_split(const float* w_oihw, unsigned short* out, int Cout, int Cin);
 int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s);
+int gemm_split_tile_class(int M, int Cout);               // igemm_tile_class, or 4 = the 128x192 tile
 void pack_linear_split(const float* w, unsigned short* out_base, int rows, int K, int n_total, int row0);          // blocks per frame = partial sums per (frame, channel)
 int launch_conv_wino(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino(const float* oihw, float* out, int O, int I);      // out: 16*O*I floats
