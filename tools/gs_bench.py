@@ -1,6 +1,13 @@
-import os, sys, torch
-sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/video_diffusion_amd') else os.getcwd())
-from video_diffusion_amd import _lib
+#!/usr/bin/env python3
+"""Sustained timing of gemm_split on the projection shapes of the headline window (VD_GS_NO192=1: 128x128 tiles only)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from video_diffusion_amd import _lib  # noqa: E402
+
 L = _lib.lib()
 for M, K, N, res in [(32768, 384, 1152, 0), (8192, 512, 1536, 0), (32768, 384, 384, 1), (8192, 512, 512, 1), (131072, 256, 256, 0)]:
     a = torch.rand(M, K, device="cuda") - 0.5
