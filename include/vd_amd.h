@@ -244,6 +244,12 @@ int vd_op_conv_wino_r64(const float* src0, int Cin, int nfr, int Hs, int Ws, int
                         void* stream);
 int vd_op_linear_split(const float* a, int M, int K, const void* w_split, const float* bias, const float* res, int act,
                        float* out, int N, void* stream);
+/* The same layer with the GroupNorm partial sums of its output from the epilogue (the rows are the HW pixels of M / HW
+ * consecutive frames; unet.py:537-538 followed by the next block's normalization, nn.py:15-17): gn_part is
+ * [M / HW][vd_linear_stats_split(M, N, HW)][N][2] doubles, per channel [sum, sum of squares]. */
+int vd_op_linear_split_stats(const float* a, int M, int K, const void* w_split, const float* bias, const float* res, int act,
+                             float* out, int N, int HW, double* gn_part, void* stream);
+int vd_linear_stats_split(int M, int N, int HW);
 /* GroupNorm32 statistics folded to y = x*A + B per (frame, channel); film ([nfr][2C] scale|shift) optional. */
 int vd_op_gn_fold(const float* src0, const float* src1, int C0, int C, int nfr, int HW, const float* gamma,
                   const float* beta, const float* film, int film_ld, float* affA, float* affB, void* stream);

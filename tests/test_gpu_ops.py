@@ -492,6 +492,35 @@ def test_linear_split_bf16x6_is_fp32_accurate(M, K, N, act, res):
         assert e_split.mean() <= 1.5 * e_fp32.mean() + 1e-8, (e_split.mean(), e_fp32.mean())
 
 
+@pytest.mark.parametrize("nfr,HW,K,N,res", [(128, 256, 96, 384, 1), (128, 64, 64, 512, 1), (6, 64, 64, 96, 0), (3, 1024, 32, 128, 0),
+                                            (129, 64, 32, 384, 1)])
+def test_linear_split_groupnorm_partial_sums(nfr, HW, K, N, res):
+    """csrc/gemm_split.hip epilogue: per-(frame, row block, channel) [sum, sum of squares] of the output, the table the next
+    GroupNorm's fold reads instead of a statistics pass (proj_out + residual of an attention block followed by the next
+    normalization: unet.py:537-538, nn.py:15-17).  All tile classes (128x192, 128x128, 64x128, 64x64), an odd frame count
+    whose last 128-row tile is half empty; checked against sums of the stored output in fp64."""
+    L = _lib.lib()
+    M = nfr * HW
+    a, w, b = rnd(M, K), rnd(N, K, scale=(3.0 / K) ** 0.5), rnd(N, scale=0.1)
+    r = rnd(M, N, seed=4) if res else None
+    ad, bd, rd = dev(a), dev(b), (dev(r) if res else None)
+    out = torch.empty(M, N, device="cuda")
+    split = L.vd_linear_stats_split(M, N, HW)
+    part = torch.full((nfr, split, N, 2), float("nan"), dtype=torch.float64, device="cuda")
+    ws = dev(pack_lin_split(w))
+    _lib.check(L.vd_op_linear_split_stats(_lib.ptr(ad), M, K, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(rd), 0, _lib.ptr(out), N, HW,
+                                          _lib.ptr(part), _lib.current_stream()))
+    torch.cuda.synchronize()
+    close(out.cpu(), a @ w.t() + b + (r if res else 0), **TOL)
+    o64 = out.double().reshape(nfr, HW, N)
+    tot = part.sum(1).cpu()
+    close(tot[..., 0], o64.sum(1).cpu(), atol=1e-3, rtol=1e-5)
+    close(tot[..., 1], (o64 * o64).sum(1).cpu(), atol=1e-3, rtol=1e-5)
+    rows = HW // split                                                # every block of rows on its own
+    blk = o64.reshape(nfr, split, rows, N)
+    close(part[..., 0].cpu(), blk.sum(2).cpu(), atol=1e-3, rtol=1e-5)
+
+
 def pack_wino_split(w):
     O, I = w.shape[:2]
     out = torch.empty(48 * O * I, dtype=torch.int16)

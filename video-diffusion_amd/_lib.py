@@ -142,6 +142,8 @@ SIGNATURES = {
     "vd_pack_conv3_split": (_I, [_P, _P, _I, _I]),
     "vd_op_conv_split": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "vd_op_linear_split": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
+    "vd_op_linear_split_stats": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P]),
+    "vd_linear_stats_split": (_I, [_I, _I, _I]),
     "vd_op_gn_fold": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "vd_op_affine_apply": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "vd_op_affine_act": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _P, _P]),

@@ -147,7 +147,7 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     char tag[56];
     snprintf(tag, sizeof(tag), "M=%d N=%d K=%d k%d s%d%s%s%s", g.M, g.Cout, g.Cin, g.ksz, g.stride, g.ups ? " ups" : "",
              g.affA ? " pro" : (g.act ? " act" : ""), g.res ? " res" : "");
-    VD_REQUIRE(g.stats == nullptr || wino,
+    VD_REQUIRE(g.stats == nullptr || wino || (split_gemm && g.stats_hw > 0),
                "GroupNorm partial sums requested from a kernel that has no such epilogue");
     ProfScope ps(cls, nz * 2.0 * g.M * g.Cout * cin * taps, bytes, st, tag);
     return launch_igemm(g, st);
@@ -269,7 +269,9 @@ struct vd_engine {
     int gn_fold(const Tens& x0, const Tens* x1, int N, int gw, int gb, const float* film,
                 int film_ld, hipStream_t st, Arena& ar, float** A, float** B);
     int linear(const float* a, int M, int K, int pw, int pb, int Nout, const float* wptr, const float* bptr, int act,
-               const float* res, float* out, hipStream_t st);
+               const float* res, float* out, hipStream_t st, const Tens* stats_of = nullptr);
+    void gemm_stats_table(Arena& ar, int M, int K, int Nout, Tens* t);
+    void conv_split_stats_table(Arena& ar, const IgemmArgs& conv, int Cout, Tens* t);
 };
 
 // ------------------------------------------------------------------------------------------ topology
@@ -443,8 +445,40 @@ int vd_engine::build() {
 }
 
 // ------------------------------------------------------------------------------------------ helpers
+static IgemmArgs linear_args(int M, int K, int Nout) {
+    IgemmArgs g{};
+    g.C0 = K; g.Cin = K; g.nfr = M; g.Hs = 1; g.Ws = 1; g.stride = 1; g.ksz = 1; g.Ho = 1; g.Wo = 1;
+    g.wsplit = split_math(); g.ldo = Nout; g.Cout = Nout; g.M = M; g.res_ld = Nout;
+    return g;
+}
+
+// The output of a linear layer that is a GroupNorm's input (t: H x H pixels per frame, rows in (frame, pixel) order): where
+// the split GEMM runs it in one launch, its epilogue writes the per-channel partial sums -- allocate the table (also in the
+// arena's dry run) and let the tensor carry it; otherwise the tensor stays without and gn_fold runs a statistics pass
+void vd_engine::gemm_stats_table(Arena& ar, int M, int K, int Nout, Tens* t) {
+    static const bool off = getenv("VD_NO_GEMM_STATS") != nullptr;                  // A/B switch
+    IgemmArgs g = linear_args(M, K, Nout);
+    g.wfrag = reinterpret_cast<const float*>(this);                                  // any non-null pointer: the shape test only
+    const int HW = t->H * t->H, rows = gemm_split_stats_rows(M, Nout);
+    if (off || !gemm_split_supported(g) || igemm_frames_per_launch(g) < M || HW % rows || M % HW) return;
+    t->split = HW / rows;
+    t->part = ar.get<double>((size_t)(M / HW) * t->split * Nout * 2);
+}
+
+// the same for a 3x3 conv that runs on the split GEMM's implicit-im2col mode (the stride-2 Downsample convs): the rows of
+// its output are the Ho x Wo pixels of consecutive frames
+void vd_engine::conv_split_stats_table(Arena& ar, const IgemmArgs& conv, int Cout, Tens* t) {
+    static const bool off = getenv("VD_NO_GEMM_STATS") != nullptr;
+    IgemmArgs g = conv;
+    g.wfrag = reinterpret_cast<const float*>(this); g.wsplit = split_math(); g.Cout = Cout; g.ldo = Cout; g.res_ld = Cout;
+    const int HW = g.Ho * g.Wo, rows = gemm_split_stats_rows(g.M, Cout);
+    if (off || !conv_split_supported(g) || igemm_frames_per_launch(g) < g.nfr || HW % rows) return;
+    t->split = HW / rows;
+    t->part = ar.get<double>((size_t)g.nfr * t->split * Cout * 2);
+}
+
 int vd_engine::linear(const float* a, int M, int K, int, int, int Nout, const float* wptr, const float* bptr, int act,
-                      const float* resid, float* out, hipStream_t st) {
+                      const float* resid, float* out, hipStream_t st, const Tens* stats_of) {
     IgemmArgs g{};
     g.src0 = a; g.src1 = nullptr; g.C0 = K; g.Cin = K;
     g.nfr = M; g.Hs = 1; g.Ws = 1; g.ups = 0; g.stride = 1; g.pad = 0; g.ksz = 1; g.Ho = 1; g.Wo = 1;
@@ -453,6 +487,7 @@ int vd_engine::linear(const float* a, int M, int K, int, int, int Nout, const fl
     g.bias = bptr; g.affA = nullptr; g.affB = nullptr; g.act = act;
     g.res = resid; g.res_ld = Nout; g.fbias = nullptr; g.fbias_ld = 0;
     g.out = out; g.ldo = Nout; g.Cout = Nout; g.M = M;
+    if (stats_of && stats_of->part) { g.stats = stats_of->part; g.stats_split = stats_of->split; g.stats_hw = stats_of->H * stats_of->H; }
     return igemm_p(g, st);
 }
 
@@ -580,6 +615,8 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
     float* R[3] = {Rall + rrows * C, Rall, Rall + 2 * rrows * C};          // k, q, v as the attention kernel takes them
     float* o = ar.get<float>(tok * C);
     float* xt = ar.get<float>(tok * C);
+    Tens xt_t{xt, C, H};                               // the spatial attention's GroupNorm reads it: statistics from the proj_out GEMM
+    gemm_stats_table(ar, (int)tok, C, C, &xt_t);
     if (!ar.dry) {
         { ProfScope ps(PC_GN_TEMPORAL, 0.0, 8.0 * tok * C, st);
           rc = launch_gn_temporal(x.p, W(a.tp.normw), W(a.tp.normb), B, T, HW, C, xn, st); }
@@ -610,15 +647,17 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
           rc = launch_attn_temporal(ta, st); }
         if (rc) return rc;
         // proj_out + residual on the NORMALISED activations (unet.py:537-538)
-        if ((rc = linear(o, (int)tok, C, 0, 0, C, W(a.tp.projw), W(a.tp.projb), 0, xn, xt, st))) return rc;
+        if ((rc = linear(o, (int)tok, C, 0, 0, C, W(a.tp.projw), W(a.tp.projb), 0, xn, xt, st, &xt_t))) return rc;
     }
     // ---- spatial attention over the HW pixels of each frame               (unet.py:258-267)
     float *A, *Bf;
-    if ((rc = gn_fold(Tens{xt, C, H}, nullptr, N, a.sp.normw, a.sp.normb, nullptr, 0, st, ar, &A, &Bf))) return rc;
+    if ((rc = gn_fold(xt_t, nullptr, N, a.sp.normw, a.sp.normb, nullptr, 0, st, ar, &A, &Bf))) return rc;
     float* xn2 = ar.get<float>(tok * C);
     float* qkv2 = ar.get<float>(tok * 3 * C);
     float* o2 = ar.get<float>(tok * C);
     float* xs = ar.get<float>(tok * C);
+    Tens xs_t{xs, C, H};                               // the block's output: the next ResBlock's GroupNorm (or a skip) reads it
+    gemm_stats_table(ar, (int)tok, C, C, &xs_t);
     if (!ar.dry) {
         { ProfScope ps(PC_ELEMENTWISE, 0.0, 8.0 * tok * C, st); rc = launch_affine_apply(xt, A, Bf, N, HW, C, xn2, st); }
         if (rc) return rc;
@@ -626,9 +665,9 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
         AttnSpatialArgs sa{qkv2, o2, N, HW, C, cfg.num_heads, scale};
         { ProfScope ps(PC_ATTN_SPATIAL, 4.0 * N * (double)HW * HW * C, 16.0 * tok * C, st); rc = launch_attn_spatial(sa, st); }
         if (rc) return rc;
-        if ((rc = linear(o2, (int)tok, C, 0, 0, C, W(a.sp.projw), W(a.sp.projb), 0, xn2, xs, st))) return rc;
+        if ((rc = linear(o2, (int)tok, C, 0, 0, C, W(a.sp.projw), W(a.sp.projb), 0, xn2, xs, st, &xs_t))) return rc;
     }
-    *out = Tens{xs, C, H};
+    *out = xs_t;
     return 0;
 }
 
@@ -677,8 +716,9 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
             } else if (L.type == 0) {                                 // stem: im2col (assemble_kernel) x [64][mc] GEMM
                 const ConvP& c = convs[L.idx];
                 float* o = ar.get<float>((size_t)N * S * S * c.c);
-                if (!ar.dry && (rc = linear(cur.p, N * S * S, STEM_KPAD, 0, 0, c.c, W(c.w), W(c.b), 0, nullptr, o, st))) return rc;
                 nxt = Tens{o, c.c, S};
+                gemm_stats_table(ar, N * S * S, STEM_KPAD, c.c, &nxt);
+                if (!ar.dry && (rc = linear(cur.p, N * S * S, STEM_KPAD, 0, 0, c.c, W(c.w), W(c.b), 0, nullptr, o, st, &nxt))) return rc;
             } else {
                 const ConvP& c = convs[L.idx];
                 const int stride = L.type == 3 ? 2 : 1, ups = L.type == 4 ? 1 : 0;
@@ -686,9 +726,11 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
                 float* o = ar.get<float>((size_t)g.M * c.c);
                 nxt = Tens{o, c.c, g.Ho};
                 if (params[c.w].kind == PK_CONV3W) nxt.part = stats_table(ar, N, g.Ho, c.c, &nxt.split);
+                else if (stride == 2) conv_split_stats_table(ar, g, c.c, &nxt);       // Downsample on the split GEMM
                 if (!ar.dry) {
                     set_w(g, c.w); g.bias = W(c.b); g.out = o; g.ldo = c.c; g.Cout = c.c;
                     g.stats = nxt.part; g.stats_split = nxt.split;
+                    if (nxt.part && params[c.w].kind != PK_CONV3W) g.stats_hw = g.Ho * g.Wo;
                     if ((rc = igemm_p(g, st))) return rc;
                 }
             }
@@ -1328,6 +1370,19 @@ int vd_op_linear_split(const float* a, int M, int K, const void* w_split, const 
     g.out = out; g.ldo = N; g.Cout = N; g.M = M;
     return launch_igemm(g, static_cast<hipStream_t>(stream));
 }
+
+int vd_op_linear_split_stats(const float* a, int M, int K, const void* w_split, const float* bias, const float* res, int act,
+                             float* out, int N, int HW, double* gn_part, void* stream) {
+    IgemmArgs g{};
+    g.src0 = a; g.C0 = K; g.Cin = K; g.nfr = M; g.Hs = g.Ws = g.Ho = g.Wo = 1; g.stride = 1; g.ksz = 1;
+    g.wfrag = static_cast<const float*>(w_split); g.wsplit = 1; g.bias = bias; g.act = act; g.res = res; g.res_ld = N;
+    g.out = out; g.ldo = N; g.Cout = N; g.M = M;
+    VD_REQUIRE(gn_part && HW > 0 && gemm_split_supported(g), "vd_op_linear_split_stats: shape not covered by gemm_split.hip");
+    g.stats = gn_part; g.stats_hw = HW; g.stats_split = HW / gemm_split_stats_rows(M, N);
+    return launch_igemm(g, static_cast<hipStream_t>(stream));
+}
+
+int vd_linear_stats_split(int M, int N, int HW) { return HW / gemm_split_stats_rows(M, N); }
 
 int vd_pack_conv3_wino(const float* host_oihw, float* host_out, int O, int I) {
     VD_REQUIRE(host_oihw && host_out && O % 64 == 0 && I % 16 == 0, "O multiple of 64, I multiple of 16");

@@ -220,6 +220,31 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         }
     }
 
+    // GroupNorm partial sums of the output (the layout gn_stats_partial / the Winograd epilogue write): a wave tile is BM/2
+    // rows of ONE frame (a.stats_hw % (BM/2) == 0), a lane holds 16 rows of its column per M-tile, the other 16 sit in lane ^ 32
+    if (a.stats) {
+        const int row0 = m0 + wm * (BM / 2);
+        if (row0 < a.M) {
+            const int fr = row0 / a.stats_hw, sp = (row0 - fr * a.stats_hw) / (BM / 2);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                // every term through fp64, as in gn_stats_partial: the stem's output carries per-frame offsets (mask channels)
+                // far above its spread, and E[x^2] - E[x]^2 amplifies an fp32 rounding of the partial sums by that ratio
+                double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const double v = (double)acc[i][j][r]; d0 += v; d1 += v * v; }
+                d0 += __shfl_xor(d0, 32);
+                d1 += __shfl_xor(d1, 32);
+                const int co = n0 + wn * (BN / 2) + j * 32 + lr;
+                if (lh == 0 && co < a.Cout) {
+                    double* o = a.stats + (((size_t)fr * a.stats_split + sp) * a.Cout + co) * 2;
+                    o[0] = d0; o[1] = d1;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -272,8 +297,18 @@ int gemm_split_tile_class(int M, int Cout) {
     return (long)((M + 127) / 128) * (Cout / 192) >= 384 ? 4 : base;
 }
 
+int gemm_split_stats_rows(int M, int Cout) {
+    const int c = gemm_split_tile_class(M, Cout);
+    return c == 2 || c == 3 ? 32 : 64;
+}
+
 int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s) {
     if (tile_class == 0) tile_class = gemm_split_tile_class(a.M, a.Cout);
+    if (a.stats) {
+        const int rows = tile_class == 2 || tile_class == 3 ? 32 : 64;
+        VD_REQUIRE(a.zcount <= 1 && a.stats_hw > 0 && a.stats_hw % rows == 0 && a.M % a.stats_hw == 0 &&
+                   a.stats_split == a.stats_hw / rows, "GroupNorm partial sums from the GEMM epilogue: whole frames of a multiple of the wave tile's rows");
+    }
     switch (tile_class) {
         case 4: return launch_gs<128, 192>(a, s);
         case 0: return launch_gs<128, 128>(a, s);

@@ -250,6 +250,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     const int per = igemm_frames_per_launch(a);
     VD_REQUIRE(per > 0, "one frame of this layer exceeds 2^28 elements");
     if (per >= a.nfr) return launch_igemm_one(a, s);
+    VD_REQUIRE(!(a.stats && a.stats_hw > 0), "GroupNorm partial sums from the split GEMM: one launch only (the tile choice, and with it the table, depends on M)");
     const size_t HWi = (size_t)a.Hs * a.Ws, HWo = (size_t)a.Ho * a.Wo;
     for (int f0 = 0; f0 < a.nfr; f0 += per) {
         IgemmArgs b = a;

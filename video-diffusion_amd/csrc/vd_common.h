@@ -60,6 +60,9 @@ struct IgemmArgs {
     // pass over the tensor.  stats_split = blocks per frame (conv_wino_stats_split).  Null: not produced.
     double* stats;
     int stats_split;
+    // gemm_split.hip (linear layers whose rows are the pixels of consecutive frames): rows per frame; the table is then
+    // [frame][stats_split = stats_hw / rows of a wave tile][Cout][2] (gemm_split_stats_rows)
+    int stats_hw;
     // gemm_frag.hip only: zcount > 1 runs zcount independent problems of identical shape in one launch (blockIdx.z);
     // problem z reads src0 + z*zs_a, wfrag + z*zs_w, bias + z*zs_bias and writes out + z*zs_out (element strides).
     // The three RPE-net output layers of an attention block (unet.py:283-298) go out this way.
@@ -140,6 +143,7 @@ bool conv_split_supported(const IgemmArgs& a);          // 3x3, stride 1|2: the 
 void pack_conv3_split(const float* w_oihw, unsigned short* out, int Cout, int Cin);
 int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s);
 int gemm_split_tile_class(int M, int Cout);               // igemm_tile_class, or 4 = the 128x192 tile
+int gemm_split_stats_rows(int M, int Cout);               // rows of a wave tile = rows behind one GroupNorm partial sum (64 | 32)
 void pack_linear_split(const float* w, unsigned short* out_base, int rows, int K, int n_total, int row0);          // blocks per frame = partial sums per (frame, channel)
 int launch_conv_wino(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino(const float* oihw, float* out, int O, int I);      // out: 16*O*I floats
