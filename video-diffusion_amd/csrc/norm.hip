@@ -163,13 +163,18 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
         if (act) { r.x = silu_f(r.x); r.y = silu_f(r.y); r.z = silu_f(r.z); r.w = silu_f(r.w); }
         return r;
     };
+#ifndef VD_AA_NT
+#define VD_AA_NT 1          // bit 0 nontemporal loads (the source is read once: 5.41 -> 5.79 TB/s), bit 1 nontemporal stores (4.93)
+#endif
+    auto ld4 = [&](const float* q) { return (VD_AA_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : *reinterpret_cast<const f32x4*>(q); };
+    auto st4 = [&](float* q, f32x4 v) { if (VD_AA_NT & 2) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(q)); else *reinterpret_cast<f32x4*>(q) = v; };
     int p = p_begin + pl;
     for (; p + 3 * ppi < p_end; p += 4 * ppi) {           // four loads in flight
         f32x4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(p + u * ppi) * ld);
+        for (int u = 0; u < 4; ++u) v[u] = ld4(src + (size_t)(p + u * ppi) * ld);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(dst + (size_t)(p + u * ppi) * C) = one(v[u]);
+        for (int u = 0; u < 4; ++u) st4(dst + (size_t)(p + u * ppi) * C, one(v[u]));
     }
     for (; p < p_end; p += ppi) *reinterpret_cast<f32x4*>(dst + (size_t)p * C) = one(*reinterpret_cast<const f32x4*>(src + (size_t)p * ld));
 }
