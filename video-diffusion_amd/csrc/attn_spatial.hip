@@ -168,7 +168,7 @@ constexpr int attn_rowv(int F) {           // bytes per V row: >= 64 per 32-feat
 }
 
 template <int F>
-__global__ __launch_bounds__(256) void attn_spatial_split_kernel(AttnSpatialArgs a) {
+__global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kernel(AttnSpatialArgs a) {
     constexpr int KS = (F + 15) / 16, FK = KS * 16;     // k-steps of the QK^T contraction (zero padded)
     constexpr int FT = (F + 31) / 32;                   // 32-wide output tiles over F
     constexpr int ROWK = FK * 2 + 16, ROWV = attn_rowv(F);
@@ -220,26 +220,43 @@ __global__ __launch_bounds__(256) void attn_spatial_split_kernel(AttnSpatialArgs
     const int koff = lr * ROWK + lh * 16;
     typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4;
 
-    for (int k0 = 0; k0 < a.L; k0 += 32) {
-        __syncthreads();
-        for (int i = tid; i < 32 * (F / 4); i += 256) {
+    // K / V rows of a key tile: requested one tile ahead into registers (the loads fly under the previous tile's MFMAs),
+    // split and stored once the tile before has been consumed
+    constexpr int NIT = (32 * (F / 4) + 255) / 256;
+    f32x4 pk[NIT], pv[NIT];
+    auto prefetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + u * 256;
             const int r = i / (F / 4), c4 = i - r * (F / 4);
             const int key = k0 + r;
-            f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
-            if (key < a.L) {
+            pk[u] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[u] = pk[u];
+            if (i < 32 * (F / 4) && key < a.L) {
                 const float* p = base + (size_t)key * C3 + c4 * 4;
-                kv = *reinterpret_cast<const f32x4*>(p + a.C);
-                vv = *reinterpret_cast<const f32x4*>(p + 2 * a.C);
+                pk[u] = *reinterpret_cast<const f32x4*>(p + a.C);
+                pv[u] = *reinterpret_cast<const f32x4*>(p + 2 * a.C);
             }
-            u32x2_t k1, k2, k3, v1, v2, v3;
-            split_f4(kv, k1, k2, k3);
-            split_f4(vv, v1, v2, v3);
-            char* kd = Ks + r * ROWK + c4 * 8;
-            char* vd = Vs + r * ROWV + c4 * 8;
-            *reinterpret_cast<u32x2_t*>(kd) = k1; *reinterpret_cast<u32x2_t*>(kd + KPL) = k2; *reinterpret_cast<u32x2_t*>(kd + 2 * KPL) = k3;
-            *reinterpret_cast<u32x2_t*>(vd) = v1; *reinterpret_cast<u32x2_t*>(vd + VPL) = v2; *reinterpret_cast<u32x2_t*>(vd + 2 * VPL) = v3;
+        }
+    };
+    prefetch(0);
+    for (int k0 = 0; k0 < a.L; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + u * 256;
+            if (i < 32 * (F / 4)) {
+                const int r = i / (F / 4), c4 = i - r * (F / 4);
+                u32x2_t k1, k2, k3, v1, v2, v3;
+                split_f4(pk[u], k1, k2, k3);
+                split_f4(pv[u], v1, v2, v3);
+                char* kd = Ks + r * ROWK + c4 * 8;
+                char* vd = Vs + r * ROWV + c4 * 8;
+                *reinterpret_cast<u32x2_t*>(kd) = k1; *reinterpret_cast<u32x2_t*>(kd + KPL) = k2; *reinterpret_cast<u32x2_t*>(kd + 2 * KPL) = k3;
+                *reinterpret_cast<u32x2_t*>(vd) = v1; *reinterpret_cast<u32x2_t*>(vd + VPL) = v2; *reinterpret_cast<u32x2_t*>(vd + 2 * VPL) = v3;
+            }
         }
         __syncthreads();
+        if (k0 + 32 < a.L) prefetch(k0 + 32);
 
         // S^T = K . Q^T, six piece products per k-step, small terms first
         f32x16 st;
