@@ -227,8 +227,8 @@ int vd_op_conv_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int st
                      const float* res, float* out, int Cout, void* stream);
 /* The same arithmetic for the 3x3 stride-1 convs: Winograd F(2x2,3x3) whose element products run as six bf16 piece
  * products of the exactly split fp32 operands, 64 couts per block.  Two kernels share the weight image: csrc/conv_wino_r64.hip
- * (maps >= 16x16: input transform and split in the MFMA fragment layout, in registers) and csrc/conv_wino_s64.hip (maps
- * >= 8x8: block-wide transform through LDS).  Weights: OIHW -> U = G g G^T (fp64, row 3 negated) split into
+ * (input transform and split in the MFMA fragment layout, in registers: the engine's choice) and csrc/conv_wino_s64.hip
+ * (block-wide transform through LDS); maps >= 8x8.  Weights: OIHW -> U = G g G^T (fp64, row 3 negated) split into
  * [I/16][16][O/32][3][64][8] bf16 = 48*O*I uint16.  One plain source tensor, stride 1, square power-of-two maps,
  * O % 64 == 0, I % 32 == 0; gn_part as vd_op_conv_stats (or NULL).  vd_op_conv_wino_split takes the kernel the engine
  * would (and cuts big windows along frames); the other two run the named kernel in one launch. */

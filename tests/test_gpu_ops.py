@@ -534,7 +534,8 @@ def pack_wino_split(w):
                                                (37, 64, 256, 16, 0), (1100, 32, 64, 8, 0), (8, 64, 128, 32, 0), (64, 32, 128, 32, 0),
                                                (3, 224, 64, 16, 1), (300, 64, 64, 16, 0), (16, 128, 192, 64, 0)])
 def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups, kernel):
-    """csrc/conv_wino_r64.hip (maps >= 16x16) and csrc/conv_wino_s64.hip (>= 8x8): Winograd F(2x2,3x3) with the element
+    """csrc/conv_wino_r64.hip and csrc/conv_wino_s64.hip (maps >= 8x8; 8x8 maps go four frames to an item, incl. frame counts
+    that are not a multiple of four): Winograd F(2x2,3x3) with the element
     products as six bf16 piece products of exactly split fp32 operands; kernel 'split' is whichever the engine takes.
     Held to the op tolerance against torch fp32, required to be no further from an fp64 conv than the fp32-MFMA Winograd
     kernel, and the GroupNorm partial sums checked against the stored output.  Several shapes have more work items than
@@ -543,8 +544,8 @@ def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups, ke
     than one cout block); the r64 cases cover 2..14 channel chunks, the x2 upsampled source and all three tile grids."""
     if Cout % 64:
         pytest.skip("the split Winograd kernels own 64 couts per block (the engine sends other widths to the fragment kernels)")
-    if kernel == "r64" and ((H << ups) < 16 or os.environ.get("VD_CONV_R64", "1").startswith("0")):
-        pytest.skip("conv_wino_r64.hip takes maps >= 16x16 (and VD_CONV_R64=0 switches it off)")
+    if kernel == "r64" and os.environ.get("VD_CONV_R64", "1").startswith("0"):
+        pytest.skip("VD_CONV_R64=0 switches conv_wino_r64.hip off")
     L = _lib.lib()
     op = {"s64": L.vd_op_conv_wino_s64, "r64": L.vd_op_conv_wino_r64, "split": L.vd_op_conv_wino_split}[kernel]
     x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, scale=(3.0 / (9 * Cin)) ** 0.5), rnd(Cout, scale=0.1)

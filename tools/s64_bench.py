@@ -40,7 +40,7 @@ def main():
         part = torch.empty(nfr, split, Cout, 2, dtype=torch.float64, device="cuda")
 
         def run():
-            OP = OPS["s64" if args.kernel == "r64" and H < 16 else args.kernel]
+            OP = OPS[args.kernel]
             _lib.check(OP(_lib.ptr(x0), Cin, nfr, Hs, Hs, ups, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(res), None, 0,
                                              _lib.ptr(out), Cout, _lib.ptr(part), _lib.current_stream()))
         for _ in range(2):

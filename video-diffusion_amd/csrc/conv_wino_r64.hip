@@ -29,12 +29,21 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct WinoR64Geom { int tiles_x, tiles_y, nbx, ncb, nitems, xcd_order; };
 
+// Geometry of an item's patch image.  TF4 = false: one frame, 8 x 8 tiles (maps >= 16 x 16).  TF4 = true: FOUR frames of an
+// 8 x 8 map, 4 x 4 tiles each, a 10 x 10 patch per frame at a frame stride of FSB bytes (every stride a multiple of 256 bytes,
+// so the bank argument for the swizzle holds across tile rows and frames alike).
+template <bool TF4> struct R64G {
+    static constexpr int P = TF4 ? 10 : 18;                 // patch width
+    static constexpr int SPP = TF4 ? 6 : 10;                // 64-byte pixel slots per plane row (P / 2 pixels + 1 pad)
+    static constexpr int PLB = SPP * 64, RSB = 2 * PLB;
+    static constexpr int FSB = TF4 ? P * RSB : 0;           // frame stride
+    static constexpr int NX = TF4 ? 8 : 6;                  // DMA instructions per thread and patch (256 threads x 16 B each)
+    static constexpr int XBUF = NX * 4096;
+    static constexpr int MOFF = TF4 ? 2 * FSB : 8 * RSB;    // second M-tile: two frames / four tile rows further
+};
 namespace r64 {
-constexpr int P = 18, SPP = 10, PLB = SPP * 64, RSB = 2 * PLB;
-constexpr int NX = 6;                       // DMA instructions per thread and patch (256 threads x 16 B x 6 >= 18 * RSB)
-constexpr int XBUF = NX * 4096;             // 24576
 constexpr int NB = 4;                       // patch buffers
-constexpr int LDS_BYTES = NB * XBUF;        // 98304; the output transform's Z image (64 KB) overlays it
+template <bool TF4> constexpr int lds_bytes() { return NB * R64G<TF4>::XBUF; }   // 98304 | 131072; the Z image (64 KB) overlays it
 }  // namespace r64
 
 #ifdef VD_WINO_TIMING
@@ -57,8 +66,11 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #define VD_R64_SKIP 0      // timing-only builds (results wrong): 1 no split, 2 no transform at all, 4 no weight loads, 16 no patch DMA,
 #endif                     // 64 no MFMA, 128 no patch reads
 
+template <bool TF4>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, WinoR64Geom g) {
     using namespace r64;
+    using G = R64G<TF4>;
+    constexpr int P = G::P, SPP = G::SPP, PLB = G::PLB, RSB = G::RSB, NX = G::NX, XBUF = G::XBUF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -79,19 +91,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     }
     const int bxx = bx % g.tiles_x; bx /= g.tiles_x;
     const int byy = bx % g.tiles_y; bx /= g.tiles_y;
-    const int f0 = bx;
-    const int ox0 = bxx * 16, oy0 = byy * 16;
+    const int f0 = TF4 ? bx * 4 : bx;                                 // first frame of the item
+    const int ox0 = bxx * 16, oy0 = byy * 16;                        // TF4: the whole 8 x 8 map (tiles_x = tiles_y = 1)
 
     // ---- patch staging: thread -> 16-byte LDS slots e*256 + tid; the slot at quad position lq of patch row py holds the
     // pixel's quad lq ^ ((py >> 1) & 3)
     unsigned xo[NX];
 #pragma unroll
     for (int e = 0; e < NX; ++e) {
-        const int gs = e * 256 + tid, lq = gs & 3, ps = gs >> 2;
+        const int gs = e * 256 + tid, lq = gs & 3, ps0 = gs >> 2;
+        const int fl = TF4 ? ps0 / (P * 2 * SPP) : 0, ps = TF4 ? ps0 % (P * 2 * SPP) : ps0;   // frame of the item, slot inside its image
         const int py = ps / (2 * SPP), r = ps % (2 * SPP), pxh = r % SPP, px = 2 * pxh + r / SPP;
         const int ly = oy0 + py - 1, lx = ox0 + px - 1;
-        const bool in = py < P && pxh < P / 2 && ly >= 0 && ly < Hl && lx >= 0 && lx < Wl;
-        xo[e] = in ? (unsigned)((f0 * a.Hs + (ly >> a.ups)) * a.Ws + (lx >> a.ups)) * (unsigned)(a.Cin * 4) + (unsigned)((lq ^ ((py >> 1) & 3)) * 16)
+        const bool in = fl < (TF4 ? 4 : 1) && f0 + fl < a.nfr && py < P && pxh < P / 2 && ly >= 0 && ly < Hl && lx >= 0 && lx < Wl;
+        xo[e] = in ? (unsigned)(((f0 + fl) * a.Hs + (ly >> a.ups)) * a.Ws + (lx >> a.ups)) * (unsigned)(a.Cin * 4) + (unsigned)((lq ^ ((py >> 1) & 3)) * 16)
                    : 0x80000000u;
     }
     const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
@@ -109,12 +122,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     // rows of B^T as d[X] + s*d[S]: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d3 - d1 (row 3 of U is negated on the host)
     const int rowX = wi, rowS = wi < 2 ? 2 : 1;
     const float tsg = wi == 1 ? 1.f : -1.f;
-    const int ttx = lr & 7, ttyl = lr >> 3;
+    // TF4: tile column lr & 3, tile row (lr >> 2) & 3, frame 2m + (lr >> 4)
+    const int ttx = TF4 ? lr & 3 : lr & 7, ttyl = TF4 ? (lr >> 2) & 3 : lr >> 3, tfl = TF4 ? lr >> 4 : 0;
     int adr[2][2];                                                    // [X | S][quad h of the lane's eight channels]
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        adr[0][h] = (2 * ttyl + rowX) * RSB + ttx * 64 + (((2 * lh + h) ^ ((ttyl + (rowX >> 1)) & 3)) * 16);
-        adr[1][h] = (2 * ttyl + rowS) * RSB + ttx * 64 + (((2 * lh + h) ^ ((ttyl + (rowS >> 1)) & 3)) * 16);
+        adr[0][h] = tfl * G::FSB + (2 * ttyl + rowX) * RSB + ttx * 64 + (((2 * lh + h) ^ ((ttyl + (rowX >> 1)) & 3)) * 16);
+        adr[1][h] = tfl * G::FSB + (2 * ttyl + rowS) * RSB + ttx * 64 + (((2 * lh + h) ^ ((ttyl + (rowS >> 1)) & 3)) * 16);
     }
     float t[4][8];                                                    // t[column][channel] of the group being transformed
     f32x4 stx[2], sts[2];                                             // one column of the patch rows X and S, in flight
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     // column c of group (chunk, m): four reads
     auto t_read = [&](int chunk, int m, int c) {
         if (VD_R64_SKIP & (2 | 128)) return;
-        const char* rb = lds + (chunk & (NB - 1)) * XBUF + m * (8 * RSB) + (c & 1) * PLB + (c >> 1) * 64;
+        const char* rb = lds + (chunk & (NB - 1)) * XBUF + m * G::MOFF + (c & 1) * PLB + (c >> 1) * 64;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             stx[h] = *reinterpret_cast<const f32x4*>(rb + adr[0][h]);
@@ -280,13 +294,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int tt = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int tx = tt & 7, ty = tt >> 3;
-            oo[m][r] = (unsigned)(((f0 * Hl + oy0 + 2 * ty + p) * Wl + ox0 + 2 * tx + q) * a.ldo + cob0 * 32 + lr) * 4u;
+            const int tx = TF4 ? tt & 3 : tt & 7, ty = TF4 ? (tt >> 2) & 3 : tt >> 3, nf = f0 + (TF4 ? tt >> 4 : 0);
+            const unsigned o = (unsigned)(((nf * Hl + oy0 + 2 * ty + p) * Wl + ox0 + 2 * tx + q) * a.ldo + cob0 * 32 + lr) * 4u;
+            oo[m][r] = nf < a.nfr ? o : 0x80000000u;                 // TF4: a frame past the end is neither read nor stored
         }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int co = (cob0 + n) * 32 + lr;
-        const float bv = (a.bias ? a.bias[co] : 0.f) + (a.fbias ? a.fbias[(size_t)f0 * a.fbias_ld + co] : 0.f);
+        const float bias = a.bias ? a.bias[co] : 0.f;
+        // per-frame bias: TF1 one frame; TF4 registers 0..7 of M-tile m belong to frame 2m, 8..15 to frame 2m + 1
+        float bvf[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                bvf[m][hf] = bias + (a.fbias ? a.fbias[(size_t)min(f0 + (TF4 ? 2 * m + hf : 0), a.nfr - 1) * a.fbias_ld + co] : 0.f);
         f32x16 rv[2];
         if (n) __syncthreads();                                      // the previous Z is no longer read
 #pragma unroll
@@ -303,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
         }
         __syncthreads();
         const float* zw = Zs + wi * 2048 + lane * 4;                 // Z[p + k][q] is plane wi + 2k
-        float gsum0 = 0.f, gsum1 = 0.f;
+        float gsum[TF4 ? 4 : 1][2] = {};
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             f32x16 y;
@@ -315,26 +337,38 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
                 y[4 * c4] = v.x; y[4 * c4 + 1] = v.y; y[4 * c4 + 2] = v.z; y[4 * c4 + 3] = v.w;
             }
             y += rv[m];
-            y += bv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] += bvf[m][r >> 3];
 #pragma unroll
             for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)y[r]), osrc, oo[m][r], n * 128, 0);
             if (a.stats) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { gsum0 += y[r]; gsum1 += y[r] * y[r]; }
+                for (int r = 0; r < 16; ++r) {
+                    const int fs = TF4 ? 2 * m + (r >> 3) : 0;
+                    gsum[fs][0] += y[r]; gsum[fs][1] += y[r] * y[r];
+                }
             }
         }
         if (a.stats) {                                               // GroupNorm partial sums of the output (conv_wino.hip)
+            constexpr int NFS = TF4 ? 4 : 1;
             __syncthreads();
-            double* red = reinterpret_cast<double*>(smem);           // [wave 4][lh 2][lr 32][2]
-            double* d = red + (((wi * 2 + lh) * 32 + lr) * 2);
-            d[0] = (double)gsum0; d[1] = (double)gsum1;
+            double* red = reinterpret_cast<double*>(smem);           // [wave 4][lh 2][frame NFS][lr 32][2]
+#pragma unroll
+            for (int fs = 0; fs < NFS; ++fs) {
+                double* d = red + ((((wi * 2 + lh) * NFS + fs) * 32 + lr) * 2);
+                d[0] = (double)gsum[fs][0]; d[1] = (double)gsum[fs][1];
+            }
             __syncthreads();
-            if (tid < 32) {
+            if (tid < NFS * 32) {
+                const int fs = tid >> 5, c = tid & 31;
                 double s = 0.0, ss = 0.0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { s += red[(k * 32 + tid) * 2]; ss += red[(k * 32 + tid) * 2 + 1]; }
-                double* o = a.stats + (((size_t)f0 * a.stats_split + byy * g.tiles_x + bxx) * a.Cout + (cob0 + n) * 32 + tid) * 2;
-                o[0] = s; o[1] = ss;
+                for (int k = 0; k < 8; ++k) { s += red[((k * NFS + fs) * 32 + c) * 2]; ss += red[((k * NFS + fs) * 32 + c) * 2 + 1]; }
+                const int nf = f0 + fs, sp = TF4 ? 0 : byy * g.tiles_x + bxx;
+                if (nf < a.nfr) {
+                    double* o = a.stats + (((size_t)nf * a.stats_split + sp) * a.Cout + (cob0 + n) * 32 + c) * 2;
+                    o[0] = s; o[1] = ss;
+                }
             }
         }
     }
@@ -346,7 +380,7 @@ static bool r64_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 bool conv_wino_r64_supported(const IgemmArgs& a) {
     static const bool on = [] { const char* e = getenv("VD_CONV_R64"); return !(e && e[0] == '0'); }();   // A/B switch: 0 = conv_wino_s64.hip everywhere
     const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
-    return on && a.wsplit == 2 && a.wwino != nullptr && a.ksz == 3 && a.stride == 1 && a.pad == 1 && Hl == Wl && r64_pow2(Hl) && Hl >= 16 &&
+    return on && a.wsplit == 2 && a.wwino != nullptr && a.ksz == 3 && a.stride == 1 && a.pad == 1 && Hl == Wl && r64_pow2(Hl) && Hl >= 8 &&
            a.Cout % 64 == 0 && a.Cin % 32 == 0 && a.src1 == nullptr && a.C0 == a.Cin && a.affA == nullptr && a.act == 0 &&
            (size_t)a.nfr * a.Hs * a.Ws * a.Cin < (1u << 29) && (size_t)a.Cin * a.Cout * 96 < (1u << 31) &&
            (size_t)a.nfr * Hl * Wl * a.ldo < (1u << 29) && (a.res == nullptr || a.res_ld == a.ldo);
@@ -356,17 +390,20 @@ int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
     const int Hl = a.Hs << a.ups;
     VD_REQUIRE(a.stats == nullptr || a.stats_split == conv_wino_stats_split(Hl), "GroupNorm partial table: split");
     WinoR64Geom g;
-    g.tiles_x = Hl / 16; g.tiles_y = Hl / 16;
-    g.nbx = g.tiles_x * g.tiles_y * a.nfr;
+    const bool tf4 = Hl == 8;                       // four frames of 4 x 4 tiles per item
+    g.tiles_x = tf4 ? 1 : Hl / 16; g.tiles_y = g.tiles_x;
+    g.nbx = g.tiles_x * g.tiles_y * (tf4 ? (a.nfr + 3) / 4 : a.nfr);
     g.ncb = a.Cout / 64;
     g.nitems = g.nbx * g.ncb;
     g.xcd_order = g.nbx % 8 == 0;
     static bool attr = false;
     if (!attr) {
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(conv3x3_wino_r64_kernel, dim3(g.nitems), dim3(256), r64::LDS_BYTES, s, a, g);
+    if (tf4) hipLaunchKernelGGL(conv3x3_wino_r64_kernel<true>, dim3(g.nitems), dim3(256), r64::lds_bytes<true>(), s, a, g);
+    else hipLaunchKernelGGL(conv3x3_wino_r64_kernel<false>, dim3(g.nitems), dim3(256), r64::lds_bytes<false>(), s, a, g);
     VD_HIP(hipGetLastError());
     return 0;
 }

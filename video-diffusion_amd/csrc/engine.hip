@@ -1316,7 +1316,7 @@ static int op_conv_wino_split(int kernel, const float* src0, int Cin, int nfr, i
     if (kernel == 0) return launch_igemm(g, static_cast<hipStream_t>(stream));       // the engine's choice
     VD_REQUIRE(igemm_frames_per_launch(g) >= nfr, "vd_op_conv_wino_*: window too large for one launch");
     if (kernel == 1) return launch_conv_wino_s64(g, static_cast<hipStream_t>(stream));
-    VD_REQUIRE(conv_wino_r64_supported(g), "vd_op_conv_wino_r64: maps >= 16x16 (and VD_CONV_R64 not 0)");
+    VD_REQUIRE(conv_wino_r64_supported(g), "vd_op_conv_wino_r64: VD_CONV_R64=0 switches the kernel off");
     return launch_conv_wino_r64(g, static_cast<hipStream_t>(stream));
 }
 
