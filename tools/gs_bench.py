@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from video_diffusion_amd import _lib  # noqa: E402
 
 L = _lib.lib()
-for M, K, N, res in [(32768, 384, 1152, 0), (8192, 512, 1536, 0), (32768, 384, 384, 1), (8192, 512, 512, 1), (131072, 256, 256, 0)]:
+for M, K, N, res in [(32768, 384, 1152, 0), (8192, 512, 1536, 0), (32768, 384, 384, 1), (8192, 512, 512, 1), (131072, 256, 256, 0), (524288, 256, 128, 0), (524288, 384, 128, 0), (131072, 512, 256, 0), (131072, 640, 256, 0)]:
     a = torch.rand(M, K, device="cuda") - 0.5
     w = torch.randint(-2000, 2000, (3 * N * K,), device="cuda", dtype=torch.int16)
     b = torch.rand(N, device="cuda")
