@@ -10,8 +10,8 @@
 // Here lane (tile r, k-half h) of wave i reads the two patch rows its Winograd row combines -- 4 columns x 8 channels,
 // sixteen ds_read_b128 per M-tile and chunk, straight from the raw patch -- and forms t = d[X] + s*d[S], the four column
 // combinations and their split in its own registers: the result IS the A fragment.  Same vector-ALU work per MFMA (5.0 per
-// slot), no V image, no stores, no fragment reads, ONE barrier per chunk (patch hand-over), and the LDS that held V now
-// holds four patches: a patch is requested four chunks ahead.
+// slot), no V image, no stores, no fragment reads, ONE barrier per TWO chunks (patch hand-over), and the LDS that held V
+// now holds four patches: a patch is requested three or four chunks ahead.
 //
 // Patch image (LDS-DMA, as conv_wino_s64.hip): [row 18][x parity 2][slot 10][64 B = 16 channels of one pixel]; the four
 // 16-byte quads of a pixel are stored at quad ^ ((row >> 1) & 3), so that the 16 lanes of a ds_read_b128 group (four tile
@@ -61,6 +61,9 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 }
 #else
 #define R64_STAMP(i)
+#endif
+#ifndef VD_R64_BAR2
+#define VD_R64_BAR2 1      // one block barrier per two chunks (0: per chunk; same-box A/B of the conv class 18.57 -> 18.41 ms)
 #endif
 #ifndef VD_R64_SKIP
 #define VD_R64_SKIP 0      // timing-only builds (results wrong): 1 no split, 2 no transform at all, 4 no weight loads, 16 no patch DMA,
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     // ---- prologue: four patches and the weights of chunk 0 requested; group (0, 0) transformed whole, position 0 split,
     // column 0 of group (0, 1) in flight -- the state the loop expects at the top of a group
 #pragma unroll
-    for (int c = 0; c < NB; ++c) x_dma(c);
+    for (int c = 0; c < (VD_R64_BAR2 ? 3 : NB); ++c) x_dma(c);
 #pragma unroll
     for (int j = 0; j < 3; ++j) { b_load(0, j, 0); b_load(0, j, 1); }
     asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");  // every patch requested so far has landed; the weights may be in flight
@@ -229,8 +232,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     // first split step of a channel pair; 6..9: second) or, k 10 and 11, of the next group's t (column ord[j], in place: its
     // last reader ran earlier in this group) + the reads of the column after it.  Products in the order (A2,B0) (A1,B1)
     // (A1,B0) (A0,B2) (A0,B1) (A0,B0).  Weights: one register set, fragment (j, n) reloaded in the position after its last use.
-    // Patch of chunk c: first read in position 3 of group (c - 1, 0), behind that group's barrier (the only one of a chunk);
-    // last read in position 2 of group (c, 0); its buffer is requested again, for chunk c + 4, behind the barrier of (c, 0).
+    // Patch of chunk c: first read in position 3 of group (c - 1, 0), last read in position 2 of group (c, 0); the block's only
+    // barrier sits in front of position 3 of the even groups (c, 0): it hands over patches c + 1, c + 2 and frees two buffers.
     constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
     constexpr int ORD[4] = {0, 2, 1, 3};
     for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -245,8 +248,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
                     if (m == 0 && j == 3 && k == 0) {
                         // patch chunk + 1 has landed in every wave; nobody reads patch chunk any more (loads return in order:
                         // the 18 youngest are weight loads)
+#if VD_R64_BAR2
+                        // one barrier per TWO chunks (the channel chunks come in pairs: Cin % 32 == 0): at an even chunk the
+                        // patches chunk + 1 and chunk + 2 (requested two chunks ago) have landed in every wave, and the buffers
+                        // of chunk - 1 and chunk are free for chunk + 3 and chunk + 4
+                        if ((chunk & 1) == 0) {
+                            asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                            x_dma(chunk + 3);
+                            x_dma(chunk + 4);
+                        }
+#else
                         asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                         x_dma(chunk + NB);                                    // past the last chunk: zeros / stale, never used
+#endif
                     }
                     if (!(VD_R64_SKIP & 64))
                         acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][PA[q]], bfr[j][n][PB[q]], acc[m][j][n], 0, 0, 0);
