@@ -65,6 +65,9 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #ifndef VD_R64_BAR2
 #define VD_R64_BAR2 1      // one block barrier per two chunks (0: per chunk; same-box A/B of the conv class 18.57 -> 18.41 ms)
 #endif
+#ifndef VD_R64_DMA_LATE
+#define VD_R64_DMA_LATE 1  // patches requested behind the chunk pair's last weight loads (0: at the barrier; conv class 18.02 -> 17.78 ms)
+#endif
 #ifndef VD_R64_SKIP
 #define VD_R64_SKIP 0      // timing-only builds (results wrong): 1 no split, 2 no transform at all, 4 no weight loads, 16 no patch DMA,
 #endif                     // 64 no MFMA, 128 no patch reads
@@ -251,17 +254,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #if VD_R64_BAR2
                         // one barrier per TWO chunks (the channel chunks come in pairs: Cin % 32 == 0): at an even chunk the
                         // patches chunk + 1 and chunk + 2 (requested two chunks ago) have landed in every wave, and the buffers
-                        // of chunk - 1 and chunk are free for chunk + 3 and chunk + 4
+                        // of chunk - 1 and chunk are free for chunk + 3 and chunk + 4 (requested five positions on, see below)
                         if ((chunk & 1) == 0) {
                             asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if !VD_R64_DMA_LATE
                             x_dma(chunk + 3);
                             x_dma(chunk + 4);
+#endif
                         }
 #else
                         asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                         x_dma(chunk + NB);                                    // past the last chunk: zeros / stale, never used
 #endif
                     }
+#if VD_R64_DMA_LATE
+                    // the two patches are requested BEHIND this chunk pair's last weight loads: loads return in order, and a
+                    // weight fragment requested behind a patch waits for it
+                    if (m == 0 && j == 0 && k == 4 && (chunk & 1) == 1) { x_dma(chunk + 2); x_dma(chunk + 3); }
+#endif
                     if (!(VD_R64_SKIP & 64))
                         acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][PA[q]], bfr[j][n][PB[q]], acc[m][j][n], 0, 0, 0);
                     // the next position's fragment: position j + 1 of this group, or position 0 of the next one
