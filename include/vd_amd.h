@@ -156,6 +156,10 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
                     int observed_frames, int sampler, int clip_denoised, float eta, unsigned long long seed,
                     unsigned long long offset, long long t_start, void* stream);
 int vd_window_run(vd_engine* e, int n_steps, void* stream);
+/* Bumped by every vd_window_begin.  The step counters are one set per engine: a host object that armed a window keeps the
+ * value it saw and refuses to run when another begin has happened since (executor.py).  vd_window_run itself fails with
+ * "window graphs invalidated" when the armed window's graph was dropped (workspace growth, vd_set_schedule). */
+unsigned long long vd_window_generation(vd_engine* e);
 int vd_window_graphs(vd_engine* e);            /* captured graphs held by the engine */
 
 /* The posterior arithmetic alone, given eps (same formulas; mode 0 p_sample, 1 ddim). */
@@ -163,6 +167,15 @@ int vd_posterior_update(vd_engine* e, int mode, int B, long long per_sample, con
                         const long long* t, int clip_denoised, float eta, const float* noise,
                         unsigned long long seed, unsigned long long offset, float* sample, float* pred_xstart,
                         void* stream);
+
+/* process_xstart with a caller-supplied `denoised_fn` (gaussian_diffusion.py:319-324): the host takes the unclipped
+ * pred_xstart (vd_p_mean_variance, clip_denoised = 0), applies its function, and hands the result back here; the clamp,
+ * q_posterior_mean_variance (:208-227) and the noise add (:438-443; ddim: eps re-derived from x_0, :597-634) run as in
+ * vd_posterior_update.  Any of sample / pred_xstart / mean may be NULL. */
+int vd_posterior_from_xstart(vd_engine* e, int mode, int B, long long per_sample, const float* x, const float* xstart_in,
+                             const long long* t, int clip_denoised, float eta, const float* noise,
+                             unsigned long long seed, unsigned long long offset, float* sample, float* pred_xstart,
+                             float* mean, void* stream);
 
 /* diffusion.q_sample(x_start, t, noise) (gaussian_diffusion.py:190-206). */
 int vd_q_sample(vd_engine* e, int B, long long per_sample, const float* x_start, const long long* t,

@@ -145,6 +145,79 @@ def test_layout_mismatch_between_ranks_is_refused():
     assert [r[1] for r in res] == ["error", "error"] and all("layout" in r[2] for r in res), res
 
 
+class _PassThroughDiffusion:
+    """Stands in for the sampler in the CLI test: the step leaves x unchanged (no GPU here)."""
+    num_timesteps = 2
+
+    def p_sample(self, model, x, t, **kw):
+        return {"sample": x}
+
+
+def _cli_worker(rank, world, port, out, ckpt, workdir):
+    import argparse
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.chdir(workdir)
+    import video_diffusion_amd as vda
+    from video_diffusion_amd import video_sample
+    opened = []
+    real_load = torch.load
+
+    def spy_load(path, *a, **k):
+        opened.append(str(path))
+        return real_load(path, *a, **k)
+
+    torch.load = spy_load
+
+    def create(**kw):                    # the REAL engine handle (packer, layout id) with a pass-through sampler
+        model, _ = vda.create_video_model_and_diffusion(**kw)
+        return model, _PassThroughDiffusion()
+
+    args = argparse.Namespace(checkpoint_path=ckpt, inference_mode="autoreg", T=6, max_frames=4, obs_length=2, step_size=2,
+                              batch_size=1, num_videos=3, timestep_respacing="ddim5", observed_frames="x_0", image_size=32,
+                              num_channels=32, num_res_blocks=1, seed=0, adaptive_distance="l2", executor="eager",
+                              eval_dir=None, out_dir=None, use_ddim=False, sample_idx=0)
+    out_dir = video_sample.run(args, create=create, device=torch.device("cpu"))
+    files = sorted(os.listdir(os.path.join(str(out_dir), "samples")))
+    out.put((rank, opened, str(out_dir), files))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sampling_cli_shards_tasks_and_broadcasts_weights(tmp_path):
+    """video_sample.run (the body of the CLI's main) with two ranks over gloo: rank 0 alone opens the checkpoint; its
+    config reaches rank 1 as an object, its weights as ONE broadcast of the engine's packed image (the real packer);
+    the tasks are dealt r, r+R; the files land under the reference's results/<ckpt subpath>/<stem>_<step>_respace<X>/
+    <mode>_<max_frames>_<step_size>_<T>_<obs_length>/samples naming (test_util.py:65-132)."""
+    vda, model = _tiny_model()
+    cfg = vda.video_model_and_diffusion_defaults()
+    cfg.update(T=4, image_size=32, num_channels=32, num_res_blocks=1, rp_alpha=4, rp_beta=4, rp_gamma=4)
+    sd = {k: torch.from_numpy(vda.weights_init.synth_param(k, s)) for k, s in model.param_specs()}
+    ckdir = tmp_path / "checkpoints" / "runs" / "abc123"
+    ckdir.mkdir(parents=True)
+    ckpt = str(ckdir / "ema_0.9999_latest.pt")
+    torch.save({"state_dict": sd, "config": cfg, "step": 7000}, ckpt)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, q, ckpt, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, opened0, dir0, files0), (r1, opened1, dir1, files1) = res
+    assert opened1 == [] and len(opened0) >= 1 and all(o == ckpt for o in opened0), (opened0, opened1)
+    assert dir0 == dir1 == "results/runs/abc123/ema_0.9999_latest_7000_respaceddim5/autoreg_4_2_6_2"
+    assert files1 == ["sample_0000-0.npy", "sample_0001-0.npy", "sample_0002-0.npy"]      # rank 0: videos 0, 2; rank 1: video 1
+    import json
+    import numpy as np
+    mc = json.load(open(tmp_path / dir0 / "model_config.json"))
+    assert mc["num_channels"] == 32 and mc["timestep_respacing"] == "ddim5"
+    a = np.load(tmp_path / dir0 / "samples" / "sample_0001-0.npy")
+    assert a.dtype == np.uint8 and a.shape == (6, 3, 32, 32)
+
+
 def test_task_to_indices_mapping():
     """video_sample.py:577-582: indices = range(task_id*bs, (task_id+1)*bs)."""
     assert vdist.indices_for_task(3, 8) == list(range(24, 32))

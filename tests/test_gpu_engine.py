@@ -73,6 +73,45 @@ def test_p_sample_and_ddim_match_reference_golden():
     close(q.cpu(), rec["q_sample_t3"], atol=1e-6, rtol=1e-6)
 
 
+def _denoised_fn(x):
+    """tools/gen_golden_r3.py: the function the reference was run with."""
+    return 1.3 * torch.tanh(1.5 * x) + 0.05
+
+
+def test_denoised_fn_matches_reference_golden():
+    """`denoised_fn` (gaussian_diffusion.py:319-324): applied to the UNCLIPPED x_0 prediction, clamp behind it; p_sample,
+    ddim_sample and p_mean_variance against dicts the imported reference produced with the recorded noise."""
+    rec = load_npz("denoised_fn_tiny.npz")
+    cfg = json.loads(str(rec["cfg_json"]))
+    model, diff = engine(cfg)
+    c = {k: torch.from_numpy(rec[k]) for k in ["x", "x0", "noise", "obs_mask", "latent_mask", "kinda_marg_mask", "frame_indices"]}
+    x = c["x"].cuda()
+    B = x.shape[0]
+    calls = []
+
+    def fn(v):
+        calls.append(tuple(v.shape))
+        return _denoised_fn(v)
+
+    for t_val in [249, 120, 0]:
+        t = torch.tensor([t_val] * B, device="cuda")
+        gain = 1.0 + float(diff.sqrt_recipm1_alphas_cumprod[t_val])
+        for clip in (True, False):
+            tag = f"t{t_val}_clip{int(clip)}"
+            sample, xstart = diff._step(0, model, x, t, clip, fn, kwargs_of(c), 0.0, c["noise"])
+            # d fn / d x <= 1.95: the x_0 bound of the plain step times that
+            close(xstart.cpu(), rec[tag + "_pred_xstart"], atol=4e-5 * gain, rtol=1e-4)
+            close(sample.cpu(), rec[tag + "_psample"], atol=2e-4, rtol=2e-4)
+            pm = diff.p_mean_variance(model, x, t, clip_denoised=clip, denoised_fn=fn, model_kwargs=kwargs_of(c))
+            close(pm["mean"].cpu(), rec[tag + "_mean"], atol=2e-4, rtol=2e-4)
+            for eta in (0, 1):
+                s2, _ = diff._step(1, model, x, t, clip, fn, kwargs_of(c), float(eta), c["noise"])
+                close(s2.cpu(), rec[tag + f"_ddim_eta{eta}"], atol=4e-4 * (1 if clip else gain), rtol=4e-4)
+    assert calls and all(s == tuple(x.shape) for s in calls)
+    out = diff.p_sample(model, x, torch.tensor([5] * B, device="cuda"), denoised_fn=fn, model_kwargs=kwargs_of(c))
+    assert set(out) >= {"sample", "pred_xstart"} and torch.isfinite(out["sample"]).all()
+
+
 def test_public_p_sample_contract():
     """Return dict keys, fresh tensors, assertion on t's shape, torch-generator noise reproducibility."""
     cfg = json.loads(str(load_npz("unet_tiny.npz")["cfg_json"]))
@@ -645,6 +684,61 @@ def test_window_executor_equals_eager_steps_bit_for_bit():
     # windows 0 and 1 share a signature; window 4 is bigger than anything before it: the workspace is reallocated and the
     # captured graphs (which hold addresses inside it) are dropped; window 5 re-captures window 0's signature
     assert seen == [1, 1, 2, 3, 1, 2], seen
+    model.check_device_errors()
+
+
+def test_window_executor_survives_a_rebound_schedule_and_refuses_interleaving():
+    """One model, two diffusions (ddim10, then ddim5, then ddim10 again): vd_set_schedule frees the tables a captured
+    graph holds as kernel arguments, so it must drop the graphs; same-size executor buffers land on the same addresses,
+    the window key matches, and a stale replay would read freed tables with the old stride.  Each window
+    must equal its eager replay to the bit.  Also: two executors on one model -- the one that did not begin last is
+    refused; and a window whose graph was dropped by a re-bind in mid-flight reports it instead of replaying."""
+    from video_diffusion_amd import _lib
+    from video_diffusion_amd.executor import WindowExecutor
+    base = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=32, num_res_blocks=1,
+                                                               rp_alpha=4, rp_beta=4, rp_gamma=4)}
+    model, diff10 = engine({**base, "timestep_respacing": "ddim10"})
+    diff5 = vda.create_video_model_and_diffusion(**{**{k: base[k] for k in KEYS if k in base}, "timestep_respacing": "ddim5"})[1]
+    L = _lib.lib()
+    c = _rand_window(2, 4, 32, 2, seed=91)
+    kw = kwargs_of(c)
+    x_init = c["x0"].cuda().clone()
+
+    def eager(diff, seed):
+        diff._bind(model)
+        cur = x_init.clone()
+        per = cur[0].numel()
+        k = model._pack_kwargs(cur, kw)
+        for step, ti in enumerate(range(diff.num_timesteps)[::-1]):
+            t = torch.full((2,), ti, dtype=torch.int64, device="cuda")
+            nxt = torch.empty_like(cur)
+            _lib.check(L.vd_p_sample(model._handle, 2, 4, _lib.ptr(cur), _lib.ptr(k["obs_src"]), _lib.ptr(k["obs_mask"]),
+                                     _lib.ptr(k["latent_mask"]), _lib.ptr(k["kinda_marg_mask"]), _lib.ptr(k["frame_indices"]),
+                                     _lib.ptr(t), k["obs_mode"], 1, None, seed, step * 2 * per, _lib.ptr(nxt), None, None,
+                                     _lib.current_stream()))
+            cur = nxt
+        return cur
+
+    for i, diff in enumerate([diff10, diff5, diff10, diff5]):
+        ex = WindowExecutor(model, diff)                    # a fresh executor per diffusion, as infer_video builds them
+        got = ex.begin(x_init, kw, seed=500 + i).run().clone()
+        del ex
+        want = eager(diff, 500 + i)
+        assert torch.isfinite(got).all() and torch.equal(got, want), i
+    # interleaving: A.begin, B.begin, A.run -> refused; B runs
+    a, b = WindowExecutor(model, diff5), WindowExecutor(model, diff5)
+    a.begin(x_init, kw, seed=1)
+    b.begin(x_init, kw, seed=2)
+    with pytest.raises(RuntimeError, match="another window was begun"):
+        a.run(1)
+    assert torch.equal(b.run().clone(), eager(diff5, 2))
+    # a re-bind in mid-window drops the armed graph: loud, and the window can be begun again
+    b.begin(x_init, kw, seed=3)
+    b.run(2)
+    diff10._bind(model)
+    with pytest.raises(_lib.VdError, match="invalidated"):
+        b.run(1)
+    assert torch.equal(b.begin(x_init, kw, seed=3).run().clone(), eager(diff5, 3))
     model.check_device_errors()
 
 

@@ -14,8 +14,26 @@ SOURCES = ["igemm.hip", "conv_halo.hip", "conv_wino.hip", "conv_wino_s64.hip", "
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vd_amd.h")
 
 
+def _toolchain():
+    """(hipcc, flags) of this process' build and a short tag of them.  Objects are cached per tag (csrc/.obj/<tag>/) and
+    the tag of the linked library is kept beside it, so objects compiled with other flags (timing-only -DVD_*_SKIP builds
+    among them) can never be linked into, or mistaken for, the product library."""
+    import hashlib
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + \
+        os.environ.get("VD_HIPCC_FLAGS", "").split()
+    tag = hashlib.sha1("\0".join([hipcc] + flags).encode()).hexdigest()[:12]
+    return hipcc, flags, tag
+
+
 def _stale():
     if not os.path.exists(SO_PATH):
+        return True
+    try:
+        with open(SO_PATH + ".flags") as f:
+            if f.read().strip() != _toolchain()[2]:
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(SO_PATH)
     deps = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(_CSRC, "vd_common.h"), HEADER]
@@ -40,12 +58,10 @@ def build(force=False, verbose=False):
         try:
             if not force and not _stale():
                 return SO_PATH
-            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-            objdir = os.path.join(_CSRC, ".obj")
+            hipcc, flags, tag = _toolchain()
+            objdir = os.path.join(_CSRC, ".obj", tag)
             os.makedirs(objdir, exist_ok=True)
             hdrs = [os.path.join(_CSRC, "vd_common.h"), HEADER]
-            flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + \
-                os.environ.get("VD_HIPCC_FLAGS", "").split()
 
             def compile_one(src):
                 obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -69,6 +85,8 @@ def build(force=False, verbose=False):
             if r.returncode != 0:
                 raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
             os.replace(tmp, SO_PATH)
+            with open(SO_PATH + ".flags", "w") as f:
+                f.write(tag + "\n")
             return SO_PATH
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
@@ -117,10 +135,12 @@ SIGNATURES = {
     "vd_p_mean_variance": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "vd_vb_terms": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "vd_prior_bpd": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "vd_window_generation": (_U, [_P]),
     "vd_window_begin": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _U, _L, _P]),
     "vd_window_run": (_I, [_P, _I, _P]),
     "vd_window_graphs": (_I, [_P]),
     "vd_posterior_update": (_I, [_P, _I, _I, _L, _P, _P, _P, _I, _F, _P, _U, _U, _P, _P, _P]),
+    "vd_posterior_from_xstart": (_I, [_P, _I, _I, _L, _P, _P, _P, _I, _F, _P, _U, _U, _P, _P, _P, _P]),
     "vd_q_sample": (_I, [_P, _I, _L, _P, _P, _P, _P, _P]),
     "vd_randn": (_I, [_P, _L, _U, _U, _P]),
     "vd_profile_begin": (_I, []),

@@ -214,6 +214,8 @@ struct vd_engine {
     struct WinGraph { WinKey key; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<WinGraph> win_graphs;
     int win_cur = -1;
+    bool win_lost = false;                               // the armed window's graph was dropped (workspace growth / new schedule)
+    unsigned long long win_gen = 0;                      // bumped by every vd_window_begin: a run must name the window it continues
     long long win_left = 0;                              // steps the current window still has (t + 1)
     long long* d_win_t = nullptr; int win_t_cap = 0;     // [B] current respaced index of the window
     unsigned long long* d_win_rng = nullptr;             // {seed, Philox offset}
@@ -229,6 +231,17 @@ struct vd_engine {
         if (d_win_t) (void)hipFree(d_win_t);
         if (d_win_rng) (void)hipFree(d_win_rng);
         for (auto& g : win_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    }
+
+    // Captured window graphs bake addresses (workspace, schedule tables, step counters) and values (num_timesteps, rescale)
+    // into their kernel arguments: whatever replaces one of those drops every graph first.  A graph may still be queued on
+    // the executor's stream, so the device is drained before an exec is destroyed.
+    void drop_window_graphs() {
+        if (win_graphs.empty()) { win_cur = -1; return; }
+        (void)hipDeviceSynchronize();
+        for (auto& g : win_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+        win_graphs.clear();
+        win_cur = -1;
     }
 
     const float* W(int p) const { return wbuf + params[p].off; }
@@ -786,9 +799,10 @@ int vd_engine::ensure_ws(int B, int T) {
     const size_t tm_bytes = ((size_t)B * sizeof(float) + 255) & ~(size_t)255;
     const size_t need = tail + tm_bytes + (size_t)B * T * 3 * cfg.image_size * cfg.image_size * sizeof(float);
     if (need > ws_cap) {
-        // captured window graphs hold addresses inside the old workspace: they die with it
-        for (auto& g : win_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
-        win_graphs.clear(); win_cur = -1;
+        // captured window graphs hold addresses inside the old workspace: they die with it (a window in flight is lost:
+        // vd_window_run then reports "window graphs invalidated")
+        if (win_cur >= 0) win_lost = true;
+        drop_window_graphs();
         if (ws) VD_HIP(hipFree(ws));
         ws = nullptr; ws_cap = 0; ws_B = ws_T = 0;
         VD_HIP(hipMalloc(reinterpret_cast<void**>(&ws), need));
@@ -992,6 +1006,9 @@ int vd_set_freqs(vd_engine* e, const float* tf, int nt, const float* ff, int nf)
 
 int vd_set_schedule(vd_engine* e, int nts, const float* tab, const int* tmap, float rescale) {
     VD_REQUIRE(e && tab && tmap && nts > 0, "schedule tables");
+    // the tables' addresses, num_timesteps and rescale are kernel arguments of every captured window graph
+    if (e->win_cur >= 0) e->win_lost = true;
+    e->drop_window_graphs();
     if (e->d_tab) VD_HIP(hipFree(e->d_tab));
     if (e->d_tmap) VD_HIP(hipFree(e->d_tmap));
     VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_tab), (size_t)NTAB * nts * sizeof(float)));
@@ -1188,12 +1205,11 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     VD_REQUIRE(st != nullptr, "the window executor captures a hipGraph: it needs a non-default stream");
     if ((rc = e->ensure_ws(B, T))) return rc;
     if (B > e->win_t_cap) {
+        e->drop_window_graphs();                                // captured graphs hold the old counter address
         if (e->d_win_t) VD_HIP(hipFree(e->d_win_t));
         e->d_win_t = nullptr; e->win_t_cap = 0;
         VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_win_t), (size_t)B * sizeof(long long)));
         e->win_t_cap = B;
-        for (auto& g : e->win_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
-        e->win_graphs.clear();                                  // captured graphs hold the old counter address
     }
     if (!e->d_win_rng) VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_win_rng), 2 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(win_set_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->d_win_t, e->d_win_rng, B, t_start, seed, offset);
@@ -1203,6 +1219,8 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     key.B = B; key.T = T; key.obs_mode = obs_mode; key.sampler = sampler; key.clip = clip; key.eta = eta;
     key.x = x; key.obs_src = obs_src; key.obs = obs; key.lat = lat; key.km = km; key.fidx = fidx;
     e->win_cur = -1;
+    e->win_lost = false;
+    ++e->win_gen;
     e->win_left = t_start + 1;
     for (size_t i = 0; i < e->win_graphs.size(); ++i)
         if (e->win_graphs[i].key == key) { e->win_cur = (int)i; return 0; }
@@ -1241,8 +1259,12 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     return 0;
 }
 
+unsigned long long vd_window_generation(vd_engine* e) { return e ? e->win_gen : 0; }
+
 int vd_window_run(vd_engine* e, int n_steps, void* stream) {
-    VD_REQUIRE(e && e->win_cur >= 0, "vd_window_begin first");
+    VD_REQUIRE(e, "null engine");
+    VD_REQUIRE(!e->win_lost, "window graphs invalidated (workspace growth or a new schedule since vd_window_begin): begin the window again");
+    VD_REQUIRE(e->win_cur >= 0, "vd_window_begin first");
     VD_REQUIRE(n_steps >= 0 && n_steps <= e->win_left, "more steps than the window has left (t would pass 0)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (int i = 0; i < n_steps; ++i) VD_HIP(hipGraphLaunch(e->win_graphs[e->win_cur].exec, st));
@@ -1274,6 +1296,17 @@ int vd_posterior_update(vd_engine* e, int mode, int B, long long per, const floa
     VD_REQUIRE(x && eps && t && sample && (mode == 0 || mode == 1), "arguments");
     PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
                      mode, eta, seed, offset, sample, xstart, nullptr, nullptr};
+    return launch_posterior(pa, static_cast<hipStream_t>(stream));
+}
+
+int vd_posterior_from_xstart(vd_engine* e, int mode, int B, long long per, const float* x, const float* xstart_in,
+                             const long long* t, int clip, float eta, const float* noise, unsigned long long seed,
+                             unsigned long long offset, float* sample, float* xstart, float* mean, void* stream) {
+    VD_REQUIRE(e && e->d_tab, "vd_set_schedule not called");
+    VD_REQUIRE(x && xstart_in && t && (sample || xstart || mean) && (mode == 0 || mode == 1), "arguments");
+    PosteriorArgs pa{x, nullptr, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
+                     mode, eta, seed, offset, sample, xstart, mean, nullptr};
+    pa.x0_given = xstart_in;
     return launch_posterior(pa, static_cast<hipStream_t>(stream));
 }
 

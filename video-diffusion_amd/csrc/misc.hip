@@ -284,8 +284,8 @@ __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
         }
         const int t = (int)tl;
         const float* tb = a.tab + t;
-        const float x = a.x[i], e = a.eps[i];
-        float x0 = tb[TAB_SQRT_RECIP * NT] * x - tb[TAB_SQRT_RECIPM1 * NT] * e;
+        const float x = a.x[i];
+        float x0 = a.x0_given ? a.x0_given[i] : tb[TAB_SQRT_RECIP * NT] * x - tb[TAB_SQRT_RECIPM1 * NT] * a.eps[i];
         if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
         if (a.xstart) a.xstart[i] = x0;
         if (a.mean) a.mean[i] = tb[TAB_COEF1 * NT] * x0 + tb[TAB_COEF2 * NT] * x;

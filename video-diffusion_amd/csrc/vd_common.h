@@ -215,6 +215,7 @@ struct PosteriorArgs {
     float* sample; float* xstart;   // outputs (either may be null; sample may alias x: the update is elementwise)
     float* mean;                    // p_mean_variance's 'mean' (posterior mean of the clipped x0 prediction), or null
     const unsigned long long* dstate;   // window executor: {seed, offset} read from device memory instead of the arguments
+    const float* x0_given = nullptr;    // denoised_fn path: the caller's x_0 prediction replaces the one derived from eps
 };
 int launch_posterior(const PosteriorArgs& a, hipStream_t s);
 int launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab, int num_timesteps, int B,

@@ -50,6 +50,15 @@ def broadcast_packed(buf, src=0):
     return buf
 
 
+def broadcast_object(obj, src=0):
+    """A small picklable object (the checkpoint's `config` dict) from `src` to every rank; identity in a 1-rank job."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        box = [obj]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+    return obj
+
+
 def share_weights(model, state_dict_fn, rank):
     """Rank 0 materialises the state_dict (disk / generator) and uploads it; everyone else receives the
     engine's packed device buffer over RCCL and marks it loaded."""

@@ -45,10 +45,18 @@ class WindowExecutor:
             raise NotImplementedError(f"observed_frames={mode!r}: the window executor handles 'x_0' and 'x_t'")
         B, T = x_init.shape[:2]
         bufs = self._buffers(B, T)
+        # the engine holds ONE schedule: another diffusion may have been bound to this model since the last window
+        # (vd_set_schedule drops the captured graphs, so a stale replay is impossible)
+        self.diffusion._bind(self.model)
         cur = th.cuda.current_stream(self.model.device)
         self.stream.wait_stream(cur)
         with th.cuda.stream(self.stream):
             kw = self.model._pack_kwargs(x_init, model_kwargs)
+            # the copies below read the caller's tensors on self.stream: keep the caching allocator from handing their
+            # memory out again on the caller's stream before these reads have run
+            for v in [x_init] + [v for v in kw.values() if isinstance(v, th.Tensor)]:
+                if v.is_cuda:
+                    v.record_stream(self.stream)
             bufs["x"].copy_(x_init)
             for k in ("obs_mask", "latent_mask", "kinda_marg_mask", "frame_indices"):
                 bufs[k].copy_(kw[k].view(bufs[k].shape))
@@ -67,12 +75,17 @@ class WindowExecutor:
         self.x = bufs["x"]
         self.seed = seed
         self._left = int(t_start) + 1
+        self._gen = int(_lib.lib().vd_window_generation(self.model._handle))
         return self
 
     def run(self, n_steps=None):
         """Replay the step graph n_steps times (default: down to t = 0).  Returns the window tensor (updated in place)."""
         if n_steps is None:
             n_steps = self._left
+        # the step counters are one set per engine: refuse to continue a window another executor has re-armed since
+        if getattr(self, "_gen", None) != int(_lib.lib().vd_window_generation(self.model._handle)):
+            raise RuntimeError("WindowExecutor.run: another window was begun on this model since this executor's begin(); "
+                               "begin() again")
         _lib.check(_lib.lib().vd_window_run(self.model._handle, int(n_steps), self.stream.cuda_stream))
         self._left -= int(n_steps)
         th.cuda.current_stream(self.model.device).wait_stream(self.stream)

@@ -139,14 +139,14 @@ class GaussianDiffusion:
     # -- per-step entry points ---------------------------------------------------------------------
     def _step(self, mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise,
               return_attn_weights=False, use_gradient_method=False):
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not supported by the fused HIP step")
         if use_gradient_method:
             raise NotImplementedError("use_gradient_method needs a UNet backward pass (out of scope, SURVEY.md 8f-4)")
         if return_attn_weights:
             raise NotImplementedError("return_attn_weights (wandb visualisation) is not supported")
         if model_kwargs is None:
             model_kwargs = {}
+        if denoised_fn is not None:
+            return self._step_denoised_fn(mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise)
         model = self._bind(model)
         B = x.shape[0]
         assert t.shape == (B,)                                   # gaussian_diffusion.py:273
@@ -178,6 +178,25 @@ class GaussianDiffusion:
         _lib.check(rc)
         return sample, xstart
 
+    def _step_denoised_fn(self, mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise):
+        """process_xstart with a caller's function (gaussian_diffusion.py:319-324): `denoised_fn` sees the UNCLIPPED x_0
+        prediction, the clamp and the posterior run on what it returns.  Two launches around a host callback instead of
+        the fused step: forward + x_0 (vd_p_mean_variance, clip off), then vd_posterior_from_xstart."""
+        out = self.p_mean_variance(model, x, t, clip_denoised=False, model_kwargs=model_kwargs)
+        base = self._bind(model)
+        dev = base.device
+        xs = _f32(x, dev)
+        B = xs.shape[0]
+        x0 = _f32(denoised_fn(out["pred_xstart"]), dev)
+        assert x0.shape == xs.shape
+        noise = th.randn_like(xs) if noise is None else _f32(noise, dev)
+        tt = t.to(device=dev, dtype=th.int64).contiguous()
+        sample, xstart = th.empty_like(xs), th.empty_like(xs)
+        _lib.check(_lib.lib().vd_posterior_from_xstart(
+            base._handle, mode, B, xs[0].numel(), _lib.ptr(xs), _lib.ptr(x0), _lib.ptr(tt), 1 if clip_denoised else 0,
+            float(eta), _lib.ptr(noise), 0, 0, _lib.ptr(sample), _lib.ptr(xstart), None, _lib.current_stream()))
+        return sample, xstart
+
     def _extract(self, arr, t, shape):
         """_extract_into_tensor (gaussian_diffusion.py:1019-1031): float64 table gathered at t, cast to float32,
         broadcast to `shape` (tensor plumbing: a gather and a view)."""
@@ -190,12 +209,22 @@ class GaussianDiffusion:
                         return_attn_weights=False, use_gradient_method=False):
         """gaussian_diffusion.py:229-372 -> {'mean', 'variance', 'log_variance', 'pred_xstart', 'attn'} (+ 'eps', the raw
         model output, which the NLL loop reuses)."""
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not supported by the fused HIP step")
         if use_gradient_method:
             raise NotImplementedError("use_gradient_method needs a UNet backward pass (out of scope, SURVEY.md 8f-4)")
         if return_attn_weights:
             raise NotImplementedError("return_attn_weights (wandb visualisation) is not supported")
+        if denoised_fn is not None:
+            out = self.p_mean_variance(model, x, t, clip_denoised=False, model_kwargs=model_kwargs)
+            base = self._bind(model)
+            xs = _f32(x, base.device)
+            x0 = _f32(denoised_fn(out["pred_xstart"]), base.device)
+            tt = t.to(device=base.device, dtype=th.int64).contiguous()
+            mean, xstart = th.empty_like(xs), th.empty_like(xs)
+            _lib.check(_lib.lib().vd_posterior_from_xstart(
+                base._handle, 0, xs.shape[0], xs[0].numel(), _lib.ptr(xs), _lib.ptr(x0), _lib.ptr(tt),
+                1 if clip_denoised else 0, 0.0, None, 0, 0, None, _lib.ptr(xstart), _lib.ptr(mean), _lib.current_stream()))
+            out.update(mean=mean, pred_xstart=xstart)
+            return out
         model = self._bind(model)
         B = x.shape[0]
         assert t.shape == (B,)

@@ -135,28 +135,44 @@ def save_samples(recon, out_dir, first_index=0, sample_idx=0):
     return written
 
 
-def load_model(args, device):
-    """video_sample.py:547-567: checkpoint dict {'state_dict','config','step'} -> (model, diffusion)."""
+def load_model(args, device, rank=0, world=1, create=None):
+    """video_sample.py:547-567: checkpoint dict {'state_dict','config','step'} -> (model, diffusion).
+
+    One process per GPU: ONLY rank 0 opens the checkpoint.  Its `config` (a small dict) goes to the other ranks with
+    `broadcast_object_list`, every rank builds the same engine from it, rank 0 packs the state_dict into the engine's
+    kernel-ready image and that ONE buffer travels by a single broadcast (RCCL over xGMI; `dist.share_weights`) -- in
+    place of the reference's N checkpoint reads or its per-tensor `sync_params` (dist_util.py:139-143)."""
+    from . import dist as vdist
+    create = create or create_video_model_and_diffusion
     defaults = video_model_and_diffusion_defaults()
-    if args.checkpoint_path:
-        data = torch.load(args.checkpoint_path, map_location="cpu")
-        cfg = dict(data["config"])
-        cfg.setdefault("enforce_position_invariance", False)      # back-compat fills, video_sample.py:25-28,557-559
-        cfg.setdefault("cond_emb_type", "channel")
-        state_dict = data["state_dict"]
+    holder = {}
+    if rank == 0:
+        if args.checkpoint_path:
+            data = torch.load(args.checkpoint_path, map_location="cpu")
+            cfg = dict(data["config"])
+            cfg.setdefault("enforce_position_invariance", False)      # back-compat fills, video_sample.py:25-28,557-559
+            cfg.setdefault("cond_emb_type", "channel")
+            holder["sd"] = data["state_dict"]
+        else:
+            cfg = dict(defaults, T=args.max_frames, image_size=args.image_size, num_channels=args.num_channels,
+                       num_res_blocks=args.num_res_blocks, rp_alpha=args.max_frames, rp_beta=args.max_frames,
+                       rp_gamma=args.max_frames)
+        cfg["timestep_respacing"] = args.timestep_respacing
     else:
-        cfg = dict(defaults, T=args.max_frames, image_size=args.image_size, num_channels=args.num_channels,
-                   num_res_blocks=args.num_res_blocks, rp_alpha=args.max_frames, rp_beta=args.max_frames,
-                   rp_gamma=args.max_frames)
-        state_dict = None
-    cfg["timestep_respacing"] = args.timestep_respacing
+        cfg = None
+    cfg = vdist.broadcast_object(cfg, src=0)
     ns = argparse.Namespace(**cfg)
-    model, diffusion = create_video_model_and_diffusion(**args_to_dict(ns, defaults.keys()))
-    if state_dict is None:
-        state_dict = {k: torch.from_numpy(synth_param(k, s)) for k, s in model.param_specs()}
-    model.load_state_dict(state_dict)
+    model, diffusion = create(**args_to_dict(ns, defaults.keys()))
+    model.config = {k: v for k, v in cfg.items() if isinstance(v, (int, float, str, bool, type(None), list, tuple, dict))}
     model.to(device)
     model.eval()
+
+    def state_dict_fn():                                              # called on rank 0 only
+        if "sd" not in holder:
+            holder["sd"] = {k: torch.from_numpy(synth_param(k, s)) for k, s in model.param_specs()}
+        return holder["sd"]
+
+    vdist.share_weights(model, state_dict_fn, rank)
     return model, diffusion
 
 
@@ -181,15 +197,45 @@ def main(argv=None):
                     help="adaptive-* modes: frame embedding for the farthest-point selection (lpips needs set_lpips_embedder)")
     ap.add_argument("--executor", default="graph", choices=["graph", "eager"],
                     help="graph: one captured hipGraph per window shape (executor.py); eager: one p_sample call per step")
-    ap.add_argument("--out_dir", default="results/synthetic")
+    ap.add_argument("--eval_dir", default=None,
+                    help="results directory; default: derived from the checkpoint path and the sampling options "
+                         "(test_util.get_model_results_path), 'results/synthetic' without a checkpoint")
+    ap.add_argument("--out_dir", default=None, help="alias of --eval_dir (earlier rounds' flag)")
+    ap.add_argument("--use_ddim", type=str2bool, nargs="?", const=True, default=False)
+    ap.add_argument("--sample_idx", type=int, default=0)
     args = ap.parse_args(argv)
+    return run(args)
+
+
+def run(args, create=None, device=None):
+    """The body of `main` (video_sample.py:520-640 of the reference): join the job, load + share the weights, walk this
+    rank's tasks, write `samples/sample_%04d-%d.npy` under the reference's results/<...>/<run id>/ naming.
+    `create` / `device` let the CPU tests drive the sharding + broadcast path with a stand-in engine."""
+    import json
+    from . import test_util
     logging.basicConfig(level=logging.INFO)
     from . import dist as vdist
     rank, local_rank, world = vdist.init()
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    if device is None:
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
     torch.manual_seed(args.seed + rank)
-    model, diffusion = load_model(args, device)
+    model, diffusion = load_model(args, device, rank, world, create=create)
+    # results/<checkpoint subpath>/<stem>[_<step>][_ddim][_respace<X>]/<mode>_<max_frames>_<step_size>_<T>_<obs_length>/
+    # (test_util.py:65-132 of the reference, video_sample.py:600-611): what video_eval.py reads
+    # -- derived on rank 0 (a '*latest' checkpoint is opened once more there for its step) and sent to the others
+    out_dir = None
+    if rank == 0:
+        if args.eval_dir is None:
+            args.eval_dir = args.out_dir if args.out_dir is not None else (None if args.checkpoint_path else "results/synthetic")
+        out_dir = test_util.get_model_results_path(args) / test_util.get_eval_run_identifier(args)
+        os.makedirs(out_dir / "samples", exist_ok=True)
+        json_path = out_dir / "model_config.json"                         # video_sample.py:620-626
+        if not json_path.exists():
+            with test_util.Protect(json_path):
+                with open(json_path, "w") as f:
+                    json.dump(model.config, f, indent=4)
+    out_dir = vdist.broadcast_object(out_dir, src=0)
     n_tasks = (args.num_videos + args.batch_size - 1) // args.batch_size
     for task in vdist.task_ids(n_tasks, rank, world):                       # video_sample.py:577-582
         idx = vdist.indices_for_task(task, args.batch_size, args.num_videos)
@@ -198,9 +244,10 @@ def main(argv=None):
         recon, _ = infer_video(args.inference_mode, model, diffusion, batch, args.max_frames, args.obs_length,
                                args.step_size, observed_frames=args.observed_frames, executor=args.executor,
                                adaptive_distance=args.adaptive_distance)
-        for p in save_samples(recon, args.out_dir, first_index=idx[0]):
+        for p in save_samples(recon, str(out_dir), first_index=idx[0], sample_idx=args.sample_idx):
             logger.info(f"*** Saved {p} ***")
     vdist.barrier()
+    return out_dir
 
 
 if __name__ == "__main__":

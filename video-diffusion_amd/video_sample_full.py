@@ -143,17 +143,21 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     torch.manual_seed(args.seed + rank)
-    model, diffusion = load_model(args, device)
-    # results/<...>/<run identifier>/ (test_util.py:65-132, video_sample_full.py:712-724); synthetic runs have no checkpoint
-    if args.eval_dir is None and not args.checkpoint_path:
-        args.eval_dir = "results/synthetic"
-    out_dir = test_util.get_model_results_path(args) / test_util.get_eval_run_identifier(args)
-    os.makedirs(out_dir, exist_ok=True)
+    model, diffusion = load_model(args, device, rank, world)      # rank 0 reads the checkpoint; one broadcast of the packed image
+    # results/<...>/<run identifier>/ (test_util.py:65-132, video_sample_full.py:712-724); synthetic runs have no
+    # checkpoint.  Derived on rank 0 only (a '*latest' checkpoint is opened there for its step) and sent to the others.
+    out_dir = None
     if rank == 0:
-        with test_util.Protect(out_dir / "model_config.json"):
-            if not (out_dir / "model_config.json").exists():
-                json.dump({k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool, type(None)))},
-                          open(out_dir / "model_config.json", "w"), indent=1)
+        if args.eval_dir is None and not args.checkpoint_path:
+            args.eval_dir = "results/synthetic"
+        out_dir = test_util.get_model_results_path(args) / test_util.get_eval_run_identifier(args)
+        os.makedirs(out_dir / "samples", exist_ok=True)
+        json_path = out_dir / "model_config.json"
+        if not json_path.exists():
+            with test_util.Protect(json_path):
+                with open(json_path, "w") as f:
+                    json.dump(model.config, f, indent=4)
+    out_dir = vdist.broadcast_object(out_dir, src=0)
     n_tasks = (args.num_videos + args.batch_size - 1) // args.batch_size
     for task in vdist.task_ids(n_tasks, rank, world):
         idx = vdist.indices_for_task(task, args.batch_size, args.num_videos)
