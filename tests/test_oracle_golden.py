@@ -231,3 +231,30 @@ def test_nll_terms_match_reference():
     m2 = s.calc_bpd_loop_subsampled(x0, kw, clip=True, latent_mask=lm, t_seq=rec["bpd2_t_seq"])
     for k in ("total_bpd", "vb", "mse"):
         close(m2[k], rec[f"bpd2_{k}"], atol=1e-5, rtol=5e-4)
+
+
+def test_full_size_oracle_matches_reference_golden():
+    """The oracle at FULL size (default 64x64 model, 116 M parameters, one 16-frame clip) against eps of the imported
+    reference (tools/gen_golden_r3.py full).  The same script timed both on this container's 8 cores -- reference 1.86 s,
+    oracle 1.89 s per step, max |d eps| 1.9e-6 (tests/golden/full_size_reference_vs_oracle.json) -- which is what backs
+    bench.py's `cpu_baseline.kind: "port"`: the restatement is the same workload as the reference."""
+    rec = load_npz("unet_full64.npz")
+    cfg = json.loads(str(rec["cfg_json"]))
+    import video_diffusion_amd as vda
+    model, _ = vda.create_video_model_and_diffusion(**{k: cfg[k] for k in vda.video_model_and_diffusion_defaults()})
+    net = UNetRef(cfg, synth_sd(model.param_specs()))
+    sched = ScheduleRef(cfg["diffusion_steps"], cfg["noise_schedule"], cfg["timestep_respacing"], cfg["sigma_small"],
+                        cfg["rescale_timesteps"])
+    T, n_obs = int(rec["T"][0]), int(rec["n_obs"][0])
+    g = torch.Generator().manual_seed(int(rec["seed"][0]))
+    x0 = torch.rand(1, T, 3, 64, 64, generator=g) * 2 - 1
+    x0[:, n_obs:] = 0
+    x = torch.randn(1, T, 3, 64, 64, generator=g)
+    obs = torch.zeros(1, T, 1, 1, 1)
+    obs[:, :n_obs] = 1
+    kw = dict(x0=x0, obs_mask=obs, latent_mask=1 - obs, kinda_marg_mask=torch.zeros(1, T, 1, 1, 1),
+              frame_indices=torch.arange(T).view(1, T))
+    got = SamplerRef(sched, net).eps(x, torch.tensor([int(rec["t"][0])]), kw)
+    close(got, rec["eps"], atol=2e-5, rtol=1e-4)
+    tm = load_json("full_size_reference_vs_oracle.json")["unet_full64.npz"]
+    assert tm["max_abs_eps_diff"] < 2e-5 and 0.5 < tm["oracle_s_per_step"] / tm["reference_s_per_step"] < 2.0

@@ -212,9 +212,9 @@ def gen_full():
             ora = UNetRef(cfg, sd)
             tm = torch.tensor([float(diff.timestep_map[200]) * (1000.0 / diff.original_num_steps)]) if diff.rescale_timesteps \
                 else torch.tensor([float(diff.timestep_map[200])])
-            ora.forward(x, tm, kw)
+            ora(x, tm, **kw)
             t0 = time.time()
-            eps_o = ora.forward(x, tm, kw)
+            eps_o = ora(x, tm, **kw)
             t_ora = time.time() - t0
         d = float((eps - eps_o).abs().max())
         timing[name] = dict(params=n_par, reference_s_per_step=t_ref, oracle_s_per_step=t_ora, max_abs_eps_diff=d, threads=8,

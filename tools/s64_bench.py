@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--only", type=int, default=0, help="only layers with this output resolution")
+    ap.add_argument("--quick", action="store_true", help="five representative layers only (kernel ablations)")
     ap.add_argument("--kernel", default="split", choices=["split", "s64", "r64"], help="split: the engine's choice per layer")
     args = ap.parse_args()
     L = _lib.lib()
@@ -29,6 +30,8 @@ def main():
     tot_ms = tot_fl = 0.0
     for Cin, Cout, H, ups, cnt in CENSUS:
         if args.only and H != args.only:
+            continue
+        if args.quick and (Cin, Cout, H) not in [(128, 128, 64), (256, 256, 32), (640, 256, 32), (384, 384, 16), (512, 512, 8)]:
             continue
         nfr, Hs = args.frames, H >> ups
         x0 = torch.rand(nfr, Hs, Hs, Cin, device="cuda") - 0.5

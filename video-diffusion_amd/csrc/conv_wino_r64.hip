@@ -27,7 +27,7 @@ namespace vd {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-struct WinoR64Geom { int tiles_x, tiles_y, nbx, ncb, nitems, xcd_order; };
+struct WinoR64Geom { int tiles_x, tiles_y, nbx, ncb, nitems, xcd_order, ksplit; };   // ksplit > 1: blockIdx.y = the block's slice of the channel chunks
 
 // Geometry of an item's patch image.  TF4 = false: one frame, 8 x 8 tiles (maps >= 16 x 16).  TF4 = true: FOUR frames of an
 // 8 x 8 map, 4 x 4 tiles each, a 10 x 10 patch per frame at a frame stride of FSB bytes (every stride a multiple of 256 bytes,
@@ -68,6 +68,9 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #ifndef VD_R64_DMA_LATE
 #define VD_R64_DMA_LATE 1  // patches requested behind the chunk pair's last weight loads (0: at the barrier; conv class 18.02 -> 17.78 ms)
 #endif
+#ifndef VD_R64_ZERO_EARLY
+#define VD_R64_ZERO_EARLY 1 // accumulators zeroed between the prologue's requests and its wait (0: wherever the compiler puts them)
+#endif
 #ifndef VD_R64_SKIP
 #define VD_R64_SKIP 0      // timing-only builds (results wrong): 1 no split, 2 no transform at all, 4 no weight loads, 16 no patch DMA,
 #endif                     // 64 no MFMA, 128 no patch reads
@@ -83,7 +86,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);         // Winograd row of this wave
     const int lr = lane & 31, lh = lane >> 5;
     const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
-    const int nchunk = a.Cin >> 4, ncoblk = a.Cout >> 5;
+    const int ncoblk = a.Cout >> 5;
+    // split-K (small grids: a B = 1 shard leaves 32 .. 96 items for 256 CUs): block (item, ks) walks channel chunks
+    // [ks * nchunk, (ks + 1) * nchunk) and writes its partial output -- no bias, residual or statistics -- to slab ks of a.out,
+    // which is then the scratch [ksplit][pixels][Cout]; wino_r64_reduce_kernel sums the slabs
+    const int nchunk = (a.Cin >> 4) / g.ksplit;
+    const int ks = g.ksplit > 1 ? (int)blockIdx.y : 0;
+    const int c_begin = ks * nchunk;
 
     // ---- item: blocks are dealt to the 8 XCDs round-robin; inside an XCD the cout blocks of one patch are neighbours
     int bx, cob0;
@@ -110,7 +119,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
         const int py = ps / (2 * SPP), r = ps % (2 * SPP), pxh = r % SPP, px = 2 * pxh + r / SPP;
         const int ly = oy0 + py - 1, lx = ox0 + px - 1;
         const bool in = fl < (TF4 ? 4 : 1) && f0 + fl < a.nfr && py < P && pxh < P / 2 && ly >= 0 && ly < Hl && lx >= 0 && lx < Wl;
-        xo[e] = in ? (unsigned)(((f0 + fl) * a.Hs + (ly >> a.ups)) * a.Ws + (lx >> a.ups)) * (unsigned)(a.Cin * 4) + (unsigned)((lq ^ ((py >> 1) & 3)) * 16)
+        xo[e] = in ? (unsigned)(((f0 + fl) * a.Hs + (ly >> a.ups)) * a.Ws + (lx >> a.ups)) * (unsigned)(a.Cin * 4) + (unsigned)((lq ^ ((py >> 1) & 3)) * 16) +
+                         (unsigned)(c_begin * 64)
                    : 0x80000000u;
     }
     const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     // ---- B fragments: U[chunk][xi = 4*wi + j][cob][piece][lane][8 bf16] = 1 KiB per (chunk, xi, cob, piece)
     const auto usrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wwino), 0, 16 * a.Cout * a.Cin * 6, 0x00020000);
     const int ustride = 16 * ncoblk * 3072, bstep = ncoblk * 3072;
-    const int bsb = (wi * 4 * ncoblk + cob0) * 3072;
+    const int bsb = (wi * 4 * ncoblk + cob0) * 3072 + c_begin * ustride;
     const unsigned blane = lane * 16u;
     bf16x8 bfr[4][2][3];
     auto b_load = [&](int chunk, int j, int n) {
@@ -192,15 +202,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
             bfr[j][n][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, so + p * 1024, 0));
     };
 
-    f32x16 acc[2][4][2];                                              // [m][j][n]
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][j][n][r] = 0.f;
+    f32x16 acc[2][4][2];                                              // [m][j][n]; zeroed behind the prologue's requests
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -219,6 +221,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     for (int c = 0; c < (VD_R64_BAR2 ? 3 : NB); ++c) x_dma(c);
 #pragma unroll
     for (int j = 0; j < 3; ++j) { b_load(0, j, 0); b_load(0, j, 1); }
+#if VD_R64_ZERO_EARLY
+    // the 256 accumulator writes (1 k cycles of issue) go under the wait for the first patch instead of behind it
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[m][j][n][r]));
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][j][n][r] = 0.f;
+#endif
     asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");  // every patch requested so far has landed; the weights may be in flight
 #pragma unroll
     for (int c = 0; c < 4; ++c) { t_read(0, 0, c); t_fma(c, 0); t_fma(c, 1); }
@@ -308,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     // Z image: [plane 2*i + q 8][m 2][c4 4][lane 64][4 floats] = 64 KB over the patch buffers.
     const int p = wi >> 1, q = wi & 1;
     const int obytes = a.nfr * Hl * Wl * a.ldo * 4;
-    const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
+    const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)ks * (obytes >> 2), 0, obytes, 0x00020000);
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
     const float sgn = p ? -1.f : 1.f;
     float* Zs = smem;
@@ -410,6 +434,57 @@ bool conv_wino_r64_supported(const IgemmArgs& a) {
            (size_t)a.nfr * Hl * Wl * a.ldo < (1u << 29) && (a.res == nullptr || a.res_ld == a.ldo);
 }
 
+// ---- split-K for small grids ------------------------------------------------------------------------------------
+// out[m][c] = sum_s part[s][m][c] + bias[c] + fbias[frame][c] + res[m][c], and the GroupNorm partial sums of the result in
+// the layout the one-launch epilogue writes ([frame][split = 1][Cout][2] doubles: maps <= 16 x 16 only).  Block = one frame
+// x 64 channels; thread (c, pixel phase): coalesced 256-byte rows.
+__global__ __launch_bounds__(256) void wino_r64_reduce_kernel(const float* part, int S, size_t slab, const float* bias, const float* fbias,
+                                                                  int fbias_ld, const float* res, int res_ld, float* out, int ldo, int HW,
+                                                                  int Cout, double* stats) {
+    const int f = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    const float b = (bias ? bias[c] : 0.f) + (fbias ? fbias[(size_t)f * fbias_ld + c] : 0.f);
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = ph; p < HW; p += 4) {
+        const size_t m = (size_t)f * HW + p;
+        float v = 0.f;
+        for (int k = 0; k < S; ++k) v += part[k * slab + m * Cout + c];
+        v += b;
+        if (res) v += res[m * res_ld + c];
+        out[m * ldo + c] = v;
+        s1 += (double)v; s2 += (double)v * (double)v;
+    }
+    if (stats) {
+        __shared__ double red[4][64][2];
+        red[ph][threadIdx.x & 63][0] = s1; red[ph][threadIdx.x & 63][1] = s2;
+        __syncthreads();
+        if (ph == 0) {
+            const int l = threadIdx.x;
+            double* o = stats + ((size_t)f * Cout + c) * 2;
+            o[0] = red[0][l][0] + red[1][l][0] + red[2][l][0] + red[3][l][0];
+            o[1] = red[0][l][1] + red[1][l][1] + red[2][l][1] + red[3][l][1];
+        }
+    }
+}
+
+// Slices of the channel loop by shape alone: 1 when the grid fills the chip anyway (every launch of the headline window)
+// or the map is larger than 16 x 16; else the largest count that keeps >= 4 chunks (an even number) per block and the
+// grid within 288 blocks.  The engine sizes the scratch from this (conv_wino_r64_ksplit_floats) in its dry run too.
+int conv_wino_r64_ksplit(int nfr, int Hl, int Cin, int Cout) {
+    static const bool off = getenv("VD_R64_NO_KSPLIT") != nullptr;             // A/B switch
+    if (off || Hl > 16 || Hl < 8 || Cout % 64 || Cin % 32) return 1;
+    const int items = (Hl == 8 ? (nfr + 3) / 4 : (Hl / 16) * (Hl / 16) * nfr) * (Cout / 64), nchunk = Cin / 16;
+    if (items >= 160) return 1;
+    int best = 1;
+    for (int s2 = 2; s2 <= 16; ++s2)
+        if (nchunk % s2 == 0 && (nchunk / s2) % 2 == 0 && nchunk / s2 >= 4 && items * s2 <= 288) best = s2;
+    return best;
+}
+
+size_t conv_wino_r64_ksplit_floats(int nfr, int Hl, int Cin, int Cout) {
+    const int S = conv_wino_r64_ksplit(nfr, Hl, Cin, Cout);
+    return S > 1 ? (size_t)S * nfr * Hl * Hl * Cout : 0;
+}
+
 int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
     const int Hl = a.Hs << a.ups;
     VD_REQUIRE(a.stats == nullptr || a.stats_split == conv_wino_stats_split(Hl), "GroupNorm partial table: split");
@@ -420,15 +495,29 @@ int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
     g.ncb = a.Cout / 64;
     g.nitems = g.nbx * g.ncb;
     g.xcd_order = g.nbx % 8 == 0;
+    // split-K only with scratch from the caller (the engine's arena; the single-operator entry points run one slice)
+    g.ksplit = a.ksplit_ws && a.ksplit_ws_floats >= conv_wino_r64_ksplit_floats(a.nfr, Hl, a.Cin, a.Cout)
+                   ? conv_wino_r64_ksplit(a.nfr, Hl, a.Cin, a.Cout) : 1;
     static bool attr = false;
     if (!attr) {
         VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    if (tf4) hipLaunchKernelGGL(conv3x3_wino_r64_kernel<true>, dim3(g.nitems), dim3(256), r64::lds_bytes<true>(), s, a, g);
-    else hipLaunchKernelGGL(conv3x3_wino_r64_kernel<false>, dim3(g.nitems), dim3(256), r64::lds_bytes<false>(), s, a, g);
+    IgemmArgs k = a;
+    if (g.ksplit > 1) {
+        k.out = a.ksplit_ws; k.ldo = a.Cout; k.bias = nullptr; k.fbias = nullptr; k.res = nullptr; k.stats = nullptr;
+    }
+    const dim3 grid(g.nitems, g.ksplit);
+    if (tf4) hipLaunchKernelGGL(conv3x3_wino_r64_kernel<true>, grid, dim3(256), r64::lds_bytes<true>(), s, k, g);
+    else hipLaunchKernelGGL(conv3x3_wino_r64_kernel<false>, grid, dim3(256), r64::lds_bytes<false>(), s, k, g);
     VD_HIP(hipGetLastError());
+    if (g.ksplit > 1) {
+        const int HW = Hl * Hl;
+        hipLaunchKernelGGL(wino_r64_reduce_kernel, dim3(a.nfr, a.Cout / 64), dim3(256), 0, s, a.ksplit_ws, g.ksplit,
+                           (size_t)a.nfr * HW * a.Cout, a.bias, a.fbias, a.fbias_ld, a.res, a.res_ld, a.out, a.ldo, HW, a.Cout, a.stats);
+        VD_HIP(hipGetLastError());
+    }
     return 0;
 }
 

@@ -565,12 +565,15 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     {   // SiLU(GroupNorm(concat(x0, x1))) once, into a transient; the conv then reads plain activations (norm.hip)
         const size_t mk = ar.mark();
         float* a1 = ar.get<float>((size_t)N * HW * cin);
+        const size_t ksf = conv_wino_r64_ksplit_floats(N, H, cin, r.cout);      // small grids: split-K scratch (conv_wino_r64.hip)
+        float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
         if (!ar.dry) {
             if ((rc = affine_act(x0.p, s1, x0.C, cin, A1, B1, N, HW, a1, st))) return rc;
             Tens at{a1, cin, H};
             IgemmArgs g = conv_args(at, nullptr, N, 3, 1, 0);
             set_w(g, r.c1w); g.bias = W(r.c1b);
             g.out = h; g.ldo = r.cout; g.Cout = r.cout; g.stats = ht.part; g.stats_split = ht.split;
+            g.ksplit_ws = ksw; g.ksplit_ws_floats = ksf;
             if (!cfg.use_scale_shift_norm) { g.fbias = film; g.fbias_ld = film_total; }    // h + emb_out (unet.py:196)
             if ((rc = igemm_p(g, st))) return rc;
         }
@@ -594,6 +597,8 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     {
         const size_t mk = ar.mark();
         float* a2 = ar.get<float>((size_t)N * HW * r.cout);
+        const size_t ksf = conv_wino_r64_ksplit_floats(N, H, r.cout, r.cout);
+        float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
         if (!ar.dry) {
             if ((rc = affine_act(h, nullptr, r.cout, r.cout, A2, B2, N, HW, a2, st))) return rc;
             Tens at{a2, r.cout, H};
@@ -601,6 +606,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
             set_w(g, r.c2w); g.bias = W(r.c2b);
             g.res = skip; g.res_ld = r.cout; g.out = o; g.ldo = r.cout; g.Cout = r.cout;
             g.stats = ot.part; g.stats_split = ot.split;
+            g.ksplit_ws = ksw; g.ksplit_ws_floats = ksf;
             if ((rc = igemm_p(g, st))) return rc;
         }
         ar.release(mk);
@@ -740,7 +746,12 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
                 nxt = Tens{o, c.c, g.Ho};
                 if (params[c.w].kind == PK_CONV3W) nxt.part = stats_table(ar, N, g.Ho, c.c, &nxt.split);
                 else if (stride == 2) conv_split_stats_table(ar, g, c.c, &nxt);       // Downsample on the split GEMM
+                const size_t mk = ar.mark();
+                const size_t ksf = stride == 1 ? conv_wino_r64_ksplit_floats(N, g.Ho, cur.C, c.c) : 0;
+                float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
+                ar.release(mk);                                                       // a transient: the launches are stream-ordered
                 if (!ar.dry) {
+                    g.ksplit_ws = ksw; g.ksplit_ws_floats = ksf;
                     set_w(g, c.w); g.bias = W(c.b); g.out = o; g.ldo = c.c; g.Cout = c.c;
                     g.stats = nxt.part; g.stats_split = nxt.split;
                     if (nxt.part && params[c.w].kind != PK_CONV3W) g.stats_hw = g.Ho * g.Wo;

@@ -23,6 +23,9 @@ namespace vd {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef VD_GS_PF3
+#define VD_GS_PF3 1        // 0: the A operand one chunk ahead for every tile (A/B)
+#endif
 #ifndef VD_GS_SKIP
 #define VD_GS_SKIP 0       // kernel-experiment builds: bit 0 no weight loads, 1 no A staging, 2 no split VALU (timing only)
 #endif
@@ -43,6 +46,10 @@ template <int BM, int BN, bool ACT, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
     constexpr int RING = NI >= 3 ? 2 : 3;                                  // weight ring slots (k-steps ahead = RING - 1): 256 registers per wave
+    // A-operand prefetch distance in chunks.  A chunk of a 64-row tile is 12 .. 24 MFMAs (0.2 .. 0.4 us): one chunk ahead, the
+    // split + store of the next chunk waits a full memory round trip every chunk, and a small-M launch (a B = 1 shard: 60 of
+    // them per step) costs ~1 us per chunk whatever its size.  The small tiles have the registers for three chunks in flight.
+    constexpr int PF = (BM == 64 && VD_GS_PF3) ? 3 : 1;
     constexpr int PLANE = BM * SROW, ABUF = 3 * PLANE;                    // bytes
     extern __shared__ __attribute__((aligned(16))) char smem_c[];         // [2][3 planes][BM][SROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,9 +93,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) bo[j] = (unsigned)min((int)blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1) * 3072u + lane * 16u;
 
-    f32x4 ra[AR];
+    f32x4 ra[PF][AR];
     bf16x8 bfr[RING][NI][3], afr[2][MI][3];      // [ring slot][tile][piece]
-    auto a_prefetch = [&](int chunk) {
+    auto a_prefetch = [&](int chunk, int rs) {
         if constexpr (CONV) {
             const int tap = chunk / cpt, c = (chunk - tap * cpt) * 32;
             const int kh = tap / 3, kw = tap - 3 * kh;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
                 const bool ok = (unsigned)(iy0[j] + kh) < (unsigned)a.Hs && (unsigned)(ix0[j] + kw) < (unsigned)a.Ws;
-                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc0, ok ? ao0[j] + shift : 0x80000000u, c * 4, 0));
+                ra[rs][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc0, ok ? ao0[j] + shift : 0x80000000u, c * 4, 0));
             }
             return;
         }
@@ -104,17 +111,17 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         if (c < a.C0) {
 #pragma unroll
             for (int j = 0; j < AR; ++j)
-                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc0, ao0[j], c * 4, 0));
+                ra[rs][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc0, ao0[j], c * 4, 0));
         } else {
 #pragma unroll
             for (int j = 0; j < AR; ++j)
-                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc1, ao1[j], (c - a.C0) * 4, 0));
+                ra[rs][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc1, ao1[j], (c - a.C0) * 4, 0));
         }
     };
-    auto a_store = [&](char* Ad) {               // split once per element, three planes
+    auto a_store = [&](char* Ad, int rs) {       // split once per element, three planes
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
-            f32x4 v = ra[j];
+            f32x4 v = ra[rs][j];
             if constexpr (ACT) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
             bf16x4 p1, p2, p3;
             split3(v, p1, p2, p3);
@@ -174,10 +181,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     }
 
     const int nks = 2 * nchunk;
-    a_prefetch(0);
+    a_prefetch(0, 0);
+    if constexpr (PF == 3) { a_prefetch(min(1, nchunk - 1), 1); a_prefetch(min(2, nchunk - 1), 2); }
     b_load(0, 0);
     if constexpr (RING == 3) b_load(1, min(1, nks - 1));
-    a_store(smem_c);
+    a_store(smem_c, 0);
     __syncthreads();
     a_frags(0, smem_c, 0);
 
@@ -209,11 +217,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         for (int cc = 0; cc < 3; ++cc) {
             const int chunk = chunk0 + cc;
             if (chunk < nchunk) {
-                const int nxt = min(chunk + 1, nchunk - 1);
-                if (!(VD_GS_SKIP & 2)) a_prefetch(nxt);
+                // PF == 3: chunk0 is a multiple of 3, so register slot chunk % 3 == cc; it held this chunk (already in LDS)
+                const int nxt = min(chunk + PF, nchunk - 1);
+                if (!(VD_GS_SKIP & 2)) a_prefetch(nxt, PF == 3 ? cc : 0);
                 kstep(chunk, 0, RING == 3 ? (2 * cc) % 3 : 0, 0);
                 kstep(chunk, 1, RING == 3 ? (2 * cc + 1) % 3 : 1, 1);
-                if (!(VD_GS_SKIP & 6)) a_store(smem_c + ((chunk + 1) & 1) * ABUF);
+                if (!(VD_GS_SKIP & 6)) a_store(smem_c + ((chunk + 1) & 1) * ABUF, PF == 3 ? (cc + 1) % 3 : 0);
                 __syncthreads();
                 a_frags(0, smem_c + ((chunk + 1) & 1) * ABUF, 0);
             }

@@ -71,6 +71,9 @@ struct IgemmArgs {
     // wfrag is the bf16-split image of the weights (gemm_split.hip: fp32 accuracy from six bf16 piece products);
     // zs_w then counts floats of that image as well
     int wsplit;
+    // conv_wino_r64.hip, small grids only: scratch for split-K partial outputs (conv_wino_r64_ksplit_floats), or null
+    float* ksplit_ws;
+    size_t ksplit_ws_floats;
 };
 
 struct AttnSpatialArgs {
@@ -138,6 +141,8 @@ int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino_s64(const float* oihw, unsigned short* out, int O, int I);
 bool conv_wino_r64_supported(const IgemmArgs& a);        // same weight image, transform + split in registers (conv_wino_r64.hip)
 int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s);
+int conv_wino_r64_ksplit(int nfr, int Hl, int Cin, int Cout);            // slices of the channel loop a small grid is cut into (1: none)
+size_t conv_wino_r64_ksplit_floats(int nfr, int Hl, int Cin, int Cout);  // floats of scratch the caller then provides in ksplit_ws
 bool gemm_split_supported(const IgemmArgs& a);            // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
 bool conv_split_supported(const IgemmArgs& a);          // 3x3, stride 1|2: the same kernel over an implicit im2col A
 void pack_conv3_split(const float* w_oihw, unsigned short* out, int Cout, int Cin);

@@ -39,7 +39,7 @@ def get_masks(x0, num_obs):
 
 @torch.no_grad()
 def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size=1, optimal_schedule_path=None, *,
-                use_gradient_method=False, observed_frames="x_0", sampler="p_sample", eta=0.0, executor="graph",
+                use_gradient_method=False, observed_frames="x_0", sampler="p_sample", eta=0.0, executor="eager",
                 adaptive_distance="lpips"):
     """video_sample.py:50-190.  Returns (samples ndarray (B,T,C,H,W), None).
 
@@ -47,10 +47,12 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
     back one index list per batch item.  `adaptive_distance` is the reference's `distance` ('lpips' is what its script
     passes and needs `inference_util.set_lpips_embedder`; 'l2' works on the frames themselves).
 
-    executor='graph' (default): each window's step loop runs on the window executor -- one captured hipGraph per window
-    shape, step index and noise counter on the device (executor.py).  executor='eager': one `diffusion.p_sample` call
-    per step from the host with `th.randn_like` noise, the reference's own loop (needed to replay a recorded noise
-    sequence, and for observed_frames='x_t_minus_1')."""
+    executor='eager' (default): one `diffusion.p_sample` call per step from the host with `th.randn_like` noise, the
+    reference's own loop.  executor='graph': each window's step loop runs on the window executor -- one captured hipGraph
+    per window shape, step index and noise counter on the device (executor.py).  The device is the bottleneck either way
+    (the eager host loop runs ahead of it; measured 7.28 ms eager vs 7.49 ms graph per step at B=1 x T=16 and 28.9 vs 29.1
+    at the headline window, profiles/r03a_*), so the graph is an option -- a host too slow to stay ahead, one launch per
+    step to trace -- not the default."""
     adaptive = "adaptive" in mode
     B, T, C, H, W = batch.shape
     device = model.device
@@ -195,8 +197,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--adaptive_distance", default="l2", choices=["l2", "lpips"],
                     help="adaptive-* modes: frame embedding for the farthest-point selection (lpips needs set_lpips_embedder)")
-    ap.add_argument("--executor", default="graph", choices=["graph", "eager"],
-                    help="graph: one captured hipGraph per window shape (executor.py); eager: one p_sample call per step")
+    ap.add_argument("--executor", default="eager", choices=["graph", "eager"],
+                    help="eager: one p_sample call per step (default); graph: one captured hipGraph per window shape (executor.py)")
     ap.add_argument("--eval_dir", default=None,
                     help="results directory; default: derived from the checkpoint path and the sampling options "
                          "(test_util.get_model_results_path), 'results/synthetic' without a checkpoint")
