@@ -83,7 +83,8 @@ int vd_set_freqs(vd_engine* e, const float* host_time_freqs, int n_time, const f
  * (respace.py:111-119): t_model = map[t] * rescale (rescale = 1000/original_steps, or 1 with rescale off). */
 enum { VD_TAB_SQRT_RECIP = 0, VD_TAB_SQRT_RECIPM1, VD_TAB_COEF1, VD_TAB_COEF2, VD_TAB_LOGVAR /* model log variance */,
        VD_TAB_ACP, VD_TAB_ACP_PREV, VD_TAB_SQRT_ACP, VD_TAB_SQRT_1M_ACP,
-       VD_TAB_POST_LOGVAR /* posterior_log_variance_clipped */, VD_TAB_LOG_1M_ACP /* log_one_minus_alphas_cumprod */, VD_NTAB };
+       VD_TAB_POST_LOGVAR /* posterior_log_variance_clipped */, VD_TAB_LOG_1M_ACP /* log_one_minus_alphas_cumprod */,
+       VD_TAB_ALPHA /* alphas = 1 - betas (the guidance weight, gaussian_diffusion.py:363) */, VD_NTAB };
 int vd_set_schedule(vd_engine* e, int num_timesteps, const float* host_tab, const int* host_timestep_map,
                     float rescale);
 
@@ -176,6 +177,24 @@ int vd_posterior_from_xstart(vd_engine* e, int mode, int B, long long per_sample
                              const long long* t, int clip_denoised, float eta, const float* noise,
                              unsigned long long seed, unsigned long long offset, float* sample, float* pred_xstart,
                              float* mean, void* stream);
+
+/* use_gradient_method (gaussian_diffusion.py:264-271,350-364; scripts/video_sample.py:429 `--use_gradient_method`).
+ * The guidance needs d(loss)/d(x_t) through the whole UNet: backward-DATA only, no weight gradients.  Its matrix products
+ * run on the forward kernels over a second packed image -- transposed linear weights, 180-degree-rotated transposed 3x3
+ * kernels -- that exists only when asked for: vd_bwd_weights_bytes -> vd_set_bwd_weight_storage (device memory, or host
+ * memory for a broadcast image) -> vd_load_weight_bwd per checkpoint tensor (a no-op for tensors the backward never reads).
+ * vd_guided_step is p_mean_variance(..., use_gradient_method=True) (+ p_sample's noise add when `sample` is given):
+ *   the network sees obs_mask := 0 and latent_mask := obs_mask + latent_mask; with the unguided mean / variance a sample
+ *   x_{t-1} = mean + [t != 0] sigma_t * noise is drawn, loss = sum(((x_{t-1} - x_t_minus_1) * obs_mask)^2) is differentiated
+ *   w.r.t. x, and mean' = mean - 10 * alpha_t * grad / 2.  Outputs (each may be NULL): mean', pred_xstart, grad,
+ *   sample = mean' + [t != 0] sigma_t * noise2. */
+long long vd_bwd_weights_bytes(vd_engine* e);
+int vd_set_bwd_weight_storage(vd_engine* e, void* buf, long long bytes, int on_host);
+int vd_load_weight_bwd(vd_engine* e, const char* name, const float* host_data, long long numel);
+int vd_guided_step(vd_engine* e, int B, int T, const float* x, const float* obs_mask, const float* latent_mask,
+                   const float* kinda_marg_mask, const long long* frame_indices, const long long* t, int clip_denoised,
+                   const float* x_t_minus_1, const float* noise, const float* noise2, float* mean, float* pred_xstart,
+                   float* grad, float* sample, void* stream);
 
 /* diffusion.q_sample(x_start, t, noise) (gaussian_diffusion.py:190-206). */
 int vd_q_sample(vd_engine* e, int B, long long per_sample, const float* x_start, const long long* t,

@@ -68,6 +68,38 @@ class SamplerRef:
         o["sample"] = o["mean"] + nz * torch.exp(0.5 * o["log_variance"]) * noise
         return o
 
+    def guided_mean_variance(self, x, t, kw, noise, clip=True):
+        """p_mean_variance(..., use_gradient_method=True), gaussian_diffusion.py:264-271,350-364: the network sees every
+        frame as latent; loss = sum(((mean + [t != 0] sigma z - x_t_minus_1) * obs_mask)^2) is differentiated w.r.t. x by
+        autograd THROUGH THE ORACLE's own network; mean' = mean - 10 * alpha_t * grad / 2."""
+        s = self.s
+        obs = kw["obs_mask"]
+        kw2 = dict(kw, obs_mask=torch.zeros_like(obs), latent_mask=obs + kw["latent_mask"])
+        x = x.detach().clone().requires_grad_(True)
+        tm = torch.tensor(s.timestep_map, dtype=t.dtype)[t]
+        if s.rescale_timesteps:
+            tm = tm.float() * (1000.0 / s.original_num_steps)
+        with torch.enable_grad():
+            eps = self.net.with_grad(x, tm, **kw2)
+            x0 = _coef(s.sqrt_recip_alphas_cumprod, t, x) * x - _coef(s.sqrt_recipm1_alphas_cumprod, t, x) * eps
+            if clip:
+                x0 = x0.clamp(-1, 1)
+            mean = _coef(s.posterior_mean_coef1, t, x) * x0 + _coef(s.posterior_mean_coef2, t, x) * x
+            logvar = _coef(s.model_log_variance, t, x).expand(x.shape)
+            nz = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+            smp = mean + nz * torch.exp(0.5 * logvar) * noise
+            loss = (((smp - kw["x_t_minus_1"]) * obs) ** 2).sum()
+            g, = torch.autograd.grad(loss, x)
+        alpha = _coef(s.alphas, t, x)
+        return dict(mean=(mean - 10 * alpha * g / 2).detach(), pred_xstart=x0.detach(), grad=g, log_variance=logvar.detach(),
+                    variance=_coef(s.model_variance, t, x).expand(x.shape))
+
+    def guided_p_sample(self, x, t, kw, noise, noise2, clip=True):
+        o = self.guided_mean_variance(x, t, kw, noise, clip)
+        nz = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+        o["sample"] = o["mean"] + nz * torch.exp(0.5 * o["log_variance"]) * noise2
+        return o
+
     def ddim_sample(self, x, t, kw, noise, eta=0.0, clip=True, eps=None):
         s = self.s
         o = self.mean_variance(x, t, kw, clip, eps)

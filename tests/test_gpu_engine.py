@@ -907,3 +907,69 @@ def test_256_topology_miniature_vs_oracle():
     want = ora.eps(c["x"], t, kw)
     got, _ = diff._wrap_model(model)(c["x"].cuda(), t.cuda(), **kwargs_of(c))
     close(got.cpu(), want, atol=1e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# use_gradient_method -- the guidance gradient through the whole UNet (backward-data on the engine)
+@pytest.mark.parametrize("case", ["c32", "c64", "c64tab"])
+def test_use_gradient_method_matches_reference_golden(case):
+    """p_mean_variance / p_sample with use_gradient_method=True (gaussian_diffusion.py:264-271,350-364) against what the
+    imported reference's autograd produced (tools/gen_golden_r3.py grad): x.grad itself, the shifted mean, p_sample's draw.
+    c32: 32 base channels (generic conv / split GEMM kernels), c64: 64 (Winograd backward-data on the rotated transposed
+    image, split-K on the small grids), c64tab: bucket-table RPE, no scale-shift norm.  Tolerance: the gradient is O(10)
+    and passes through ~60 layers twice; 2e-4 of its largest entry + 1e-3 relative (observed: a few 1e-5 of the scale)."""
+    rec = load_npz("grad_tiny.npz")
+    cfg = json.loads(str(rec[f"{case}_cfg_json"]))
+    model, diff = engine(cfg)
+    g = lambda k: torch.from_numpy(rec[f"{case}_{k}"])  # noqa: E731
+    kw = dict(frame_indices=g("frame_indices").cuda(), x0=g("x0").cuda(), obs_mask=g("obs_mask").cuda(), latent_mask=g("latent_mask").cuda(),
+              kinda_marg_mask=g("kinda_marg_mask").cuda(), x_t_minus_1=g("x_t_minus_1").cuda(), observed_frames="x_0")
+    x = g("x").cuda()
+    B = x.shape[0]
+    for t_val in [249, 100, 1, 0]:
+        t = torch.tensor([t_val] * B, device="cuda")
+        o = diff._guided(model, x, t, True, kw, noise2=g("noise2"), want_sample=True, _noise=g("noise"))
+        want = rec[f"{case}_t{t_val}_grad"]
+        scale = float(np.abs(want).max())
+        close(o["grad"].cpu(), want, atol=2e-4 * scale, rtol=1e-3)
+        close(o["mean"].cpu(), rec[f"{case}_t{t_val}_mean"], atol=1e-3 * scale, rtol=1e-3)
+        close(o["sample"].cpu(), rec[f"{case}_t{t_val}_psample"], atol=1e-3 * scale, rtol=1e-3)
+        gain = 1.0 + float(diff.sqrt_recipm1_alphas_cumprod[t_val])
+        close(o["pred_xstart"].cpu(), rec[f"{case}_t{t_val}_pred_xstart"], atol=2e-5 * gain, rtol=1e-4)
+    # the public surface: p_sample / p_mean_variance with the flag, noise from torch's generator in the reference's order
+    torch.manual_seed(3)
+    a = diff.p_sample(model, x, torch.tensor([50] * B, device="cuda"), model_kwargs=kw, use_gradient_method=True)
+    torch.manual_seed(3)
+    n1 = torch.randn_like(x); n2 = torch.randn_like(x)
+    b = diff._guided(model, x, torch.tensor([50] * B, device="cuda"), True, kw, noise2=n2, want_sample=True, _noise=n1)
+    assert torch.equal(a["sample"], b["sample"]) and torch.isfinite(a["sample"]).all()
+    pm = diff.p_mean_variance(model, x, torch.tensor([50] * B, device="cuda"), model_kwargs=kw, use_gradient_method=True)
+    assert set(pm) >= {"mean", "variance", "log_variance", "pred_xstart"} and pm["mean"].shape == x.shape
+    # an unguided step afterwards is unaffected (the guided step leaves the engine's workspace reusable)
+    c = case_inputs(load_npz("unet_tiny.npz"), 0) if case == "c32" else None
+    if c is not None:
+        eps, _ = diff._wrap_model(model)(c["x"].cuda(), c["t"].cuda(), **kwargs_of(c))
+        close(eps.cpu(), c["eps"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,n_obs,mc,S", [(2, 5, 2, 64, 32), (1, 3, 1, 128, 32), (1, 4, 2, 128, 64)])
+def test_use_gradient_method_vs_oracle_autograd(B, T, n_obs, mc, S):
+    """Wider shapes than the goldens (odd frame counts, 128 base channels, a 64x64 image: every backward kernel family incl.
+    the stride-2 and upsample convs at four resolutions) against autograd through the CPU oracle (itself pinned to the
+    reference's gradient in tests/test_oracle_golden.py)."""
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=8, image_size=S, num_channels=mc, num_res_blocks=1, rp_alpha=8,
+                                                              rp_beta=8, rp_gamma=8, timestep_respacing="ddim50")}
+    model, diff, ora = _oracle(cfg)
+    c = _rand_window(B, T, S, n_obs, seed=700 + B * 10 + T)
+    gen = torch.Generator().manual_seed(5)
+    n1, n2 = torch.randn(c["x"].shape, generator=gen), torch.randn(c["x"].shape, generator=gen)
+    xtm1 = c["x0"] + 0.2 * torch.randn(c["x"].shape, generator=gen) * c["obs_mask"]
+    t = torch.tensor([30] * B)
+    kwo = dict(x0=c["x0"], obs_mask=c["obs_mask"], latent_mask=c["latent_mask"], kinda_marg_mask=c["kinda_marg_mask"],
+               frame_indices=c["frame_indices"], x_t_minus_1=xtm1)
+    want = ora.guided_p_sample(c["x"], t, kwo, n1, n2)
+    kw = dict(kwargs_of(c), x_t_minus_1=xtm1.cuda())
+    got = diff._guided(model, c["x"].cuda(), t.cuda(), True, kw, noise2=n2, want_sample=True, _noise=n1)
+    scale = float(want["grad"].abs().max())
+    close(got["grad"].cpu(), want["grad"], atol=2e-4 * scale, rtol=1e-3)
+    close(got["sample"].cpu(), want["sample"], atol=1e-3 * scale, rtol=1e-3)

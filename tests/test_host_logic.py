@@ -40,7 +40,8 @@ def test_schedule_tables_bit_exact(tag):
         want = np.array([float.fromhex(h) for h in rec[name]])
         assert np.array_equal(getattr(d, name), want), name
     tab = d._device_tables()
-    assert tab.shape == (11, d.num_timesteps) and tab.dtype == np.float32
+    assert tab.shape == (12, d.num_timesteps) and tab.dtype == np.float32      # VD_NTAB rows (include/vd_amd.h)
+    assert np.array_equal(tab[11], (1.0 - d.betas).astype(np.float32))          # alphas: the guidance weight
 
 
 def test_schedulers_match_reference_sequences():

@@ -258,3 +258,28 @@ def test_full_size_oracle_matches_reference_golden():
     close(got, rec["eps"], atol=2e-5, rtol=1e-4)
     tm = load_json("full_size_reference_vs_oracle.json")["unet_full64.npz"]
     assert tm["max_abs_eps_diff"] < 2e-5 and 0.5 < tm["oracle_s_per_step"] / tm["reference_s_per_step"] < 2.0
+
+
+@pytest.mark.parametrize("case", ["c32", "c64", "c64tab"])
+def test_guidance_gradient_matches_reference(case):
+    """use_gradient_method (gaussian_diffusion.py:264-271,350-364): x.grad, the shifted mean and p_sample's draw of the
+    imported reference (tools/gen_golden_r3.py grad) against autograd through the oracle's own network."""
+    rec = load_npz("grad_tiny.npz")
+    cfg = json.loads(str(rec[f"{case}_cfg_json"]))
+    import video_diffusion_amd as vda
+    model, _ = vda.create_video_model_and_diffusion(**{k: cfg[k] for k in vda.video_model_and_diffusion_defaults()})
+    net = UNetRef(cfg, synth_sd(model.param_specs()))
+    sched = ScheduleRef(cfg["diffusion_steps"], cfg["noise_schedule"], cfg["timestep_respacing"], cfg["sigma_small"],
+                        cfg["rescale_timesteps"])
+    ora = SamplerRef(sched, net)
+    g = lambda k: torch.from_numpy(rec[f"{case}_{k}"])  # noqa: E731
+    kw = dict(x0=g("x0"), obs_mask=g("obs_mask"), latent_mask=g("latent_mask"), kinda_marg_mask=g("kinda_marg_mask"),
+              frame_indices=g("frame_indices"), x_t_minus_1=g("x_t_minus_1"))
+    B = g("x").shape[0]
+    for t_val in [249, 100, 1, 0]:
+        o = ora.guided_p_sample(g("x"), torch.tensor([t_val] * B), kw, g("noise"), g("noise2"))
+        want = rec[f"{case}_t{t_val}_grad"]
+        scale = float(np.abs(want).max())
+        close(o["grad"], want, atol=2e-5 * scale, rtol=1e-3)
+        close(o["mean"], rec[f"{case}_t{t_val}_mean"], atol=1e-4 * scale, rtol=1e-3)
+        close(o["sample"], rec[f"{case}_t{t_val}_psample"], atol=1e-4 * scale, rtol=1e-3)

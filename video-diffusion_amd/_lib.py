@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libvdamd.so")
-SOURCES = ["igemm.hip", "conv_halo.hip", "conv_wino.hip", "conv_wino_s64.hip", "conv_wino_r64.hip", "gemm_frag.hip", "gemm_split.hip", "norm.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "conv_halo.hip", "conv_wino.hip", "conv_wino_s64.hip", "conv_wino_r64.hip", "gemm_frag.hip", "gemm_split.hip", "norm.hip", "backward.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vd_amd.h")
 
 
@@ -141,6 +141,10 @@ SIGNATURES = {
     "vd_window_graphs": (_I, [_P]),
     "vd_posterior_update": (_I, [_P, _I, _I, _L, _P, _P, _P, _I, _F, _P, _U, _U, _P, _P, _P]),
     "vd_posterior_from_xstart": (_I, [_P, _I, _I, _L, _P, _P, _P, _I, _F, _P, _U, _U, _P, _P, _P, _P]),
+    "vd_bwd_weights_bytes": (_L, [_P]),
+    "vd_set_bwd_weight_storage": (_I, [_P, _P, _L, _I]),
+    "vd_load_weight_bwd": (_I, [_P, ctypes.c_char_p, _P, _L]),
+    "vd_guided_step": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vd_q_sample": (_I, [_P, _I, _L, _P, _P, _P, _P, _P]),
     "vd_randn": (_I, [_P, _L, _U, _U, _P]),
     "vd_profile_begin": (_I, []),

@@ -437,31 +437,35 @@ bool conv_wino_r64_supported(const IgemmArgs& a) {
 // ---- split-K for small grids ------------------------------------------------------------------------------------
 // out[m][c] = sum_s part[s][m][c] + bias[c] + fbias[frame][c] + res[m][c], and the GroupNorm partial sums of the result in
 // the layout the one-launch epilogue writes ([frame][split = 1][Cout][2] doubles: maps <= 16 x 16 only).  Block = one frame
-// x 64 channels; thread (c, pixel phase): coalesced 256-byte rows.
-__global__ __launch_bounds__(256) void wino_r64_reduce_kernel(const float* part, int S, size_t slab, const float* bias, const float* fbias,
-                                                                  int fbias_ld, const float* res, int res_ld, float* out, int ldo, int HW,
-                                                                  int Cout, double* stats) {
-    const int f = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
-    const float b = (bias ? bias[c] : 0.f) + (fbias ? fbias[(size_t)f * fbias_ld + c] : 0.f);
-    double s1 = 0.0, s2 = 0.0;
-    for (int p = ph; p < HW; p += 4) {
+// x 16 channels: thread (channel quad, pixel phase of 64) runs HW / 64 <= 4 iterations of independent 16-byte loads (the
+// first version, one frame x 64 channels per block with 64 dependent iterations, took longer than the convolution).
+__global__ __launch_bounds__(256) void wino_r64_reduce_kernel(const float* __restrict__ part, int S, size_t slab, const float* __restrict__ bias,
+                                                                  const float* __restrict__ fbias, int fbias_ld, const float* __restrict__ res, int res_ld,
+                                                                  float* __restrict__ out, int ldo, int HW, int Cout, double* __restrict__ stats) {
+    const int f = blockIdx.x, q = threadIdx.x & 3, ph = threadIdx.x >> 2, c = blockIdx.y * 16 + q * 4;
+    f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (fbias) b += *reinterpret_cast<const f32x4*>(fbias + (size_t)f * fbias_ld + c);
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int p = ph; p < HW; p += 64) {
         const size_t m = (size_t)f * HW + p;
-        float v = 0.f;
-        for (int k = 0; k < S; ++k) v += part[k * slab + m * Cout + c];
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + m * Cout + c);
+        for (int k = 1; k < S; ++k) v += *reinterpret_cast<const f32x4*>(part + k * slab + m * Cout + c);
         v += b;
-        if (res) v += res[m * res_ld + c];
-        out[m * ldo + c] = v;
-        s1 += (double)v; s2 += (double)v * (double)v;
+        if (res) v += *reinterpret_cast<const f32x4*>(res + m * res_ld + c);
+        *reinterpret_cast<f32x4*>(out + m * ldo + c) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += (double)v[e]; s2[e] += (double)v[e] * (double)v[e]; }
     }
     if (stats) {
-        __shared__ double red[4][64][2];
-        red[ph][threadIdx.x & 63][0] = s1; red[ph][threadIdx.x & 63][1] = s2;
+        __shared__ double red[64][16][2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[ph][q * 4 + e][0] = s1[e]; red[ph][q * 4 + e][1] = s2[e]; }
         __syncthreads();
-        if (ph == 0) {
-            const int l = threadIdx.x;
-            double* o = stats + ((size_t)f * Cout + c) * 2;
-            o[0] = red[0][l][0] + red[1][l][0] + red[2][l][0] + red[3][l][0];
-            o[1] = red[0][l][1] + red[1][l][1] + red[2][l][1] + red[3][l][1];
+        if (threadIdx.x < 32) {
+            const int ch = threadIdx.x >> 1, w = threadIdx.x & 1;
+            double t = 0.0;
+            for (int k = 0; k < 64; ++k) t += red[k][ch][w];
+            stats[((size_t)f * Cout + blockIdx.y * 16 + ch) * 2 + w] = t;
         }
     }
 }
@@ -514,7 +518,7 @@ int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
     VD_HIP(hipGetLastError());
     if (g.ksplit > 1) {
         const int HW = Hl * Hl;
-        hipLaunchKernelGGL(wino_r64_reduce_kernel, dim3(a.nfr, a.Cout / 64), dim3(256), 0, s, a.ksplit_ws, g.ksplit,
+        hipLaunchKernelGGL(wino_r64_reduce_kernel, dim3(a.nfr, a.Cout / 16), dim3(256), 0, s, a.ksplit_ws, g.ksplit,
                            (size_t)a.nfr * HW * a.Cout, a.bias, a.fbias, a.fbias_ld, a.res, a.res_ld, a.out, a.ldo, HW, a.Cout, a.stats);
         VD_HIP(hipGetLastError());
     }

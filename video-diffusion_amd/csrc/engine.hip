@@ -39,6 +39,10 @@ struct Param {
     // PK_LINF members of a batched matrix (all FiLM projections / all RPE time projections are ONE GEMM):
     // `off` is the base of the whole fragment-major image, rows [frag_row0, +shape[0]) of frag_rows in total
     int frag_rows = 0, frag_row0 = 0;
+    // backward-data image (use_gradient_method): the transposed matrix of a linear layer / 1x1 conv, the 180-degree-rotated
+    // transposed kernel of a 3x3 conv, in the layout of kind_bwd; -1: the backward pass does not need this parameter
+    int kind_bwd = -1;
+    size_t off_bwd = 0, packed_bwd = 0;
 };
 
 struct ResP {
@@ -54,6 +58,20 @@ struct Layer { int type; int idx; };      // 0 stem, 1 res, 2 attn, 3 down, 4 up
 // An activation tensor [N][H][H][C]; part/split: its GroupNorm partial sums [N][split][C][2] when the producing
 // convolution's epilogue wrote them (conv_wino.hip), else null and the consumer's GroupNorm runs the statistics pass.
 struct Tens { float* p; int C, H; double* part = nullptr; int split = 0; };
+
+// ---- tape of one forward pass, kept when the step is guided (use_gradient_method): every op with the tensors its
+// backward reads.  Pointers are arena addresses; nothing of a taped forward is released before the backward has run.
+struct TapeRes { int idx; Tens x0, x1; bool has_x1; int N; float *A1, *B1, *mr1, *h, *A2, *B2, *mr2, *o; };
+struct TapeAttn { int idx; Tens x; int B, T; float *xn, *qkv, *Rk, *Rq, *Rv, *o, *xt, *A, *Bf, *mr, *xn2, *qkv2, *o2, *xs; const float* amask; };
+struct TapeConv { int type, idx; Tens in, out; };                     // 0 stem, 3 down, 4 up
+struct TapePos { Tens in, out; };
+struct TapeOp { int kind, i; };                                       // kind: 0 conv, 1 res, 2 attn, 5 posenc
+struct Tape {
+    std::vector<TapeOp> ops;
+    std::vector<TapeRes> res; std::vector<TapeAttn> attn; std::vector<TapeConv> conv; std::vector<TapePos> pos;
+    Tens head; float *headA = nullptr, *headB = nullptr, *head_mr = nullptr;
+    void clear() { ops.clear(); res.clear(); attn.clear(); conv.clear(); pos.clear(); }
+};
 
 static const int CH_MULT_256[] = {1, 1, 2, 2, 4, 4};
 static const int CH_MULT_128[] = {1, 1, 2, 3, 4};
@@ -81,7 +99,7 @@ struct Arena {
     bool dry = false;
     template <class Tp> Tp* get(size_t n) {
         size_t bytes = (n * sizeof(Tp) + 255) & ~(size_t)255;
-        char* p = dry ? reinterpret_cast<char*>(0x1000) : base + used;
+        char* p = (dry ? reinterpret_cast<char*>(0x1000) : base) + used;     // dry run: distinct, never dereferenced (the backward keys gradients by tensor address)
         used += bytes;
         peak = std::max(peak, used);
         return reinterpret_cast<Tp*>(p);
@@ -202,6 +220,9 @@ struct vd_engine {
     char* ws = nullptr; size_t ws_cap = 0;
     int ws_B = 0, ws_T = 0; size_t ws_tail = 0;      // the window shape ws_tail was computed for (dry run of the topology)
     std::unordered_map<long long, size_t> ws_peaks;  // (B << 32 | T) -> arena peak
+    // ---- use_gradient_method: second packed image (backward-data weights) + the tape of the guided step's forward
+    float* wbuf_bwd = nullptr; bool wbuf_bwd_on_host = false; size_t packed_bwd_total = 0;
+    Tape* tape = nullptr;
     int* d_err = nullptr;                            // sticky device flags: bit 0 = timestep index out of range
     int device = -1;
     double* d_part = nullptr; size_t part_cap = 0;   // NLL partial sums
@@ -280,7 +301,12 @@ struct vd_engine {
     int attn_block(const AttnP& a, Tens x, int B, int T, const float* te_all, const int64_t* fidx, const float* amask,
                    hipStream_t st, Arena& ar, Tens* out);
     int gn_fold(const Tens& x0, const Tens* x1, int N, int gw, int gb, const float* film,
-                int film_ld, hipStream_t st, Arena& ar, float** A, float** B);
+                int film_ld, hipStream_t st, Arena& ar, float** A, float** B, float** mr = nullptr);
+    int backward(const FwdIn& in, const float* deps, float* dx, hipStream_t st, Arena& ar);
+    int bwd_linear(const float* dy, int M, int pw, const float* res, float* out, hipStream_t st);
+    int bwd_conv3(Tens dy, int N, int pw, int cout_bwd, const float* res, float* out, hipStream_t st, Arena& ar);
+    int ensure_ws_guided(int B, int T);
+    const float* WB(int p) const { return wbuf_bwd + params[p].off_bwd; }
     int linear(const float* a, int M, int K, int pw, int pb, int Nout, const float* wptr, const float* bptr, int act,
                const float* res, float* out, hipStream_t st, const Tens* stats_of = nullptr);
     void gemm_stats_table(Arena& ar, int M, int K, int Nout, Tens* t);
@@ -316,6 +342,12 @@ int vd_engine::build() {
         if (res_out >= 8 && cout % 64 == 0 && !no_wino) return (int)PK_CONV3W;
         return res_out >= 8 && cout % 32 == 0 ? (int)PK_CONV3F : (int)PK_CONV3;
     };
+    // backward-data image of a 3x3 stride-1 conv with `co` outputs (= the forward's inputs) and `ci` inputs at resolution rs
+    auto k3b = [&](int rs, int co, int ci) {
+        return rs >= 8 && (rs & (rs - 1)) == 0 && co % 64 == 0 && ci % 32 == 0 && split_conv() && !no_wino ? (int)PK_CONV3W : (int)PK_CONV3;
+    };
+    auto bwd3 = [&](int p, int rs) { params[p].kind_bwd = k3b(rs, (int)params[p].shape[1], (int)params[p].shape[0]); };
+    auto bwdl = [&](int p) { params[p].kind_bwd = PK_LINF; };
     auto add_res = [&](const std::string& pre, int cin, int cout, int rs) {
         ResP r; r.cin = cin; r.cout = cout;
         r.gn1w = add(pre + ".in_layers.0.weight", {cin}); r.gn1b = add(pre + ".in_layers.0.bias", {cin});
@@ -326,7 +358,9 @@ int vd_engine::build() {
         r.c2w = add(pre + ".out_layers.3.weight", {cout, cout, 3, 3}, k3(rs, cout)); r.c2b = add(pre + ".out_layers.3.bias", {cout});
         if (cin != cout) {
             r.skw = add(pre + ".skip_connection.weight", {cout, cin, 1, 1}, PK_LINF); r.skb = add(pre + ".skip_connection.bias", {cout});
+            bwdl(r.skw);
         }
+        bwd3(r.c1w, rs); bwd3(r.c2w, rs);
         res.push_back(r);
         return (int)res.size() - 1;
     };
@@ -335,6 +369,7 @@ int vd_engine::build() {
         a.qkvw = add(pre + ".qkv.weight", {3 * C, C}, PK_LINF); a.qkvb = add(pre + ".qkv.bias", {3 * C});
         a.projw = add(pre + ".proj_out.weight", {C, C}, PK_LINF); a.projb = add(pre + ".proj_out.bias", {C});
         a.normw = add(pre + ".norm.weight", {C}); a.normb = add(pre + ".norm.bias", {C});
+        bwdl(a.qkvw); bwdl(a.projw);
         return a;
     };
     auto add_rpe = [&](const std::string& pre, int C) {
@@ -359,15 +394,17 @@ int vd_engine::build() {
         attn.push_back(a);
         return (int)attn.size() - 1;
     };
-    auto add_conv = [&](const std::string& pre, int cin, int cout, int kind) {
+    auto add_conv = [&](const std::string& pre, int cin, int cout, int kind, int rs_bwd) {
         ConvP c; c.c = cout;
         c.w = add(pre + ".weight", {cout, cin, 3, 3}, kind); c.b = add(pre + ".bias", {cout});
+        if (kind == PK_STEM) params[c.w].kind_bwd = PK_LINF;          // [STEM_KPAD][cout]: dcols = dy * W
+        else bwd3(c.w, rs_bwd);                                       // Down: a stride-1 conv of the zero-stuffed gradient at the INPUT resolution
         convs.push_back(c);
         return (int)convs.size() - 1;
     };
 
     std::vector<int> chans;
-    input_blocks.push_back({Layer{0, add_conv("input_blocks.0.0", 5, mc, PK_STEM)}});
+    input_blocks.push_back({Layer{0, add_conv("input_blocks.0.0", 5, mc, PK_STEM, cfg.image_size)}});
     chans.push_back(mc);
     int ch = mc, ds = 1, first_ds = -1, first_ch = -1;
     n_before_attn = -1;
@@ -386,7 +423,7 @@ int vd_engine::build() {
         if (lvl != nlev - 1) {
             const std::string pre = "input_blocks." + std::to_string(input_blocks.size());
             // Downsample (unet.py:98): stride-2 3x3 -> the split GEMM over an implicit im2col operand
-            input_blocks.push_back({Layer{3, add_conv(pre + ".0.op", ch, ch, split_math() ? PK_CONV3S : PK_CONV3)}});
+            input_blocks.push_back({Layer{3, add_conv(pre + ".0.op", ch, ch, split_math() ? PK_CONV3S : PK_CONV3, cfg.image_size / ds)}});
             chans.push_back(ch);
             ds *= 2;
         }
@@ -414,7 +451,7 @@ int vd_engine::build() {
             int li = 1;
             if (in_att(ds)) { int ai = add_attn(pre + "." + std::to_string(li++), ch); if (ai < 0) return ai; blk.push_back(Layer{2, ai}); }
             if (lvl && i == nrb) {
-                blk.push_back(Layer{4, add_conv(pre + "." + std::to_string(li++) + ".conv", ch, ch, k3(2 * cfg.image_size / ds, ch))});
+                blk.push_back(Layer{4, add_conv(pre + "." + std::to_string(li++) + ".conv", ch, ch, k3(2 * cfg.image_size / ds, ch), 2 * cfg.image_size / ds)});
                 ds /= 2;
             }
             output_blocks.push_back(blk);
@@ -449,6 +486,19 @@ int vd_engine::build() {
     if (cfg.use_rpe_net)
         for (auto& a : attn)
             for (RpeP* r : {&a.rq, &a.rk, &a.rv}) { Param& p = params[r->tw]; p.off = te_w_off; p.frag_rows = te_total; p.frag_row0 = r->te_off; }
+    // ---- backward-data image (its own buffer, set only when a guided step is wanted: vd_set_bwd_weight_storage)
+    size_t offb = 0;
+    for (auto& p : params) {
+        if (p.kind_bwd < 0) continue;
+        const size_t O = (size_t)p.shape[1], I = (size_t)p.shape[0];          // outputs / inputs of the BACKWARD operator
+        if (p.kind == PK_STEM) p.packed_bwd = (size_t)STEM_KPAD * I * 3 / 2;
+        else if (p.kind_bwd == PK_LINF) p.packed_bwd = O * I * 3 / 2;
+        else if (p.kind_bwd == PK_CONV3W) p.packed_bwd = 16 * O * I * 3 / 2;
+        else p.packed_bwd = 9 * O * I;
+        p.off_bwd = offb;
+        offb += (p.packed_bwd + 3) & ~(size_t)3;
+    }
+    packed_bwd_total = offb;
     for (auto& p : params)
         if (p.kind == PK_LINF) {
             if (!p.frag_rows) p.frag_rows = (int)p.shape[0];
@@ -505,7 +555,7 @@ int vd_engine::linear(const float* a, int M, int K, int, int, int Nout, const fl
 }
 
 int vd_engine::gn_fold(const Tens& x0, const Tens* x1, int N, int gw, int gb,
-                       const float* film, int film_ld, hipStream_t st, Arena& ar, float** A, float** Bp) {
+                       const float* film, int film_ld, hipStream_t st, Arena& ar, float** A, float** Bp, float** mr) {
     const int HW = x0.H * x0.H, C = x0.C + (x1 ? x1->C : 0);
     // per-channel partial sums of each source: the table its producer wrote, or one statistics pass over it
     const Tens* src[2] = {&x0, x1};
@@ -524,9 +574,11 @@ int vd_engine::gn_fold(const Tens& x0, const Tens* x1, int N, int gw, int gb,
     }
     *A = ar.get<float>((size_t)N * C);
     *Bp = ar.get<float>((size_t)N * C);
+    float* mrp = tape && mr ? ar.get<float>((size_t)N * 64) : nullptr;      // group mean / rstd for the backward pass
+    if (mr) *mr = mrp;
     if (ar.dry) return 0;
     return launch_gn_affine(part[0], split[0], x0.C, part[1], split[1], (double)HW * (C / 32), W(gw), W(gb), film, film_ld, N,
-                            C, *A, *Bp, st);
+                            C, *A, *Bp, st, mrp);
 }
 
 // the epilogue of the Winograd conv (the kernel every PK_CONV3W weight runs on) writes the GroupNorm partial sums of
@@ -553,8 +605,8 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     const int cin = x0.C + (x1 ? x1->C : 0);
     VD_REQUIRE(cin == r.cin, "ResBlock input channels");
     const float* s1 = x1 ? x1->p : nullptr;
-    float *A1, *B1, *A2, *B2;
-    int rc = gn_fold(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, st, ar, &A1, &B1);
+    float *A1, *B1, *A2, *B2, *mr1 = nullptr, *mr2 = nullptr;
+    int rc = gn_fold(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, st, ar, &A1, &B1, &mr1);
     if (rc) return rc;
     float* h = ar.get<float>((size_t)N * HW * r.cout);
     Tens ht{h, r.cout, H};
@@ -579,7 +631,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         }
         ar.release(mk);
     }
-    rc = gn_fold(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, st, ar, &A2, &B2);
+    rc = gn_fold(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, st, ar, &A2, &B2, &mr2);
     if (rc) return rc;
     const float* skip = x0.p;
     if (r.skw >= 0) {
@@ -613,6 +665,10 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     }
     ot.p = o;
     *out = ot;
+    if (tape) {
+        tape->ops.push_back(TapeOp{1, (int)tape->res.size()});
+        tape->res.push_back(TapeRes{(int)(&r - res.data()), x0, x1 ? *x1 : Tens{}, x1 != nullptr, N, A1, B1, mr1, h, A2, B2, mr2, o});
+    }
     return 0;
 }
 
@@ -669,8 +725,8 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
         if ((rc = linear(o, (int)tok, C, 0, 0, C, W(a.tp.projw), W(a.tp.projb), 0, xn, xt, st, &xt_t))) return rc;
     }
     // ---- spatial attention over the HW pixels of each frame               (unet.py:258-267)
-    float *A, *Bf;
-    if ((rc = gn_fold(xt_t, nullptr, N, a.sp.normw, a.sp.normb, nullptr, 0, st, ar, &A, &Bf))) return rc;
+    float *A, *Bf, *mrs = nullptr;
+    if ((rc = gn_fold(xt_t, nullptr, N, a.sp.normw, a.sp.normb, nullptr, 0, st, ar, &A, &Bf, &mrs))) return rc;
     float* xn2 = ar.get<float>(tok * C);
     float* qkv2 = ar.get<float>(tok * 3 * C);
     float* o2 = ar.get<float>(tok * C);
@@ -687,6 +743,10 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
         if ((rc = linear(o2, (int)tok, C, 0, 0, C, W(a.sp.projw), W(a.sp.projb), 0, xn2, xs, st, &xs_t))) return rc;
     }
     *out = xs_t;
+    if (tape) {
+        tape->ops.push_back(TapeOp{2, (int)tape->attn.size()});
+        tape->attn.push_back(TapeAttn{(int)(&a - attn.data()), x, B, T, xn, qkv, R[0], R[1], R[2], o, xt, A, Bf, mrs, xn2, qkv2, o2, xs, amask});
+    }
     return 0;
 }
 
@@ -738,6 +798,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
                 nxt = Tens{o, c.c, S};
                 gemm_stats_table(ar, N * S * S, STEM_KPAD, c.c, &nxt);
                 if (!ar.dry && (rc = linear(cur.p, N * S * S, STEM_KPAD, 0, 0, c.c, W(c.w), W(c.b), 0, nullptr, o, st, &nxt))) return rc;
+                if (tape) { tape->ops.push_back(TapeOp{0, (int)tape->conv.size()}); tape->conv.push_back(TapeConv{0, L.idx, cur, nxt}); }
             } else {
                 const ConvP& c = convs[L.idx];
                 const int stride = L.type == 3 ? 2 : 1, ups = L.type == 4 ? 1 : 0;
@@ -757,6 +818,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
                     if (nxt.part && params[c.w].kind != PK_CONV3W) g.stats_hw = g.Ho * g.Wo;
                     if ((rc = igemm_p(g, st))) return rc;
                 }
+                if (tape) { tape->ops.push_back(TapeOp{0, (int)tape->conv.size()}); tape->conv.push_back(TapeConv{L.type, L.idx, cur, nxt}); }
             }
             cur = nxt;
             second = nullptr;
@@ -776,6 +838,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
                 if ((rc = launch_posenc_add(h.p, cfg.use_spatial_encoding ? W(p_posenc) : nullptr, femb, N, h.H * h.H, h.C, y, st)))
                     return rc;
             }
+            if (tape) { tape->ops.push_back(TapeOp{5, (int)tape->pos.size()}); tape->pos.push_back(TapePos{h, Tens{y, h.C, h.H}}); }
             h = Tens{y, h.C, h.H};
         }
     }
@@ -784,8 +847,9 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
         Tens skip = hs.back(); hs.pop_back();
         if ((rc = run(output_blocks[i], h, &skip, &h))) return rc;      // cat([h, hs.pop()]) read in place
     }
-    float *A, *Bf;
-    if ((rc = gn_fold(h, nullptr, N, p_outgw, p_outgb, nullptr, 0, st, ar, &A, &Bf))) return rc;
+    float *A, *Bf, *mrh = nullptr;
+    if ((rc = gn_fold(h, nullptr, N, p_outgw, p_outgb, nullptr, 0, st, ar, &A, &Bf, &mrh))) return rc;
+    if (tape) { tape->head = h; tape->headA = A; tape->headB = Bf; tape->head_mr = mrh; }
     if (!ar.dry) {
         VD_REQUIRE(h.H == S && h.C == final_ch, "output head shape");
         { ProfScope ps(PC_OUT_CONV, 2.0 * N * S * S * h.C * 27.0, 4.0 * N * S * S * (h.C + 3.0), st);
@@ -820,6 +884,206 @@ int vd_engine::ensure_ws(int B, int T) {
         ws_cap = need;
     }
     ws_B = B; ws_T = T; ws_tail = tail;
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------ backward (use_gradient_method)
+// d(out)/d(in) of every taped op, walked in reverse.  Gradients live in the same arena behind the forward's tensors; a
+// tensor's gradient buffer is created by its first consumer (assigned) and accumulated into by the others (the skip
+// connections: an encoder output feeds the next encoder block AND a decoder block).
+namespace {
+struct GradMap {
+    std::unordered_map<const float*, std::pair<float*, bool>> m;     // tensor -> (gradient, written)
+    Arena* ar;
+    float* get(const Tens& t, int N, bool* fresh) {
+        auto it = m.find(t.p);
+        if (it == m.end()) it = m.emplace(t.p, std::make_pair(ar->get<float>((size_t)N * t.H * t.H * t.C), false)).first;
+        *fresh = !it->second.second;
+        it->second.second = true;
+        return it->second.first;
+    }
+    float* have(const float* p) const { auto it = m.find(p); return it == m.end() ? nullptr : it->second.first; }
+};
+}  // namespace
+
+// out[M][K_fwd] = dy[M][N_fwd] * W  (+ res): the forward's split GEMM over the transposed image of parameter pw
+int vd_engine::bwd_linear(const float* dy, int M, int pw, const float* resid, float* out, hipStream_t st) {
+    const Param& p = params[pw];
+    const int Kb = p.kind == PK_STEM ? (int)p.shape[0] : (int)p.shape[0], Nb = p.kind == PK_STEM ? STEM_KPAD : (int)p.shape[1];
+    IgemmArgs g = linear_args(M, Kb, Nb);
+    g.src0 = dy; g.wfrag = WB(pw); g.wsplit = 1; g.res = resid; g.out = out;
+    VD_REQUIRE(gemm_split_supported(g), "backward linear layer: shape not covered by gemm_split.hip");
+    return launch_igemm(g, st);
+}
+
+// out[N][H][H][cout_bwd] = conv3x3_s1(dy, rotated transposed kernel of parameter pw) (+ res, in place allowed)
+int vd_engine::bwd_conv3(Tens dy, int N, int pw, int cout_bwd, const float* resid, float* out, hipStream_t st, Arena& ar) {
+    const Param& p = params[pw];
+    IgemmArgs g = conv_args(dy, nullptr, N, 3, 1, 0);
+    const size_t mk = ar.mark();
+    const size_t ksf = p.kind_bwd == PK_CONV3W ? conv_wino_r64_ksplit_floats(N, dy.H, dy.C, cout_bwd) : 0;
+    g.ksplit_ws = ksf ? ar.get<float>(ksf) : nullptr; g.ksplit_ws_floats = ksf;
+    ar.release(mk);
+    if (ar.dry) return 0;
+    if (p.kind_bwd == PK_CONV3W) { g.wwino = WB(pw); g.wsplit = 2; } else { g.w = WB(pw); g.wsplit = 0; }
+    g.res = resid; g.res_ld = cout_bwd; g.out = out; g.ldo = cout_bwd; g.Cout = cout_bwd;
+    return launch_igemm(g, st);
+}
+
+int vd_engine::backward(const FwdIn& in, const float* deps, float* dx, hipStream_t st, Arena& ar) {
+    const int B = in.B, T = in.T, N = B * T, S = cfg.image_size;
+    const bool dry = ar.dry;
+    int rc;
+    GradMap gm; gm.ar = &ar;
+    bool fresh;
+    // GroupNorm(+act) backward with its workspaces
+    auto gn_bwd = [&](const Tens& x0, const Tens* x1, const float* A, const float* Bv, const float* mr, const float* dy, int act,
+                      float* dx0, int acc0, float* dx1, int acc1, const float* extra) -> int {
+        const int C = x0.C + (x1 ? x1->C : 0), HW = x0.H * x0.H;
+        const size_t mk = ar.mark();
+        double* part = ar.get<double>((size_t)N * gn_bwd_split(N, HW, C) * C * 2);
+        float* K = ar.get<float>((size_t)N * 64);
+        ar.release(mk);
+        if (dry) return 0;
+        GnBwdArgs a{x0.p, x1 ? x1->p : nullptr, x0.C, C, A, Bv, mr, dy, act, N, HW, dx0, dx1, acc0, acc1, extra, part, K};
+        return launch_gn_bwd(a, st);
+    };
+    // ---- output head: eps = conv(silu(gn(h)))   (unet.py:744-749,838)
+    {
+        const Tens& h = tape->head;
+        float* dh = gm.get(h, N, &fresh);
+        const size_t mk = ar.mark();
+        float* da = ar.get<float>((size_t)N * S * S * h.C);
+        if (!dry && (rc = launch_out_conv_bwd(deps, W(p_outw), N, S, S, h.C, 3, da, st))) return rc;
+        if ((rc = gn_bwd(h, nullptr, tape->headA, tape->headB, tape->head_mr, da, 1, dh, 0, nullptr, 0, nullptr))) return rc;
+        ar.release(mk);
+    }
+    for (int oi = (int)tape->ops.size() - 1; oi >= 0; --oi) {
+        const TapeOp op = tape->ops[oi];
+        if (op.kind == 1) {                                              // ---- ResBlock (unet.py:185-198)
+            const TapeRes& t = tape->res[op.i];
+            const ResP& r = res[t.idx];
+            const int H = t.x0.H, HW = H * H, cin = r.cin;
+            float* d_o = gm.have(t.o);
+            VD_REQUIRE(dry || d_o, "backward: ResBlock output without a gradient");
+            if (!d_o) d_o = gm.get(Tens{t.o, r.cout, H}, N, &fresh);
+            bool f0, f1 = true;
+            float* dx0 = gm.get(t.x0, N, &f0);
+            float* dx1 = t.has_x1 ? gm.get(t.x1, N, &f1) : nullptr;
+            const size_t mk = ar.mark();
+            float* d_a2 = ar.get<float>((size_t)N * HW * r.cout);
+            float* d_h = ar.get<float>((size_t)N * HW * r.cout);
+            float* d_a1 = ar.get<float>((size_t)N * HW * cin);
+            float* d_sk = r.skw >= 0 ? ar.get<float>((size_t)N * HW * cin) : nullptr;
+            if ((rc = bwd_conv3(Tens{d_o, r.cout, H}, N, r.c2w, r.cout, nullptr, d_a2, st, ar))) return rc;
+            if ((rc = gn_bwd(Tens{t.h, r.cout, H}, nullptr, t.A2, t.B2, t.mr2, d_a2, 1, d_h, 0, nullptr, 0, nullptr))) return rc;
+            if ((rc = bwd_conv3(Tens{d_h, r.cout, H}, N, r.c1w, cin, nullptr, d_a1, st, ar))) return rc;
+            if (r.skw >= 0 && !dry && (rc = bwd_linear(d_o, N * HW, r.skw, nullptr, d_sk, st))) return rc;
+            // the skip path's gradient (identity: d_o itself) rides on the GroupNorm backward's write
+            if ((rc = gn_bwd(t.x0, t.has_x1 ? &t.x1 : nullptr, t.A1, t.B1, t.mr1, d_a1, 1, dx0, !f0, dx1, !f1, r.skw >= 0 ? d_sk : d_o))) return rc;
+            ar.release(mk);
+        } else if (op.kind == 2) {                                       // ---- FactorizedAttentionBlock (unet.py:236-267)
+            const TapeAttn& t = tape->attn[op.i];
+            const AttnP& a = attn[t.idx];
+            const int C = a.C, H = t.x.H, HW = H * H;
+            const size_t tok = (size_t)N * HW;
+            const float scale = 1.0f / sqrtf((float)(C / cfg.num_heads));
+            float* d_xs = gm.have(t.xs);
+            VD_REQUIRE(dry || d_xs, "backward: attention output without a gradient");
+            if (!d_xs) d_xs = gm.get(Tens{t.xs, C, H}, N, &fresh);
+            float* dxin = gm.get(t.x, N, &fresh);
+            const size_t mk = ar.mark();
+            float* d_o2 = ar.get<float>(tok * C);
+            float* d_qkv = ar.get<float>(tok * 3 * C);
+            float* d_xn2 = ar.get<float>(tok * C);
+            float* d_xt = ar.get<float>(tok * C);
+            float* d_o = ar.get<float>(tok * C);
+            float* d_xn = ar.get<float>(tok * C);
+            AttnSpatialArgs sa{t.qkv2, nullptr, N, HW, C, cfg.num_heads, scale};
+            float* sws = ar.get<float>(attn_spatial_bwd_ws_floats(sa));
+            if (!dry) {
+                // spatial half: xs = xn2 + proj(attn(qkv(xn2))), xn2 = gn(xt)
+                if ((rc = bwd_linear(d_xs, (int)tok, a.sp.projw, nullptr, d_o2, st))) return rc;
+                if ((rc = launch_attn_spatial_bwd(sa, d_o2, d_qkv, sws, st))) return rc;
+                if ((rc = bwd_linear(d_qkv, (int)tok, a.sp.qkvw, d_xs, d_xn2, st))) return rc;
+            }
+            if ((rc = gn_bwd(Tens{t.xt, C, H}, nullptr, t.A, t.Bf, t.mr, d_xn2, 0, d_xt, 0, nullptr, 0, nullptr))) return rc;
+            if (!dry) {
+                // temporal half: xt = xn + proj(attn(qkv(xn), R)), xn = temporal gn(x)
+                if ((rc = bwd_linear(d_xt, (int)tok, a.tp.projw, nullptr, d_o, st))) return rc;
+                AttnTemporalArgs ta{t.qkv, t.Rk, t.Rq, t.Rv, t.amask, nullptr, t.B, t.T, HW, C, cfg.num_heads, cfg.allow_interactions_between_padding, scale};
+                if ((rc = launch_attn_temporal_bwd(ta, d_o, d_qkv, st))) return rc;
+                if ((rc = bwd_linear(d_qkv, (int)tok, a.tp.qkvw, d_xt, d_xn, st))) return rc;
+                if ((rc = launch_gn_temporal_bwd(t.x.p, W(a.tp.normw), d_xn, t.B, t.T, HW, C, !fresh, dxin, st))) return rc;
+            }
+            ar.release(mk);
+        } else if (op.kind == 5) {                                       // ---- + positional encodings: the gradient passes
+            const TapePos& t = tape->pos[op.i];
+            float* d_y = gm.have(t.out.p);
+            VD_REQUIRE(dry || d_y, "backward: positional-encoding output without a gradient");
+            if (!d_y) d_y = gm.get(t.out, N, &fresh);
+            float* d_h = gm.get(t.in, N, &fresh);
+            if (!dry && (rc = launch_add(d_y, (size_t)N * t.in.H * t.in.H * t.in.C, !fresh, d_h, st))) return rc;
+        } else {
+            const TapeConv& t = tape->conv[op.i];
+            const ConvP& c = convs[t.idx];
+            float* d_out = gm.have(t.out.p);
+            VD_REQUIRE(dry || d_out, "backward: conv output without a gradient");
+            if (!d_out) d_out = gm.get(t.out, N, &fresh);
+            if (t.type == 0) {                                           // ---- stem: dcols = dy * W, then col2im onto x
+                const size_t mk = ar.mark();
+                float* dcols = ar.get<float>((size_t)N * S * S * STEM_KPAD);
+                if (!dry) {
+                    if ((rc = bwd_linear(d_out, N * S * S, c.w, nullptr, dcols, st))) return rc;
+                    if ((rc = launch_stem_col2im(dcols, in.obs, in.lat, in.km, N, S, S, STEM_KPAD, dx, st))) return rc;
+                }
+                ar.release(mk);
+            } else if (t.type == 3) {                                    // ---- Downsample (stride 2): stride-1 conv of the zero-stuffed gradient
+                float* d_in = gm.get(t.in, N, &fresh);
+                const size_t mk = ar.mark();
+                float* dz = ar.get<float>((size_t)N * t.in.H * t.in.H * c.c);
+                if (!dry && (rc = launch_zero_stuff2(d_out, N, t.out.H, t.out.H, c.c, dz, st))) return rc;
+                if ((rc = bwd_conv3(Tens{dz, c.c, t.in.H}, N, c.w, t.in.C, fresh ? nullptr : d_in, d_in, st, ar))) return rc;
+                ar.release(mk);
+            } else {                                                     // ---- Upsample: conv backward at 2H, then the 2x2 sums
+                float* d_in = gm.get(t.in, N, &fresh);
+                const size_t mk = ar.mark();
+                float* dup = ar.get<float>((size_t)N * t.out.H * t.out.H * t.in.C);
+                if ((rc = bwd_conv3(Tens{d_out, c.c, t.out.H}, N, c.w, t.in.C, nullptr, dup, st, ar))) return rc;
+                if (!dry && (rc = launch_sumpool2(dup, N, t.in.H, t.in.H, t.in.C, !fresh, d_in, st))) return rc;
+                ar.release(mk);
+            }
+        }
+    }
+    return 0;
+}
+
+// workspace of a guided step: forward (taped, nothing released that the backward reads) + backward + the step's own buffers
+int vd_engine::ensure_ws_guided(int B, int T) {
+    const long long key = ((long long)B << 32) | (unsigned)T | (1ll << 62);
+    auto it = ws_peaks.find(key);
+    if (it == ws_peaks.end()) {
+        Arena dry; dry.dry = true;
+        Tape tp; tape = &tp;
+        FwdIn fi{}; fi.B = B; fi.T = T;
+        int rc = forward(fi, nullptr, dry);
+        if (!rc) rc = backward(fi, nullptr, nullptr, nullptr, dry);
+        tape = nullptr;
+        if (rc) return rc;
+        it = ws_peaks.emplace(key, dry.peak).first;
+    }
+    const size_t per = (size_t)B * T * 3 * cfg.image_size * cfg.image_size * sizeof(float);
+    const size_t need = ((it->second + 255) & ~(size_t)255) + 4096 + 8 * per;
+    if (need > ws_cap) {
+        if (win_cur >= 0) win_lost = true;
+        drop_window_graphs();
+        if (ws) VD_HIP(hipFree(ws));
+        ws = nullptr; ws_cap = 0; ws_B = ws_T = 0;
+        VD_HIP(hipMalloc(reinterpret_cast<void**>(&ws), need));
+        ws_cap = need;
+    }
+    ws_B = ws_T = 0;                       // the plain step recomputes its tail offsets on its next call
     return 0;
 }
 
@@ -1319,6 +1583,106 @@ int vd_posterior_from_xstart(vd_engine* e, int mode, int B, long long per, const
                      mode, eta, seed, offset, sample, xstart, mean, nullptr};
     pa.x0_given = xstart_in;
     return launch_posterior(pa, static_cast<hipStream_t>(stream));
+}
+
+
+// ---- use_gradient_method (gaussian_diffusion.py:264-271,350-364) ------------------------------------------------------
+long long vd_bwd_weights_bytes(vd_engine* e) { return e ? (long long)(e->packed_bwd_total * sizeof(float)) : -1; }
+
+int vd_set_bwd_weight_storage(vd_engine* e, void* buf, long long bytes, int on_host) {
+    VD_REQUIRE(e && buf, "null argument");
+    VD_REQUIRE(split_conv(), "use_gradient_method runs on the default arithmetic only (VD_MATH / VD_CONV_SPLIT unset)");
+    VD_REQUIRE(bytes >= (long long)(e->packed_bwd_total * sizeof(float)), "backward weight buffer too small");
+    e->wbuf_bwd = static_cast<float*>(buf);
+    e->wbuf_bwd_on_host = on_host != 0;
+    return 0;
+}
+
+// the backward-data image of one parameter (no-op for parameters the backward pass does not read)
+int vd_load_weight_bwd(vd_engine* e, const char* name, const float* host, long long numel) {
+    VD_REQUIRE(e && name && host, "null argument");
+    VD_REQUIRE(e->wbuf_bwd, "vd_set_bwd_weight_storage first");
+    auto it = e->pidx.find(name);
+    if (it == e->pidx.end()) { set_error(std::string("unexpected key in state_dict: ") + name); return -1; }
+    const Param& p = e->params[it->second];
+    if (p.kind_bwd < 0) return 0;
+    VD_REQUIRE((long long)p.numel == numel, "size mismatch");
+    std::vector<float> tmp((size_t)p.packed_bwd, 0.f);
+    const int O = (int)p.shape[0], I = (int)p.shape[1];
+    if (p.kind == PK_STEM) {                           // forward lin[o][k = tap*I + i]; backward matrix [k][o]
+        std::vector<float> lt((size_t)STEM_KPAD * O, 0.f);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int t = 0; t < 9; ++t) lt[(size_t)(t * I + i) * O + o] = host[((size_t)o * I + i) * 9 + t];
+        pack_linear_split(lt.data(), reinterpret_cast<unsigned short*>(tmp.data()), STEM_KPAD, O, STEM_KPAD, 0);
+    } else if (p.kind_bwd == PK_LINF) {                // W[O][I] -> W^T[I][O]
+        std::vector<float> wt((size_t)O * I);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i) wt[(size_t)i * O + o] = host[(size_t)o * I + i];
+        pack_linear_split(wt.data(), reinterpret_cast<unsigned short*>(tmp.data()), I, O, I, 0);
+    } else {                                           // w'[i][o][ky][kx] = w[o][i][2-ky][2-kx]
+        std::vector<float> wr((size_t)O * I * 9);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int t = 0; t < 9; ++t) wr[((size_t)i * O + o) * 9 + t] = host[((size_t)o * I + i) * 9 + (8 - t)];
+        if (p.kind_bwd == PK_CONV3W) {
+            pack_conv3_wino_s64(wr.data(), reinterpret_cast<unsigned short*>(tmp.data()), I, O);
+        } else {                                       // generic kernel: [tap][Cout' = I][Cin' = O]
+            for (int i = 0; i < I; ++i)
+                for (int o = 0; o < O; ++o)
+                    for (int t = 0; t < 9; ++t) tmp[((size_t)t * I + i) * O + o] = wr[((size_t)i * O + o) * 9 + t];
+        }
+    }
+    float* dst = e->wbuf_bwd + p.off_bwd;
+    if (e->wbuf_bwd_on_host) std::memcpy(dst, tmp.data(), p.packed_bwd * sizeof(float));
+    else VD_HIP(hipMemcpy(dst, tmp.data(), p.packed_bwd * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+__global__ void guided_masks_kernel(const float* obs, const float* lat, int n, float* obs_net, float* lat_net) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { obs_net[i] = 0.f; lat_net[i] = obs[i] + lat[i]; }      // gaussian_diffusion.py:268-271
+}
+
+// One guided step.  The network sees every frame as latent (obs_mask := 0, latent_mask := obs + latent); a sample of
+// x_{t-1} is drawn with `noise` from the unguided posterior, its squared distance to x_t_minus_1 on the observed frames is
+// back-propagated to x, and mean' = mean - 10 * alpha_t * grad / 2.  Outputs (any may be NULL): mean' , pred_xstart, grad,
+// and sample = mean' + [t != 0] * sigma_t * noise2 (p_sample's own draw, gaussian_diffusion.py:438-443).
+int vd_guided_step(vd_engine* e, int B, int T, const float* x, const float* obs, const float* lat, const float* km,
+                   const long long* fidx, const long long* t, int clip, const float* x_t_minus_1, const float* noise,
+                   const float* noise2, float* mean, float* xstart, float* grad, float* sample, void* stream) {
+    int rc = check_ready(e, B, T);
+    if (rc) return rc;
+    VD_REQUIRE(e->d_tab, "vd_set_schedule not called");
+    VD_REQUIRE(e->wbuf_bwd && !e->wbuf_bwd_on_host, "use_gradient_method: the backward-data weight image is not on the device (vd_set_bwd_weight_storage / vd_load_weight_bwd)");
+    VD_REQUIRE(x && obs && lat && km && fidx && t && x_t_minus_1 && noise && (sample == nullptr || noise2 != nullptr), "null tensor");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = e->ensure_ws_guided(B, T))) return rc;
+    const int N = B * T;
+    const size_t per = (size_t)T * 3 * e->cfg.image_size * e->cfg.image_size, tot = (size_t)B * per;
+    // tail of the workspace: t_model, the two masks, then eps, deps, dxd, mean0, dx_net, xstart0
+    char* tail = e->ws + e->ws_cap - (4096 + 8 * tot * sizeof(float));
+    float* tm = reinterpret_cast<float*>(tail);
+    float* obs_net = tm + 256; float* lat_net = obs_net + 256;
+    VD_REQUIRE(N <= 256 && B <= 256, "window of at most 256 frames");
+    float* buf = reinterpret_cast<float*>(tail + 4096);
+    float *eps = buf, *deps = buf + tot, *dxd = buf + 2 * tot, *mean0 = buf + 3 * tot, *dxn = buf + 4 * tot, *xs0 = buf + 5 * tot;
+    hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(t), e->d_tmap,
+                       e->rescale, B, e->num_timesteps, tm, e->d_err);
+    hipLaunchKernelGGL(guided_masks_kernel, dim3((N + 63) / 64), dim3(64), 0, st, obs, lat, N, obs_net, lat_net);
+    Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
+    Tape tp; e->tape = &tp;
+    FwdIn fi{B, T, x, x, obs_net, lat_net, km, tm, reinterpret_cast<const int64_t*>(fidx), 0, eps};
+    rc = e->forward(fi, st, ar);
+    if (!rc) {
+        GuidedArgs ga{x, eps, noise, x_t_minus_1, obs, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, T, (long)per, clip,
+                      deps, dxd, mean0, xstart ? xstart : xs0};
+        rc = launch_guided_grad(ga, st);
+        if (!rc) rc = e->backward(fi, deps, dxn, st, ar);
+        if (!rc) rc = launch_guided_final(ga, dxn, noise2, grad, mean, sample, st);
+    }
+    e->tape = nullptr;
+    return rc;
 }
 
 int vd_q_sample(vd_engine* e, int B, long long per, const float* x0, const long long* t, const float* noise, float* out,

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gn_final_affine_kernel(const double* __re
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
                                                               const float* __restrict__ film, int film_ld, int C,
-                                                              float* __restrict__ affA, float* __restrict__ affB) {
+                                                              float* __restrict__ affA, float* __restrict__ affB, float* __restrict__ mr_out) {
     __shared__ float mr[64];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int g = tid >> 3, l = tid & 7;
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void gn_final_affine_kernel(const double* __re
         if (var < 0) var = 0;
         mr[g * 2] = (float)mean;
         mr[g * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+        if (mr_out) { mr_out[((size_t)n * 32 + g) * 2] = mr[g * 2]; mr_out[((size_t)n * 32 + g) * 2 + 1] = mr[g * 2 + 1]; }
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -128,10 +129,10 @@ __global__ __launch_bounds__(256) void gn_final_affine_kernel(const double* __re
 
 int launch_gn_affine(const double* part0, int split0, int C0, const double* part1, int split1, double count,
                      const float* gamma, const float* beta, const float* film, int film_ld, int nfr, int C, float* affA,
-                     float* affB, hipStream_t s) {
+                     float* affB, hipStream_t s, float* mr_out) {
     VD_REQUIRE(part0 && (C0 == C || part1), "GroupNorm partial tables");
     hipLaunchKernelGGL(gn_final_affine_kernel, dim3(nfr), dim3(256), 0, s, part0, split0, C0, part1, split1, count, gamma,
-                       beta, film, film_ld, C, affA, affB);
+                       beta, film, film_ld, C, affA, affB, mr_out);
     VD_HIP(hipGetLastError());
     return 0;
 }

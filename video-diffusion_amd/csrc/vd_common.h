@@ -164,7 +164,7 @@ int gn_stats_split(int nfr, int HW, int C);
 // count = elements per group (HW * C/32)
 int launch_gn_affine(const double* part0, int split0, int C0, const double* part1, int split1, double count,
                      const float* gamma, const float* beta, const float* film, int film_ld, int nfr, int C, float* affA,
-                     float* affB, hipStream_t s);
+                     float* affB, hipStream_t s, float* mr_out = nullptr);      // mr_out: [nfr][32][2] mean, rstd (backward pass)
 // y = x*A[n][c] + B[n][c]  (materialised normalisation for the attention residual, unet.py:474,538)
 // y[n][p][0..C) = silu?(concat(src0, src1)[n][p][c] * A[n][c] + B[n][c])
 int launch_affine_act(const float* src0, const float* src1, int C0, int C, const float* affA, const float* affB, int nfr,
@@ -228,7 +228,47 @@ int launch_q_sample(const float* x0, const float* noise, const int64_t* t, const
 int launch_randn(float* out, long n, unsigned long long seed, unsigned long long offset, hipStream_t s);
 
 enum { TAB_SQRT_RECIP = 0, TAB_SQRT_RECIPM1, TAB_COEF1, TAB_COEF2, TAB_LOGVAR, TAB_ACP, TAB_ACP_PREV,
-       TAB_SQRT_ACP, TAB_SQRT_1M_ACP, TAB_POST_LOGVAR, TAB_LOG_1M_ACP, NTAB };
+       TAB_SQRT_ACP, TAB_SQRT_1M_ACP, TAB_POST_LOGVAR, TAB_LOG_1M_ACP, TAB_ALPHA, NTAB };
+
+// ---- backward-data pieces of `use_gradient_method` (backward.hip)
+struct GnBwdArgs {
+    const float* x0; const float* x1;   // the GroupNorm's input: one tensor or a virtual concat [N][HW][C0] | [N][HW][C-C0]
+    int C0, C;
+    const float* A; const float* B;     // the forward's folded affine [N][C]
+    const float* mr;                    // [N][32][2] group mean, rstd (gn_final_affine's optional output)
+    const float* dy;                    // [N][HW][C] gradient w.r.t. act(x*A + B)
+    int act;                            // 1: SiLU behind the affine
+    int N, HW;
+    float* dx0; float* dx1;             // gradients of the two sources, each assigned (acc = 0) or accumulated (acc = 1)
+    int acc0, acc1;
+    const float* extra;                 // [N][HW][C] added to the result (the ResBlock's skip path), or null
+    double* part;                       // [N][gn_bwd_split][C][2] workspace
+    float* K;                           // [N][32][2] workspace
+};
+int gn_bwd_split(int nfr, int HW, int C);
+int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s);
+int launch_gn_temporal_bwd(const float* x, const float* gamma, const float* dy, int B, int T, int HW, int C, int accumulate,
+                           float* dx, hipStream_t s);
+int launch_attn_temporal_bwd(const AttnTemporalArgs& a, const float* dout, float* dqkv, hipStream_t s);
+size_t attn_spatial_bwd_ws_floats(const AttnSpatialArgs& a);
+int launch_attn_spatial_bwd(const AttnSpatialArgs& a, const float* dout, float* dqkv, float* ws, hipStream_t s);
+int launch_zero_stuff2(const float* x, int nfr, int Ho, int Wo, int C, float* y, hipStream_t s);
+int launch_sumpool2(const float* x, int nfr, int Ho, int Wo, int C, int accumulate, float* y, hipStream_t s);
+int launch_add(const float* x, size_t n, int accumulate, float* y, hipStream_t s);
+int launch_out_conv_bwd(const float* deps, const float* w, int nfr, int H, int W, int C, int Cout, float* da, hipStream_t s);
+int launch_stem_col2im(const float* dcols, const float* obs, const float* lat, const float* km, int nfr, int H, int W, int Kpad, float* dx,
+                       hipStream_t s);
+struct GuidedArgs {
+    const float* x; const float* eps; const float* noise; const float* xtm1;   // [B][per]
+    const float* obs;                   // [B*T] the ORIGINAL observation mask (the network saw every frame as latent)
+    const int64_t* t; const float* tab; int num_timesteps;
+    int B, T; long per; int clip;
+    float* deps; float* dxd;            // d loss / d eps, and the direct part of d loss / d x
+    float* mean; float* xstart;         // the unguided posterior mean and the x_0 prediction
+};
+int launch_guided_grad(const GuidedArgs& a, hipStream_t s);
+int launch_guided_final(const GuidedArgs& a, const float* dx_net, const float* noise2, float* grad, float* mean_out, float* sample,
+                        hipStream_t s);
 
 // _vb_terms_bpd + the two MSEs of calc_bpd_loop_subsampled's loop body (gaussian_diffusion.py:750-790, 975-990), given eps
 struct VbArgs {

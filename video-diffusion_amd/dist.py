@@ -79,6 +79,12 @@ def share_weights(model, state_dict_fn, rank):
     broadcast_packed(buf, src=0)
     if rank != 0:
         model.mark_weights_received()     # state_dict() stays rank 0's: other ranks hold only the packed device image
+    # use_gradient_method: the backward-data image travels the same way (only when the option is on: enable_guidance())
+    bwd = model.guidance_weights() if hasattr(model, "guidance_weights") else None
+    if bwd is not None:
+        broadcast_packed(bwd, src=0)
+        if rank != 0:
+            model.mark_guidance_received()
     return model
 
 

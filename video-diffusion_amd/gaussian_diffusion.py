@@ -112,7 +112,7 @@ class GaussianDiffusion:
         rows = [self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
                 self.posterior_mean_coef2, self._model_log_variance(), self.alphas_cumprod,
                 self.alphas_cumprod_prev, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod,
-                self.posterior_log_variance_clipped, self.log_one_minus_alphas_cumprod]
+                self.posterior_log_variance_clipped, self.log_one_minus_alphas_cumprod, 1.0 - self.betas]
         return np.ascontiguousarray(np.stack(rows).astype(np.float32))
 
     def _timestep_map_and_scale(self):
@@ -139,12 +139,16 @@ class GaussianDiffusion:
     # -- per-step entry points ---------------------------------------------------------------------
     def _step(self, mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise,
               return_attn_weights=False, use_gradient_method=False):
-        if use_gradient_method:
-            raise NotImplementedError("use_gradient_method needs a UNet backward pass (out of scope, SURVEY.md 8f-4)")
         if return_attn_weights:
             raise NotImplementedError("return_attn_weights (wandb visualisation) is not supported")
         if model_kwargs is None:
             model_kwargs = {}
+        if use_gradient_method:
+            if mode != 0 or denoised_fn is not None:
+                raise NotImplementedError("use_gradient_method: p_sample without denoised_fn (the reference's ddim_sample "
+                                          "has no such option, gaussian_diffusion.py:597-634)")
+            out = self._guided(model, x, t, clip_denoised, model_kwargs, noise2=noise, want_sample=True)
+            return out["sample"], out["pred_xstart"]
         if denoised_fn is not None:
             return self._step_denoised_fn(mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise)
         model = self._bind(model)
@@ -178,6 +182,33 @@ class GaussianDiffusion:
         _lib.check(rc)
         return sample, xstart
 
+    def _guided(self, model, x, t, clip_denoised, model_kwargs, noise2=None, want_sample=False, _noise=None):
+        """p_mean_variance(..., use_gradient_method=True) (+ p_sample's noise add) on the engine: one taped forward, the
+        loss gradient, one backward-data pass (gaussian_diffusion.py:264-271,350-364).  Draw order as in the reference:
+        the noise of the x_{t-1} sample inside p_mean_variance first, p_sample's own noise second."""
+        base = self._bind(model)
+        base._require_guidance()
+        dev = base.device
+        xs = _f32(x, dev)
+        B, T = xs.shape[:2]
+        assert t.shape == (B,)
+        if t.device.type == "cpu" and B and (int(t.min()) < 0 or int(t.max()) >= self.num_timesteps):
+            raise IndexError(f"index {int(t.max())} is out of bounds for dimension 0 with size {self.num_timesteps}")
+        kw = base._pack_kwargs(xs, dict(model_kwargs, observed_frames="x_t"))      # obs_src is unused: every frame is latent
+        xtm1 = _f32(model_kwargs["x_t_minus_1"], dev)
+        noise = th.randn_like(xs) if _noise is None else _f32(_noise, dev)         # gaussian_diffusion.py:351
+        if want_sample:
+            noise2 = th.randn_like(xs) if noise2 is None else _f32(noise2, dev)     # gaussian_diffusion.py:438
+        tt = t.to(device=dev, dtype=th.int64).contiguous()
+        mean, xstart, grad = th.empty_like(xs), th.empty_like(xs), th.empty_like(xs)
+        sample = th.empty_like(xs) if want_sample else None
+        _lib.check(_lib.lib().vd_guided_step(
+            base._handle, B, T, _lib.ptr(xs), _lib.ptr(kw["obs_mask"]), _lib.ptr(kw["latent_mask"]), _lib.ptr(kw["kinda_marg_mask"]),
+            _lib.ptr(kw["frame_indices"]), _lib.ptr(tt), 1 if clip_denoised else 0, _lib.ptr(xtm1), _lib.ptr(noise),
+            _lib.ptr(noise2) if want_sample else None, _lib.ptr(mean), _lib.ptr(xstart), _lib.ptr(grad),
+            _lib.ptr(sample) if want_sample else None, _lib.current_stream()))
+        return {"mean": mean, "pred_xstart": xstart, "grad": grad, "sample": sample}
+
     def _step_denoised_fn(self, mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise):
         """process_xstart with a caller's function (gaussian_diffusion.py:319-324): `denoised_fn` sees the UNCLIPPED x_0
         prediction, the clamp and the posterior run on what it returns.  Two launches around a host callback instead of
@@ -209,10 +240,18 @@ class GaussianDiffusion:
                         return_attn_weights=False, use_gradient_method=False):
         """gaussian_diffusion.py:229-372 -> {'mean', 'variance', 'log_variance', 'pred_xstart', 'attn'} (+ 'eps', the raw
         model output, which the NLL loop reuses)."""
-        if use_gradient_method:
-            raise NotImplementedError("use_gradient_method needs a UNet backward pass (out of scope, SURVEY.md 8f-4)")
         if return_attn_weights:
             raise NotImplementedError("return_attn_weights (wandb visualisation) is not supported")
+        if use_gradient_method:
+            if denoised_fn is not None:
+                raise NotImplementedError("use_gradient_method with denoised_fn")
+            g = self._guided(model, x, t, clip_denoised, model_kwargs or {}, _noise=getattr(self, "_guidance_noise", None))
+            tt = t.to(device=g["mean"].device, dtype=th.int64)
+            variance = self.posterior_variance if self.model_var_type == ModelVarType.FIXED_SMALL \
+                else np.append(self.posterior_variance[1], self.betas[1:])
+            return {"mean": g["mean"], "variance": self._extract(variance, tt, g["mean"].shape),
+                    "log_variance": self._extract(self._model_log_variance(), tt, g["mean"].shape),
+                    "pred_xstart": g["pred_xstart"], "attn": None, "grad": g["grad"]}
         if denoised_fn is not None:
             out = self.p_mean_variance(model, x, t, clip_denoised=False, model_kwargs=model_kwargs)
             base = self._bind(model)

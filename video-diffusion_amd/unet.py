@@ -63,6 +63,7 @@ class CondMargVideoModel:
         self._specs = self._read_specs()
         self._host_sd = None          # CPU copy kept until the weights are on the device
         self._wbuf = None             # packed device weights (a torch tensor: broadcastable over RCCL)
+        self._wbuf_bwd = None         # backward-data image (use_gradient_method only: enable_guidance())
         self._bound_schedule = None
         self._pos_ch = _lib.lib().vd_pos_channels(h)
         self._use_frame_encoding = bool(use_frame_encoding)
@@ -138,6 +139,52 @@ class CondMargVideoModel:
         L = _lib.lib()
         for k, v in self._host_sd.items():
             _lib.check(L.vd_load_weight(self._handle, k.encode(), _lib.ptr(v), v.numel()))
+        if self._wbuf_bwd is not None:
+            self._upload_bwd()
+
+    def _upload_bwd(self):
+        L = _lib.lib()
+        for k, v in self._host_sd.items():
+            _lib.check(L.vd_load_weight_bwd(self._handle, k.encode(), _lib.ptr(v), v.numel()))
+        self._bwd_loaded = True
+
+    # -- use_gradient_method ------------------------------------------------------------------------
+    def enable_guidance(self):
+        """Allocate (and, when this process holds the checkpoint, fill) the backward-data weight image that
+        `p_sample(..., use_gradient_method=True)` needs: transposed linear weights and rotated transposed 3x3 kernels in
+        the forward kernels' layouts.  On ranks that only received the packed forward image, call this BEFORE
+        `dist.share_weights` so the second image is broadcast as well."""
+        if self._wbuf_bwd is None:
+            nbytes = _lib.lib().vd_bwd_weights_bytes(self._handle)
+            self._wbuf_bwd = th.zeros(max(nbytes // 4, 4), dtype=th.float32, device=self.device)
+            _lib.check(_lib.lib().vd_set_bwd_weight_storage(self._handle, _lib.ptr(self._wbuf_bwd), nbytes,
+                                                            0 if self.device.type == "cuda" else 1))
+            self._bwd_loaded = False
+            if self._host_sd is not None:
+                self._upload_bwd()
+        return self
+
+    def guidance_weights(self):
+        """The backward-data image (None unless enable_guidance() was called): a second buffer for the start-up broadcast."""
+        return self._wbuf_bwd
+
+    def mark_guidance_received(self):
+        self._bwd_loaded = True
+
+    def _require_guidance(self):
+        if self._wbuf_bwd is None:
+            if self._host_sd is None:
+                raise RuntimeError("use_gradient_method: this rank holds only the broadcast forward weights; call "
+                                   "model.enable_guidance() before dist.share_weights")
+            self.enable_guidance()
+        if self._wbuf_bwd.device.type != "cuda":
+            if self.device.type != "cuda":
+                raise RuntimeError("model.to('cuda') first: the HIP engine has no CPU path")
+            nbytes = _lib.lib().vd_bwd_weights_bytes(self._handle)
+            self._wbuf_bwd = self._wbuf_bwd.to(self.device)
+            _lib.check(_lib.lib().vd_set_bwd_weight_storage(self._handle, _lib.ptr(self._wbuf_bwd), nbytes, 0))
+        if not getattr(self, "_bwd_loaded", False):
+            raise RuntimeError("use_gradient_method: the backward-data weights were never filled")
 
     def _upload_freqs(self):
         # nn.py:99-101 evaluated with the reference's own float32 expression (bit-identical angles)
