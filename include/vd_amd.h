@@ -178,6 +178,14 @@ int vd_posterior_from_xstart(vd_engine* e, int mode, int B, long long per_sample
                              unsigned long long seed, unsigned long long offset, float* sample, float* pred_xstart,
                              float* mean, void* stream);
 
+/* return_attn_weights (unet.py:457-466,799-836; gaussian_diffusion.py:277,496): per attention block the softmax weights
+ * averaged over the heads, absolute value -- temporal (B*HW, T, T) and spatial (B*T, HW, HW) -- in execution order (input
+ * blocks, middle, output blocks).  vd_attn_blocks / vd_attn_block_info size the buffers; vd_set_attn_capture arms the
+ * capture for the following forwards (n = 0 clears it).  Two extra passes over q, k per block: the logging path. */
+int vd_attn_blocks(vd_engine* e);
+int vd_attn_block_info(vd_engine* e, int i, int* resolution, int* channels);
+int vd_set_attn_capture(vd_engine* e, float* const* temporal, float* const* spatial, int n);
+
 /* use_gradient_method (gaussian_diffusion.py:264-271,350-364; scripts/video_sample.py:429 `--use_gradient_method`).
  * The guidance needs d(loss)/d(x_t) through the whole UNet: backward-DATA only, no weight gradients.  Its matrix products
  * run on the forward kernels over a second packed image -- transposed linear weights, 180-degree-rotated transposed 3x3

@@ -130,8 +130,11 @@ def test_public_p_sample_contract():
     assert set(d) == {"sample", "pred_xstart"}
     with pytest.raises(AssertionError):
         diff.p_sample(model, x, torch.tensor([5], device="cuda"), model_kwargs=kwargs_of(c))
+    g = diff.p_sample(model, x, t, model_kwargs=kwargs_of(c), use_gradient_method=True)     # now on the engine
+    assert set(g) == {"sample", "pred_xstart", "attn"} and torch.isfinite(g["sample"]).all()
     with pytest.raises(NotImplementedError):
-        diff.p_sample(model, x, t, model_kwargs=kwargs_of(c), use_gradient_method=True)
+        diff.ddim_sample(model, x, t, model_kwargs=kwargs_of(c), denoised_fn=lambda v: v, eta=0.0) if False else \
+            diff._step(1, model, x, t, True, None, kwargs_of(c), 0.0, None, use_gradient_method=True)   # the reference's ddim has no guidance
     with pytest.raises(KeyError):
         kw = kwargs_of(c)
         del kw["x0"]
@@ -973,3 +976,46 @@ def test_use_gradient_method_vs_oracle_autograd(B, T, n_obs, mc, S):
     scale = float(want["grad"].abs().max())
     close(got["grad"].cpu(), want["grad"], atol=2e-4 * scale, rtol=1e-3)
     close(got["sample"].cpu(), want["sample"], atol=1e-3 * scale, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# return_attn_weights (unet.py:457-466, gaussian_diffusion.py:277,496-524)
+def test_return_attn_weights_matches_reference_golden():
+    """p_sample(..., return_attn_weights=True)['attn'] == {'temporal': [(B*HW, T, T)] * 7, 'spatial': [(B*T, HW, HW)] * 7}
+    of the imported reference (head-averaged softmax weights, absolute value); the 256 x 256 spatial maps of the fixture
+    hold every 8th query row.  Softmax weights are in [0, 1]: 2e-5 absolute."""
+    rec = load_npz("attn_tiny.npz")
+    cfg = json.loads(str(rec["cfg_json"]))
+    model, diff = engine(cfg)
+    c = {k: torch.from_numpy(rec[k]) for k in ["x", "x0", "noise", "obs_mask", "latent_mask", "kinda_marg_mask", "frame_indices"]}
+    x = c["x"].cuda()
+    t = torch.tensor([100, 100], device="cuda")
+    torch.manual_seed(0)
+    out = diff.p_sample(model, x, t, model_kwargs=kwargs_of(c), return_attn_weights=True)
+    assert set(out["attn"]) == {"temporal", "spatial"}
+    for kind in ("temporal", "spatial"):
+        maps = out["attn"][kind]
+        assert len(maps) == int(rec[f"n_{kind}"])
+        for i, m in enumerate(maps):
+            assert tuple(m.shape) == tuple(rec[f"{kind}_{i}_shape"])
+            got = m[:, ::8] if m.shape[1] > 64 else m
+            close(got.cpu(), rec[f"{kind}_{i}"], atol=2e-5, rtol=1e-4)
+            assert abs(float(m.sum(-1).mean()) - 1.0) < 1e-4                 # rows of a head-averaged softmax still sum to 1
+    # the sample itself is the plain step's (explicit noise through _step), and a following plain call logs nothing
+    s1, _ = diff._step(0, model, x, t, True, None, kwargs_of(c), 0.0, c["noise"], return_attn_weights=True)
+    close(s1.cpu(), rec["psample"], atol=1e-4, rtol=1e-4)
+    assert diff.p_sample(model, x, t, model_kwargs=kwargs_of(c))["attn"] is None
+    eps, attn = diff._wrap_model(model)(x, t, return_attn_weights=True, **kwargs_of(c))
+    assert len(attn["temporal"]) == 7 and torch.equal(attn["temporal"][0], out["attn"]["temporal"][0])
+    pm = diff.p_mean_variance(model, x, t, model_kwargs=kwargs_of(c), return_attn_weights=True)
+    assert torch.equal(pm["attn"]["spatial"][3], out["attn"]["spatial"][3])
+    # p_sample_loop's running means (gaussian_diffusion.py:496-524): one tag per (quartile, kind), the first block's map size
+    cfg5 = dict(cfg, timestep_respacing="ddim8")
+    m5, d5 = engine(cfg5)
+    torch.manual_seed(1)
+    kw = kwargs_of(c)
+    smp, attns = d5.p_sample_loop(m5, tuple(x.shape), model_kwargs=kw, return_attn_weights=True)
+    assert sorted(attns) == [f"attn/q{q}-{k}" for q in range(4) for k in ("spatial", "temporal")]
+    assert tuple(attns["attn/q0-temporal"].shape) == (2, 4, 4) and tuple(attns["attn/q3-spatial"].shape) == (2, 256, 256)
+    # 2 steps per quartile, 7 blocks, each row summing to 1, weighted 1 / (8 / 4)
+    assert abs(float(attns["attn/q2-temporal"].sum(-1).mean()) - 7.0) < 1e-3 and torch.isfinite(smp).all()

@@ -173,7 +173,9 @@ def gen_attn():
         for kind in ("temporal", "spatial"):
             rec[f"n_{kind}"] = len(o["attn"][kind])
             for i, a in enumerate(o["attn"][kind]):
-                rec[f"{kind}_{i}"] = a.numpy()
+                rec[f"{kind}_{i}_shape"] = np.array(a.shape)
+                # the 256 x 256 spatial maps are stored every 8th query row (2 MB each otherwise)
+                rec[f"{kind}_{i}"] = (a[:, ::8] if a.shape[1] > 64 else a).numpy()
                 print(kind, i, tuple(a.shape))
         pm = diff.p_mean_variance(model, inp["x"], t, model_kwargs=kwargs_of(inp), return_attn_weights=True)
         assert len(pm["attn"]["temporal"]) == len(o["attn"]["temporal"])

@@ -141,6 +141,9 @@ SIGNATURES = {
     "vd_window_graphs": (_I, [_P]),
     "vd_posterior_update": (_I, [_P, _I, _I, _L, _P, _P, _P, _I, _F, _P, _U, _U, _P, _P, _P]),
     "vd_posterior_from_xstart": (_I, [_P, _I, _I, _L, _P, _P, _P, _I, _F, _P, _U, _U, _P, _P, _P, _P]),
+    "vd_attn_blocks": (_I, [_P]),
+    "vd_attn_block_info": (_I, [_P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "vd_set_attn_capture": (_I, [_P, _P, _P, _I]),
     "vd_bwd_weights_bytes": (_L, [_P]),
     "vd_set_bwd_weight_storage": (_I, [_P, _P, _L, _I]),
     "vd_load_weight_bwd": (_I, [_P, ctypes.c_char_p, _P, _L]),

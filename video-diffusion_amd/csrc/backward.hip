@@ -632,3 +632,151 @@ int launch_guided_final(const GuidedArgs& a, const float* dx_net, const float* n
 }
 
 }  // namespace vd
+
+// ================================================================================================ return_attn_weights
+// The reference logs, per attention block, the softmax weights averaged over the heads (unet.py:457-466:
+// attn.view(B*D, -1, T, T).mean(dim=1).abs()): temporal blocks (B*HW, T, T), spatial blocks (B*T, HW, HW).  The attention
+// kernels of the step never materialise them (online softmax / registers), so a caller that asks for them gets these two
+// extra passes over q, k -- the visualisation path, not the sampling path.
+namespace vd {
+
+template <bool RPE>
+__global__ __launch_bounds__(256) void attn_temporal_weights_kernel(AttnTemporalArgs a, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = a.T, C = a.C, HW = a.HW, C3 = 3 * C, F = C / a.heads, FP = F + 4, TS = T + 1;
+    float* qs = smem;                    // [T][FP]
+    float* ks = qs + T * FP;
+    float* P = ks + T * FP;              // [T][TS] one head
+    float* M = P + T * TS;               // [T][TS] mean over heads
+    const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const size_t tok0 = (size_t)b * T * HW + p;
+    for (int i = tid; i < T * TS; i += 256) M[i] = 0.f;
+    for (int h = 0; h < a.heads; ++h) {
+        __syncthreads();
+        for (int i = tid; i < T * F; i += 256) {
+            const int t = i / F, f = i - t * F;
+            const float* r = a.qkv + (tok0 + (size_t)t * HW) * C3 + h * F + f;
+            qs[t * FP + f] = r[0] * a.scale; ks[t * FP + f] = r[C];
+        }
+        __syncthreads();
+        for (int pr = tid; pr < T * T; pr += 256) {
+            const int t = pr / T, s_ = pr - t * T;
+            const float* rk = RPE ? a.Rk + (((size_t)b * T + t) * T + s_) * C + h * F : nullptr;
+            const float* rq = RPE ? a.Rq + (((size_t)b * T + s_) * T + t) * C + h * F : nullptr;
+            float w = 0.f;
+            for (int f = 0; f < F; ++f) {
+                const float k = ks[s_ * FP + f];
+                w += qs[t * FP + f] * (k + (RPE ? rk[f] : 0.f)) + (RPE ? a.scale * k * rq[f] : 0.f);
+            }
+            bool masked = false;
+            if (a.mask) {
+                const float mt = a.mask[b * T + t], ms = a.mask[b * T + s_];
+                float allowed = mt * ms;
+                if (a.allow_pad) allowed += (1.f - mt) * (1.f - ms);
+                else if (t == s_) allowed = 1.f;
+                masked = allowed == 0.f;
+            }
+            P[t * TS + s_] = masked ? -INFINITY : w;
+        }
+        __syncthreads();
+        if (tid < T) {
+            float* r = P + tid * TS;
+            float mx = -INFINITY;
+            for (int s_ = 0; s_ < T; ++s_) mx = fmaxf(mx, r[s_]);
+            float sum = 0.f;
+            for (int s_ = 0; s_ < T; ++s_) { const float e = __expf(r[s_] - mx); r[s_] = e; sum += e; }
+            const float inv = 1.0f / sum;
+            for (int s_ = 0; s_ < T; ++s_) M[tid * TS + s_] += r[s_] * inv;
+        }
+    }
+    __syncthreads();
+    const float ih = 1.0f / (float)a.heads;
+    for (int i = tid; i < T * T; i += 256) out[((size_t)b * HW + p) * T * T + i] = fabsf(M[(i / T) * TS + (i % T)] * ih);
+}
+
+int launch_attn_temporal_weights(const AttnTemporalArgs& a, float* out, hipStream_t s) {
+    VD_REQUIRE(a.T >= 1 && a.T <= 32 && a.C % a.heads == 0, "temporal attention weights: shape");
+    const int F = a.C / a.heads;
+    const size_t lds = ((size_t)2 * a.T * (F + 4) + (size_t)2 * a.T * (a.T + 1)) * sizeof(float);
+    VD_REQUIRE(lds <= 150 * 1024, "temporal attention weights: head dim too large");
+    const dim3 grid(a.HW, a.B);
+    if (a.Rk) {
+        static size_t attr = 0;
+        if (lds > attr) { VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_weights_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = lds; }
+        hipLaunchKernelGGL(attn_temporal_weights_kernel<true>, grid, dim3(256), lds, s, a, out);
+    } else {
+        static size_t attr = 0;
+        if (lds > attr) { VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_weights_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = lds; }
+        hipLaunchKernelGGL(attn_temporal_weights_kernel<false>, grid, dim3(256), lds, s, a, out);
+    }
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// block = 16 queries of one frame; heads in sequence, score rows in LDS
+__global__ __launch_bounds__(256) void attn_spatial_weights_kernel(AttnSpatialArgs a, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = a.L, C = a.C, C3 = 3 * C, F = C / a.heads, FP = F + 4, LS = L + 1;
+    float* qs = smem;                    // [SQT][FP]
+    float* S = qs + SQT * FP;            // [SQT][LS]
+    float* M = S + SQT * LS;             // [SQT][LS]
+    const int n = blockIdx.y, t0 = blockIdx.x * SQT, tid = threadIdx.x;
+    const size_t tok0 = (size_t)n * L;
+    for (int i = tid; i < SQT * LS; i += 256) M[i] = 0.f;
+    for (int h = 0; h < a.heads; ++h) {
+        __syncthreads();
+        for (int i = tid; i < SQT * F; i += 256) {
+            const int t = i / F, f = i - t * F, tt = min(t0 + t, L - 1);
+            qs[t * FP + f] = a.qkv[(tok0 + tt) * C3 + h * F + f] * a.scale;
+        }
+        __syncthreads();
+        for (int s_ = tid; s_ < L; s_ += 256) {
+            float sc[SQT];
+#pragma unroll
+            for (int t = 0; t < SQT; ++t) sc[t] = 0.f;
+            const float* kr = a.qkv + (tok0 + s_) * C3 + C + h * F;
+            for (int f = 0; f < F; f += 4) {
+                const f32x4 k = *reinterpret_cast<const f32x4*>(kr + f);
+#pragma unroll
+                for (int t = 0; t < SQT; ++t) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(qs + t * FP + f);
+                    sc[t] += q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < SQT; ++t) S[t * LS + s_] = sc[t];
+        }
+        __syncthreads();
+        const int t = tid >> 4, l = tid & 15;
+        float mx = -INFINITY;
+        for (int s_ = l; s_ < L; s_ += 16) mx = fmaxf(mx, S[t * LS + s_]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float sum = 0.f;
+        for (int s_ = l; s_ < L; s_ += 16) { const float e = __expf(S[t * LS + s_] - mx); S[t * LS + s_] = e; sum += e; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float inv = 1.0f / sum;
+        for (int s_ = l; s_ < L; s_ += 16) M[t * LS + s_] += S[t * LS + s_] * inv;
+    }
+    __syncthreads();
+    const float ih = 1.0f / (float)a.heads;
+    for (int i = tid; i < SQT * L; i += 256) {
+        const int t = i / L, s_ = i - t * L;
+        if (t0 + t < L) out[((size_t)n * L + t0 + t) * L + s_] = fabsf(M[t * LS + s_] * ih);
+    }
+}
+
+int launch_attn_spatial_weights(const AttnSpatialArgs& a, float* out, hipStream_t s) {
+    const int F = a.C / a.heads;
+    VD_REQUIRE(a.C % a.heads == 0 && F % 4 == 0 && a.L <= 4096, "spatial attention weights: shape");
+    const size_t lds = ((size_t)SQT * (F + 4) + (size_t)2 * SQT * (a.L + 1)) * sizeof(float);
+    VD_REQUIRE(lds <= 150 * 1024, "spatial attention weights: sequence too long");
+    static size_t attr = 0;
+    if (lds > attr) { VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_spatial_weights_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = lds; }
+    hipLaunchKernelGGL(attn_spatial_weights_kernel, dim3((a.L + SQT - 1) / SQT, a.nfr), dim3(256), lds, s, a, out);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vd

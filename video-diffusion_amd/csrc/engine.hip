@@ -223,6 +223,9 @@ struct vd_engine {
     // ---- use_gradient_method: second packed image (backward-data weights) + the tape of the guided step's forward
     float* wbuf_bwd = nullptr; bool wbuf_bwd_on_host = false; size_t packed_bwd_total = 0;
     Tape* tape = nullptr;
+    // return_attn_weights: device buffers for the next forward, one pair per attention block in execution order
+    std::vector<float*> attn_cap_t, attn_cap_s;
+    int attn_seq = 0;
     int* d_err = nullptr;                            // sticky device flags: bit 0 = timestep index out of range
     int device = -1;
     double* d_part = nullptr; size_t part_cap = 0;   // NLL partial sums
@@ -721,6 +724,8 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
           ProfScope ps(PC_ATTN_TEMPORAL, 10.0 * B * HW * cfg.num_heads * T * T * Fd, 16.0 * tok * C + 12.0 * rrows * C, st);
           rc = launch_attn_temporal(ta, st); }
         if (rc) return rc;
+        if (!attn_cap_t.empty() && attn_seq < (int)attn_cap_t.size() && attn_cap_t[attn_seq] &&
+            (rc = launch_attn_temporal_weights(ta, attn_cap_t[attn_seq], st))) return rc;
         // proj_out + residual on the NORMALISED activations (unet.py:537-538)
         if ((rc = linear(o, (int)tok, C, 0, 0, C, W(a.tp.projw), W(a.tp.projb), 0, xn, xt, st, &xt_t))) return rc;
     }
@@ -740,9 +745,12 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
         AttnSpatialArgs sa{qkv2, o2, N, HW, C, cfg.num_heads, scale};
         { ProfScope ps(PC_ATTN_SPATIAL, 4.0 * N * (double)HW * HW * C, 16.0 * tok * C, st); rc = launch_attn_spatial(sa, st); }
         if (rc) return rc;
+        if (!attn_cap_s.empty() && attn_seq < (int)attn_cap_s.size() && attn_cap_s[attn_seq] &&
+            (rc = launch_attn_spatial_weights(sa, attn_cap_s[attn_seq], st))) return rc;
         if ((rc = linear(o2, (int)tok, C, 0, 0, C, W(a.sp.projw), W(a.sp.projb), 0, xn2, xs, st, &xs_t))) return rc;
     }
     *out = xs_t;
+    if (!ar.dry) ++attn_seq;
     if (tape) {
         tape->ops.push_back(TapeOp{2, (int)tape->attn.size()});
         tape->attn.push_back(TapeAttn{(int)(&a - attn.data()), x, B, T, xn, qkv, R[0], R[1], R[2], o, xt, A, Bf, mrs, xn2, qkv2, o2, xs, amask});
@@ -781,6 +789,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
             if ((rc = launch_sinus_embed(ftv, N, pos_ch, d_freq_frame, femb, st))) return rc;
         }
     }
+    attn_seq = 0;
     std::vector<Tens> hs;
     Tens h{x8, STEM_KPAD, S};
     auto run = [&](const std::vector<Layer>& blk, Tens in0, const Tens* in1, Tens* outp) -> int {
@@ -1585,6 +1594,30 @@ int vd_posterior_from_xstart(vd_engine* e, int mode, int B, long long per, const
     return launch_posterior(pa, static_cast<hipStream_t>(stream));
 }
 
+
+// ---- return_attn_weights (unet.py:457-466, 799-836) ---------------------------------------------------------------------
+int vd_attn_blocks(vd_engine* e) { return e ? (int)e->attn.size() : -1; }
+
+// resolution (pixels per side) and channels of attention block i, in execution order (input blocks, middle, output blocks)
+int vd_attn_block_info(vd_engine* e, int i, int* res, int* channels) {
+    VD_REQUIRE(e && i >= 0 && i < (int)e->attn.size() && res && channels, "attention block index");
+    int k = 0;
+    auto scan = [&](const std::vector<Layer>& blk, int r) { for (const Layer& L : blk) if (L.type == 2 && k++ == i) { *res = r; *channels = e->attn[L.idx].C; return true; } return false; };
+    int r = e->cfg.image_size;
+    for (auto& blk : e->input_blocks) { if (scan(blk, r)) return 0; for (const Layer& L : blk) if (L.type == 3) r /= 2; }
+    if (scan(e->middle, r)) return 0;
+    for (auto& blk : e->output_blocks) { if (scan(blk, r)) return 0; for (const Layer& L : blk) if (L.type == 4) r *= 2; }
+    set_error("attention block not found"); return -1;
+}
+
+// Arm (n > 0) or clear (n = 0) the capture: the next forwards write block i's head-averaged softmax weights to
+// temporal[i] ([B*HW][T][T]) and spatial[i] ([B*T][HW][HW]); a NULL entry skips that block.
+int vd_set_attn_capture(vd_engine* e, float* const* temporal, float* const* spatial, int n) {
+    VD_REQUIRE(e && n >= 0 && n <= (int)e->attn.size() && (n == 0 || (temporal && spatial)), "attention capture");
+    e->attn_cap_t.assign(temporal, temporal + n);
+    e->attn_cap_s.assign(spatial, spatial + n);
+    return 0;
+}
 
 // ---- use_gradient_method (gaussian_diffusion.py:264-271,350-364) ------------------------------------------------------
 long long vd_bwd_weights_bytes(vd_engine* e) { return e ? (long long)(e->packed_bwd_total * sizeof(float)) : -1; }

@@ -26,6 +26,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef VD_GS_PF3
 #define VD_GS_PF3 1        // 0: the A operand one chunk ahead for every tile (A/B)
 #endif
+#ifndef VD_GS_RING6
+#define VD_GS_RING6 1      // 0: three weight slots for the 64x64 tile too (A/B)
+#endif
 #ifndef VD_GS_SKIP
 #define VD_GS_SKIP 0       // kernel-experiment builds: bit 0 no weight loads, 1 no A staging, 2 no split VALU (timing only)
 #endif
@@ -45,7 +48,10 @@ __device__ __forceinline__ void split3(f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& 
 template <int BM, int BN, bool ACT, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
-    constexpr int RING = NI >= 3 ? 2 : 3;                                  // weight ring slots (k-steps ahead = RING - 1): 256 registers per wave
+    // weight ring slots (k-steps ahead = RING - 1): 2 for the 128x192 tile (256 registers per wave), 3 for the others -- and 6
+    // for the 64x64 tile: its k-step is 6 MFMAs (0.1 us), its launches are the small-M ones (one block per CU, nothing else
+    // to hide behind), and two steps ahead left every weight fragment a full L2 round trip short
+    constexpr int RING = NI >= 3 ? 2 : (BM == 64 && BN == 64 && VD_GS_RING6) ? 6 : 3;
     // A-operand prefetch distance in chunks.  A chunk of a 64-row tile is 12 .. 24 MFMAs (0.2 .. 0.4 us): one chunk ahead, the
     // split + store of the next chunk waits a full memory round trip every chunk, and a small-M launch (a B = 1 shard: 60 of
     // them per step) costs ~1 us per chunk whatever its size.  The small tiles have the registers for three chunks in flight.
@@ -183,8 +189,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     const int nks = 2 * nchunk;
     a_prefetch(0, 0);
     if constexpr (PF == 3) { a_prefetch(min(1, nchunk - 1), 1); a_prefetch(min(2, nchunk - 1), 2); }
-    b_load(0, 0);
-    if constexpr (RING == 3) b_load(1, min(1, nks - 1));
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r) b_load(r, min(r, nks - 1));
     a_store(smem_c, 0);
     __syncthreads();
     a_frags(0, smem_c, 0);
@@ -220,8 +226,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
                 // PF == 3: chunk0 is a multiple of 3, so register slot chunk % 3 == cc; it held this chunk (already in LDS)
                 const int nxt = min(chunk + PF, nchunk - 1);
                 if (!(VD_GS_SKIP & 2)) a_prefetch(nxt, PF == 3 ? cc : 0);
-                kstep(chunk, 0, RING == 3 ? (2 * cc) % 3 : 0, 0);
-                kstep(chunk, 1, RING == 3 ? (2 * cc + 1) % 3 : 1, 1);
+                kstep(chunk, 0, RING == 2 ? 0 : (2 * cc) % RING, 0);
+                kstep(chunk, 1, RING == 2 ? 1 : (2 * cc + 1) % RING, 1);
                 if (!(VD_GS_SKIP & 6)) a_store(smem_c + ((chunk + 1) & 1) * ABUF, PF == 3 ? (cc + 1) % 3 : 0);
                 __syncthreads();
                 a_frags(0, smem_c + ((chunk + 1) & 1) * ABUF, 0);

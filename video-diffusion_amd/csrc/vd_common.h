@@ -258,6 +258,9 @@ int launch_add(const float* x, size_t n, int accumulate, float* y, hipStream_t s
 int launch_out_conv_bwd(const float* deps, const float* w, int nfr, int H, int W, int C, int Cout, float* da, hipStream_t s);
 int launch_stem_col2im(const float* dcols, const float* obs, const float* lat, const float* km, int nfr, int H, int W, int Kpad, float* dx,
                        hipStream_t s);
+// return_attn_weights (unet.py:457-466): softmax weights averaged over the heads, |.|; temporal [B*HW][T][T], spatial [nfr][L][L]
+int launch_attn_temporal_weights(const AttnTemporalArgs& a, float* out, hipStream_t s);
+int launch_attn_spatial_weights(const AttnSpatialArgs& a, float* out, hipStream_t s);
 struct GuidedArgs {
     const float* x; const float* eps; const float* noise; const float* xtm1;   // [B][per]
     const float* obs;                   // [B*T] the ORIGINAL observation mask (the network saw every frame as latent)

@@ -139,10 +139,10 @@ class GaussianDiffusion:
     # -- per-step entry points ---------------------------------------------------------------------
     def _step(self, mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise,
               return_attn_weights=False, use_gradient_method=False):
-        if return_attn_weights:
-            raise NotImplementedError("return_attn_weights (wandb visualisation) is not supported")
         if model_kwargs is None:
             model_kwargs = {}
+        if return_attn_weights and (use_gradient_method or denoised_fn is not None):
+            raise NotImplementedError("return_attn_weights together with use_gradient_method / denoised_fn")
         if use_gradient_method:
             if mode != 0 or denoised_fn is not None:
                 raise NotImplementedError("use_gradient_method: p_sample without denoised_fn (the reference's ddim_sample "
@@ -173,12 +173,17 @@ class GaussianDiffusion:
         common = (model._handle, B, T, _lib.ptr(xs), _lib.ptr(kw["obs_src"]), _lib.ptr(kw["obs_mask"]),
                   _lib.ptr(kw["latent_mask"]), _lib.ptr(kw["kinda_marg_mask"]), _lib.ptr(kw["frame_indices"]),
                   _lib.ptr(tt), kw["obs_mode"], 1 if clip_denoised else 0)
-        if mode == 0:
-            rc = L.vd_p_sample(*common, _lib.ptr(noise), 0, 0, _lib.ptr(sample), _lib.ptr(xstart), None,
-                               _lib.current_stream())
-        else:
-            rc = L.vd_ddim_sample(*common, float(eta), _lib.ptr(noise), 0, 0, _lib.ptr(sample), _lib.ptr(xstart), None,
-                                  _lib.current_stream())
+        self._last_attn = model._attn_capture(B, T) if return_attn_weights else None     # unet.py:457-466 per block
+        try:
+            if mode == 0:
+                rc = L.vd_p_sample(*common, _lib.ptr(noise), 0, 0, _lib.ptr(sample), _lib.ptr(xstart), None,
+                                   _lib.current_stream())
+            else:
+                rc = L.vd_ddim_sample(*common, float(eta), _lib.ptr(noise), 0, 0, _lib.ptr(sample), _lib.ptr(xstart), None,
+                                      _lib.current_stream())
+        finally:
+            if return_attn_weights:
+                model._attn_release()
         _lib.check(rc)
         return sample, xstart
 
@@ -240,8 +245,8 @@ class GaussianDiffusion:
                         return_attn_weights=False, use_gradient_method=False):
         """gaussian_diffusion.py:229-372 -> {'mean', 'variance', 'log_variance', 'pred_xstart', 'attn'} (+ 'eps', the raw
         model output, which the NLL loop reuses)."""
-        if return_attn_weights:
-            raise NotImplementedError("return_attn_weights (wandb visualisation) is not supported")
+        if return_attn_weights and (use_gradient_method or denoised_fn is not None):
+            raise NotImplementedError("return_attn_weights together with use_gradient_method / denoised_fn")
         if use_gradient_method:
             if denoised_fn is not None:
                 raise NotImplementedError("use_gradient_method with denoised_fn")
@@ -274,15 +279,21 @@ class GaussianDiffusion:
         kw = model._pack_kwargs(xs, model_kwargs or {})
         tt = t.to(device=dev, dtype=th.int64).contiguous()
         mean, xstart, eps = th.empty_like(xs), th.empty_like(xs), th.empty_like(xs)
-        _lib.check(_lib.lib().vd_p_mean_variance(
-            model._handle, B, xs.shape[1], _lib.ptr(xs), _lib.ptr(kw["obs_src"]), _lib.ptr(kw["obs_mask"]),
-            _lib.ptr(kw["latent_mask"]), _lib.ptr(kw["kinda_marg_mask"]), _lib.ptr(kw["frame_indices"]), _lib.ptr(tt),
-            kw["obs_mode"], 1 if clip_denoised else 0, _lib.ptr(mean), _lib.ptr(xstart), _lib.ptr(eps), _lib.current_stream()))
+        attn = model._attn_capture(B, xs.shape[1]) if return_attn_weights else None
+        try:
+            rc = _lib.lib().vd_p_mean_variance(
+                model._handle, B, xs.shape[1], _lib.ptr(xs), _lib.ptr(kw["obs_src"]), _lib.ptr(kw["obs_mask"]),
+                _lib.ptr(kw["latent_mask"]), _lib.ptr(kw["kinda_marg_mask"]), _lib.ptr(kw["frame_indices"]), _lib.ptr(tt),
+                kw["obs_mode"], 1 if clip_denoised else 0, _lib.ptr(mean), _lib.ptr(xstart), _lib.ptr(eps), _lib.current_stream())
+        finally:
+            if attn is not None:
+                model._attn_release()
+        _lib.check(rc)
         logvar = self._model_log_variance()
         variance = self.posterior_variance if self.model_var_type == ModelVarType.FIXED_SMALL \
             else np.append(self.posterior_variance[1], self.betas[1:])             # gaussian_diffusion.py:299-317
         return {"mean": mean, "variance": self._extract(variance, tt, xs.shape),
-                "log_variance": self._extract(logvar, tt, xs.shape), "pred_xstart": xstart, "attn": None, "eps": eps}
+                "log_variance": self._extract(logvar, tt, xs.shape), "pred_xstart": xstart, "attn": attn, "eps": eps}
 
     def q_posterior_mean_variance(self, x_start, x_t, t):
         """gaussian_diffusion.py:208-227 (host composition of schedule rows; the samplers fuse it in posterior_kernel)."""
@@ -366,7 +377,7 @@ class GaussianDiffusion:
         """gaussian_diffusion.py:403-448.  `x` is not modified; returns fresh tensors."""
         sample, xstart = self._step(0, model, x, t, clip_denoised, denoised_fn, model_kwargs, 0.0, None,
                                     return_attn_weights, use_gradient_method)
-        return {"sample": sample, "pred_xstart": xstart, "attn": None}
+        return {"sample": sample, "pred_xstart": xstart, "attn": self._last_attn if return_attn_weights else None}
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
         """gaussian_diffusion.py:597-634."""
@@ -403,15 +414,34 @@ class GaussianDiffusion:
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                       latent_mask=None, device=None, progress=False, return_attn_weights=False,
                       use_gradient_method=False):
-        """gaussian_diffusion.py:450-526: returns (sample, attns) with attns == {} (no attention logging)."""
-        final = None
-        for sample in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
-                                                     denoised_fn=denoised_fn, model_kwargs=model_kwargs,
-                                                     latent_mask=latent_mask, device=device, progress=progress,
-                                                     return_attn_weights=return_attn_weights,
-                                                     use_gradient_method=use_gradient_method):
-            final = sample
-        return final["sample"], {}
+        """gaussian_diffusion.py:450-526: returns (sample, attns).  With return_attn_weights, attns holds one running mean
+        per (quartile of the schedule, attention type): 'attn/q<k>-temporal' / 'attn/q<k>-spatial' (:496-524) -- each
+        block's head-averaged weights averaged over the non-attended axis, spatial maps resized (nearest) to the first
+        block's size and renormalised to keep their mean, every step weighted 1 / (num_timesteps / 4)."""
+        final, attns = None, {}
+        steps = self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                               model_kwargs=model_kwargs, latent_mask=latent_mask, device=device,
+                                               progress=progress, return_attn_weights=return_attn_weights,
+                                               use_gradient_method=use_gradient_method)
+        for k, out in enumerate(steps):
+            final = out
+            if not return_attn_weights:
+                continue
+            quartile = (4 * (self.num_timesteps - k - 1)) // self.num_timesteps
+            for kind, maps in out["attn"].items():
+                if not maps:
+                    continue
+                tag = f"attn/q{quartile}-{kind}"
+                target = maps[0][0].shape                              # the first block's map size (largest resolution)
+                acc = attns.get(tag, 0)
+                for m in maps:
+                    per_item = m.view(shape[0], m.shape[0] // shape[0], *m.shape[1:]).mean(dim=1)
+                    if "temporal" not in kind:
+                        r = th.nn.functional.interpolate(per_item.unsqueeze(0), size=target, mode="nearest").squeeze(0)
+                        per_item = r / r.mean() * per_item.mean()
+                    acc = acc + per_item / (self.num_timesteps / 4)
+                attns[tag] = acc
+        return final["sample"], attns
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
                                   model_kwargs=None, latent_mask=None, device=None, progress=False,

@@ -293,10 +293,29 @@ class CondMargVideoModel:
                     kinda_marg_mask=f32(kw["kinda_marg_mask"]).reshape(B * T),
                     frame_indices=fi.to(device=dev, dtype=th.int64).contiguous(), obs_mode=_OBS_MODES[mode])
 
+    # -- return_attn_weights ---------------------------------------------------------------------------
+    def _attn_capture(self, B, T):
+        """Arm the engine's attention-weight capture for the next forward and return the reference's dict
+        {'temporal': [(B*HW, T, T) per block], 'spatial': [(B*T, HW, HW) per block]} (unet.py:457-466,799-836)."""
+        L = _lib.lib()
+        n = L.vd_attn_blocks(self._handle)
+        temporal, spatial = [], []
+        res, ch = ctypes.c_int(), ctypes.c_int()
+        for i in range(n):
+            _lib.check(L.vd_attn_block_info(self._handle, i, ctypes.byref(res), ctypes.byref(ch)))
+            hw = res.value * res.value
+            temporal.append(th.empty(B * hw, T, T, dtype=th.float32, device=self.device))
+            spatial.append(th.empty(B * T, hw, hw, dtype=th.float32, device=self.device))
+        pt = (ctypes.c_void_p * n)(*[v.data_ptr() for v in temporal])
+        ps = (ctypes.c_void_p * n)(*[v.data_ptr() for v in spatial])
+        _lib.check(L.vd_set_attn_capture(self._handle, pt, ps, n))
+        return {"temporal": temporal, "spatial": spatial}
+
+    def _attn_release(self):
+        _lib.check(_lib.lib().vd_set_attn_capture(self._handle, None, None, 0))
+
     def __call__(self, x, timesteps, return_attn_weights=False, **kwargs):
-        """model(x, timesteps, **model_kwargs) -> (eps, None)   (unet.py:949-1026)."""
-        if return_attn_weights:
-            raise NotImplementedError("return_attn_weights")
+        """model(x, timesteps, **model_kwargs) -> (eps, attn)   (unet.py:949-1026); attn is None unless asked for."""
         if self._wbuf is None or self._wbuf.device.type != "cuda":
             raise RuntimeError("model.to('cuda') first: the HIP engine has no CPU path")
         B, T, C, H, W = x.shape
@@ -305,10 +324,15 @@ class CondMargVideoModel:
         kw = self._pack_kwargs(xs, kwargs)
         tm = timesteps.to(device=self.device, dtype=th.float32).reshape(B).contiguous()
         eps = th.empty_like(xs)
-        _lib.check(_lib.lib().vd_unet_forward(self._handle, B, T, _lib.ptr(xs), _lib.ptr(kw["obs_src"]),
-                                              _lib.ptr(kw["obs_mask"]), _lib.ptr(kw["latent_mask"]),
-                                              _lib.ptr(kw["kinda_marg_mask"]), _lib.ptr(kw["frame_indices"]),
-                                              _lib.ptr(tm), kw["obs_mode"], _lib.ptr(eps), _lib.current_stream()))
-        return eps, None
+        attn = self._attn_capture(B, T) if return_attn_weights else None
+        try:
+            _lib.check(_lib.lib().vd_unet_forward(self._handle, B, T, _lib.ptr(xs), _lib.ptr(kw["obs_src"]),
+                                                  _lib.ptr(kw["obs_mask"]), _lib.ptr(kw["latent_mask"]),
+                                                  _lib.ptr(kw["kinda_marg_mask"]), _lib.ptr(kw["frame_indices"]),
+                                                  _lib.ptr(tm), kw["obs_mode"], _lib.ptr(eps), _lib.current_stream()))
+        finally:
+            if attn is not None:
+                self._attn_release()
+        return eps, attn
 
     forward = __call__
