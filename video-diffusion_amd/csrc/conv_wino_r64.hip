@@ -43,7 +43,9 @@ template <bool TF4> struct R64G {
 };
 namespace r64 {
 constexpr int NB = 4;                       // patch buffers
-template <bool TF4> constexpr int lds_bytes() { return NB * R64G<TF4>::XBUF; }   // 98304 | 131072; the Z image (64 KB) overlays it
+// 4 patch buffers (98304 | 131072 bytes; the Z image, 64 KB, overlays them) + one more that only ever receives the requests
+// past the item's last chunk (see x_dma): 122880 | 163840
+template <bool TF4> constexpr int lds_bytes() { return (NB + 1) * R64G<TF4>::XBUF; }
 }  // namespace r64
 
 #ifdef VD_WINO_TIMING
@@ -125,12 +127,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     }
     const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    // A request past the item's last chunk must not land in the output transform's Z image.  It is NOT skipped by a branch:
+    // hipcc's s_waitcnt insertion merges the two paths of a conditional request to the one with FEWER loads in flight, i.e.
+    // every wait for a weight fragment behind it becomes a wait for the patch itself (the loop ran `vmcnt(0)` three
+    // positions behind each request pair: the HBM round trip of the patch, every second chunk).  The request always issues;
+    // when it is late it goes through a descriptor of zero records (no memory access, zeros) into the spare fifth buffer.
+    const auto xnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, 0, 0x00020000);
     auto x_dma = [&](int chunk) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if ((VD_R64_SKIP & 16) || chunk >= nchunk) return;           // a late request would land in the output transform's Z image
+        if (VD_R64_SKIP & 16) return;
+        const bool live = chunk < nchunk;
+        const int bufi = live ? (chunk & (NB - 1)) : NB;
 #pragma unroll
         for (int e = 0; e < NX; ++e)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr)(lds + (chunk & (NB - 1)) * XBUF + e * 4096 + wi * 1024), 16, xo[e], chunk * 64, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? xsrc : xnull, (lds_ptr)(lds + bufi * XBUF + e * 4096 + wi * 1024), 16, xo[e], chunk * 64, 0, 0);
 #endif
     };
 
@@ -163,7 +173,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     auto t_fma = [&](int c, int h) {
         if (VD_R64_SKIP & 2) return;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[c][4 * h + e] = stx[h][e] + tsg * sts[h][e];
+        for (int e = 0; e < 4; ++e)      // plain v_fma_f32: hipcc pairs these into v_pk_fma_f32, which does not co-issue with the bf16 MFMA
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t[c][4 * h + e]) : "v"(tsg), "v"(sts[h][e]), "v"(stx[h][e]));
     };
     auto t_comb = [&](int j, int h) {                                // column combination of position j, channels 4h .. 4h+3
         if (VD_R64_SKIP & 2) return;
@@ -263,7 +274,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     // barrier sits in front of position 3 of the even groups (c, 0): it hands over patches c + 1, c + 2 and frees two buffers.
     constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
     constexpr int ORD[4] = {0, 2, 1, 3};
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
+    // two chunks per trip: the chunk's parity (which decides the barrier and the patch requests) is a compile-time constant,
+    // so the wait counts hipcc derives for the weight fragments are exact on every path
+    for (int chunk0 = 0; chunk0 < nchunk; chunk0 += 2) {
+#pragma unroll
+      for (int cpar = 0; cpar < 2; ++cpar) {
+        const int chunk = chunk0 + cpar;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
                         // one barrier per TWO chunks (the channel chunks come in pairs: Cin % 32 == 0): at an even chunk the
                         // patches chunk + 1 and chunk + 2 (requested two chunks ago) have landed in every wave, and the buffers
                         // of chunk - 1 and chunk are free for chunk + 3 and chunk + 4 (requested five positions on, see below)
-                        if ((chunk & 1) == 0) {
+                        if (cpar == 0) {
                             asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #if !VD_R64_DMA_LATE
                             x_dma(chunk + 3);
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #if VD_R64_DMA_LATE
                     // the two patches are requested BEHIND this chunk pair's last weight loads: loads return in order, and a
                     // weight fragment requested behind a patch waits for it
-                    if (m == 0 && j == 0 && k == 4 && (chunk & 1) == 1) { x_dma(chunk + 2); x_dma(chunk + 3); }
+                    if (m == 0 && j == 0 && k == 4 && cpar == 1) { x_dma(chunk + 2); x_dma(chunk + 3); }
 #endif
                     if (!(VD_R64_SKIP & 64))
                         acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][PA[q]], bfr[j][n][PB[q]], acc[m][j][n], 0, 0, 0);
@@ -323,6 +339,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
                 }
             }
         }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
