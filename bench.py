@@ -356,9 +356,18 @@ def main():
             headline = (S, args.batch, T, args.num_res_blocks) == (64, 8, 16, 2) and B == 8
             if os.path.exists(pmc) and headline:
                 rec = json.load(open(pmc))
-                if rec.get("kernel") == name:
+                # the counters belong to the kernel source they were collected on: a kernel edited since then carries no
+                # traffic figure until tools/profile_bench.sh + tools/make_pmc_dominant.py have been re-run
+                import hashlib
+                srcs = rec.get("kernel_sources", {})
+                fresh = bool(srcs) and all(
+                    os.path.exists(os.path.join(ROOT, f)) and hashlib.sha1(open(os.path.join(ROOT, f), "rb").read()).hexdigest() == h
+                    for f, h in srcs.items())
+                if rec.get("kernel") == name and fresh:
                     traffic = round(rec["hbm_bytes_per_launch"])
-                    traffic_source = "profiles/pmc_dominant.json (rocprofv3 --pmc passes of this workload, not this run)"
+                    traffic_source = "profiles/pmc_dominant.json (rocprofv3 --pmc passes of this workload on this kernel source, not this run)"
+                elif rec.get("kernel") == name:
+                    traffic_source = "profiles/pmc_dominant.json is stale (kernel source changed since the PMC passes): traffic withheld"
             split_conv = name in ("conv3x3_wino_s64_kernel", "conv3x3_wino_r64_kernel")
             # the dominant kernel runs on the bf16 matrix pipe (fp32 operands split exactly into three bf16 pieces) unless
             # VD_CONV_SPLIT=0 / VD_MATH=fp32 keep it on the fp32 MFMA: `peak` is the dense peak of the pipe it uses

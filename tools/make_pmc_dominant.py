@@ -3,7 +3,9 @@
 launch of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE / WRITE_SIZE in KiB; gfx950:
 FETCH_SIZE x2 for wide coalesced reads), plus the MFMA-busy and LDS figures of the same passes.
   python tools/make_pmc_dominant.py gpurun_out/prof_r01m/summary.json conv3x3_wino_s64_kernel r01m"""
+import hashlib
 import json
+import os
 import sys
 
 summary, kernel, tag = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -17,8 +19,13 @@ for v in rows.values():
 n = tot["dispatches"]
 stats = [v for k, v in d["stats"].items() if kernel in k]
 fetch, write = tot["FETCH_SIZE"] * 1024 / n, tot["WRITE_SIZE"] * 1024 / n
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KSRC = {"conv3x3_wino_r64_kernel": ["video-diffusion_amd/csrc/conv_wino_r64.hip"],
+        "conv3x3_wino_s64_kernel": ["video-diffusion_amd/csrc/conv_wino_s64.hip"]}.get(kernel, [])
 out = {
     "kernel": kernel,
+    # bench.py withholds `traffic` when these no longer match the tree (a kernel edited after the PMC passes)
+    "kernel_sources": {f: hashlib.sha1(open(os.path.join(ROOT, f), "rb").read()).hexdigest() for f in KSRC},
     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes, tools/profile_bench.sh {tag}) on "
               f"`bench.py --steps 5 --warmup 1`, {int(n)} dispatches of {kernel}",
     "fetch_size_bytes_per_launch": fetch,

@@ -32,10 +32,12 @@ logger = logging.getLogger("video_sample_full")
 
 
 def _window(samples, obs_frame_indices, latent_frame_indices, B, device):
-    """video_sample_full.py:127-153 / :233-260 (non-adaptive branch): the window's tensors on the device."""
-    x0 = torch.cat([samples[:, obs_frame_indices], samples[:, latent_frame_indices]], dim=1).clone()
-    frame_indices = torch.cat([torch.tensor(obs_frame_indices, dtype=torch.int64),
-                               torch.tensor(latent_frame_indices, dtype=torch.int64)], dim=0).repeat((B, 1))
+    """video_sample_full.py:127-153 / :233-260 (non-adaptive branch): the window's tensors on the device.  `samples` stays
+    resident on the device for the whole run: the horizontal loop touches every window at every timestep, and a host copy
+    per (timestep, window) pair -- what the reference does -- is a device synchronisation per denoise step."""
+    idx = torch.tensor(list(obs_frame_indices) + list(latent_frame_indices), dtype=torch.int64, device=samples.device)
+    x0 = samples.index_select(1, idx)
+    frame_indices = idx.view(1, -1).repeat((B, 1))
     obs_mask, latent_mask, kinda_marg_mask = get_masks(x0, len(obs_frame_indices))
     return [v.to(device) for v in (x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices)]
 
@@ -50,13 +52,14 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
         raise NotImplementedError(f"inference mode {mode!r} needs the LPIPS network (out of scope)")
     B, T, C, H, W = batch.shape
     device = model.device
-    samples = torch.zeros_like(batch).cpu()
-    samples[:, :obs_length] = batch[:, :obs_length].cpu()
+    batch = batch.to(device=device, dtype=torch.float32)
+    samples = torch.zeros_like(batch)
+    samples[:, :obs_length] = batch[:, :obs_length]
     if "goal-directed" in mode:
-        samples[:, -5] = batch[:, -5].cpu()              # the reference hands over ONE goal frame (index -5) here
+        samples[:, -5] = batch[:, -5]                    # the reference hands over ONE goal frame (index -5) here
     nts = diffusion.num_timesteps
     if save_all_timesteps:
-        all_timestep_samples = torch.zeros([B, nts, T, C, H, W])
+        all_timestep_samples = torch.zeros([B, nts, T, C, H, W], device=device)
         all_timestep_samples[:, :, :obs_length] = samples[:, :obs_length].unsqueeze(1).expand(-1, nts, -1, -1, -1, -1)
     else:
         all_timestep_samples = torch.zeros([1])
@@ -90,11 +93,11 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
                                                    use_gradient_method=use_gradient_method)["sample"]
                 if save_all_timesteps:
                     all_local.append(local_samples.clone())
-            samples[:, latent_frame_indices] = local_samples[:, -n_latent:].cpu()
+            samples[:, latent_frame_indices] = local_samples[:, -n_latent:]
             if save_all_timesteps:
                 all_local = torch.stack(all_local, dim=1)
                 all_timestep_samples[:, :len(vertical_diff_timesteps), latent_frame_indices] = \
-                    all_local[:, :len(vertical_diff_timesteps), -n_latent:].cpu()
+                    all_local[:, :len(vertical_diff_timesteps), -n_latent:]
 
     horizontal = []
     for timestep in list(range(nts))[::-1][vertical_steps:]:           # :202-315
@@ -107,12 +110,12 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
                 model_kwargs=dict(frame_indices=frame_indices, x0=x0, obs_mask=obs_mask, latent_mask=latent_mask,
                                   kinda_marg_mask=kinda_marg_mask, x_t_minus_1=x0, observed_frames=observed_frames),
                 return_attn_weights=False, use_gradient_method=use_gradient_method)["sample"]
-            samples[:, latent_frame_indices] = local_samples[:, -n_latent:].cpu()
+            samples[:, latent_frame_indices] = local_samples[:, -n_latent:]
         if save_all_timesteps:
             horizontal.append(samples.clone())
     if save_all_timesteps and horizontal:
         all_timestep_samples[:, vertical_steps:] = torch.stack(horizontal, dim=1)
-    return samples.numpy(), all_timestep_samples.numpy()
+    return samples.cpu().numpy(), all_timestep_samples.cpu().numpy()
 
 
 def main(argv=None):
