@@ -35,6 +35,13 @@ typedef struct vd_config {
     int allow_interactions_between_padding;
     float rp_alpha, rp_beta, rp_gamma;   /* bucket parameters of the table RPE (unet.py:330-340) */
     int time_embed_mult;         /* 4: time_embed_dim = 4*num_channels (unet.py:605) */
+    int cond_emb_type;           /* CondMargVideoModel (unet.py:929-1020): 0 'channel' (5 input channels: frames + obs / kinda-marg
+                                    indicators), 1 'duplicate' | 'all' (6: noisy frames | x0 * obs_mask), 2 't=0' (3: x itself,
+                                    observed frames get timestep -1); the '-initzero' spellings differ at initialisation only */
+    int learn_sigma;             /* 1: the network has 6 output channels, eps | variance values (script_util.py:129-131).  Boundary A
+                                    only: the reference's own sampler cannot use them on video tensors -- p_mean_variance
+                                    asserts model_output.shape == (B, 2*T, ...) (gaussian_diffusion.py:283, C = x.shape[1] = T) --
+                                    so vd_p_sample & co. refuse such an engine as the reference does */
 } vd_config;
 
 typedef struct vd_engine vd_engine;
@@ -87,6 +94,7 @@ enum { VD_TAB_SQRT_RECIP = 0, VD_TAB_SQRT_RECIPM1, VD_TAB_COEF1, VD_TAB_COEF2, V
        VD_TAB_ALPHA /* alphas = 1 - betas (the guidance weight, gaussian_diffusion.py:363) */, VD_NTAB };
 int vd_set_schedule(vd_engine* e, int num_timesteps, const float* host_tab, const int* host_timestep_map,
                     float rescale);
+
 
 /* Timestep indices outside [0, num_timesteps) make the reference raise IndexError (_extract_into_tensor,
  * gaussian_diffusion.py:1019-1031).  The step entry points stay asynchronous: such a batch element is written as NaN

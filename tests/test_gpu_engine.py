@@ -1019,3 +1019,34 @@ def test_return_attn_weights_matches_reference_golden():
     assert tuple(attns["attn/q0-temporal"].shape) == (2, 4, 4) and tuple(attns["attn/q3-spatial"].shape) == (2, 256, 256)
     # 2 steps per quartile, 7 blocks, each row summing to 1, weighted 1 / (8 / 4)
     assert abs(float(attns["attn/q2-temporal"].sum(-1).mean()) - 7.0) < 1e-3 and torch.isfinite(smp).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cond_emb_type variants and the learn_sigma network (unet.py:932-947,1014-1019; script_util.py:129-131)
+@pytest.mark.parametrize("name", ["dup", "allz", "t0", "ls"])
+def test_cond_emb_variants_and_learn_sigma_match_reference_golden(name):
+    """The stem's other conditioning layouts -- 'duplicate' / 'all(-initzero)': 6 channels [noisy frames | x0 * obs_mask];
+    't=0': 3 channels, timestep -1 for a batch item with an observed frame (the reference's expanded-tensor write) -- and the
+    6-output-channel network of learn_sigma=True: eps at Boundary A, p_sample and ddim_sample against the imported
+    reference.  With learn_sigma the reference's sampler asserts on video tensors (gaussian_diffusion.py:283); so does this."""
+    rec = load_npz("variants_tiny.npz")
+    cfg = json.loads(str(rec[f"{name}_cfg_json"]))
+    model, diff = engine(cfg)
+    c = {k: torch.from_numpy(rec[f"{name}_{k}"]) for k in ["x", "x0", "noise", "obs_mask", "latent_mask", "kinda_marg_mask", "frame_indices"]}
+    x = c["x"].cuda()
+    for t_val in [100, 0]:
+        t = torch.tensor([t_val] * 2, device="cuda")
+        out, _ = diff._wrap_model(model)(x, t, **kwargs_of(c))
+        assert tuple(out.shape) == tuple(rec[f"{name}_t{t_val}_out"].shape)
+        close(out.cpu(), rec[f"{name}_t{t_val}_out"], atol=1e-4, rtol=1e-4)
+        if name == "ls":
+            assert str(rec[f"{name}_t{t_val}_psample_error"]) == "AssertionError"
+            with pytest.raises(AssertionError, match="gaussian_diffusion.py:283"):
+                diff.p_sample(model, x, t, model_kwargs=kwargs_of(c))
+            continue
+        sample, xstart = diff._step(0, model, x, t, True, None, kwargs_of(c), 0.0, c["noise"])
+        gain = 1.0 + float(diff.sqrt_recipm1_alphas_cumprod[t_val])
+        close(xstart.cpu(), rec[f"{name}_t{t_val}_pred_xstart"], atol=2e-5 * gain, rtol=1e-4)
+        close(sample.cpu(), rec[f"{name}_t{t_val}_psample"], atol=1e-4, rtol=1e-4)
+        s2, _ = diff._step(1, model, x, t, True, None, kwargs_of(c), 1.0, c["noise"])
+        close(s2.cpu(), rec[f"{name}_t{t_val}_ddim_eta1"], atol=2e-4, rtol=2e-4)

@@ -283,3 +283,29 @@ def test_guidance_gradient_matches_reference(case):
         close(o["grad"], want, atol=2e-5 * scale, rtol=1e-3)
         close(o["mean"], rec[f"{case}_t{t_val}_mean"], atol=1e-4 * scale, rtol=1e-3)
         close(o["sample"], rec[f"{case}_t{t_val}_psample"], atol=1e-4 * scale, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["dup", "allz", "t0", "ls"])
+def test_cond_emb_variants_and_learn_sigma_forward_match_reference(name):
+    """cond_emb_type duplicate / all-initzero / t=0 (unet.py:932-947,1014-1019 -- 't=0' with the reference's write through an
+    expanded tensor: a whole batch item gets timestep -1 once one of its frames is observed) and the 6-channel network of
+    learn_sigma=True at Boundary A (tools/gen_golden_r3.py variants)."""
+    rec = load_npz("variants_tiny.npz")
+    cfg = json.loads(str(rec[f"{name}_cfg_json"]))
+    import video_diffusion_amd as vda
+    model, _ = vda.create_video_model_and_diffusion(**{k: cfg[k] for k in vda.video_model_and_diffusion_defaults()})
+    net = UNetRef(cfg, synth_sd(model.param_specs()))
+    sched = ScheduleRef(cfg["diffusion_steps"], cfg["noise_schedule"], cfg["timestep_respacing"], cfg["sigma_small"],
+                        cfg["rescale_timesteps"])
+    ora = SamplerRef(sched, net)
+    g = lambda k: torch.from_numpy(rec[f"{name}_{k}"])  # noqa: E731
+    kw = dict(x0=g("x0"), obs_mask=g("obs_mask"), latent_mask=g("latent_mask"), kinda_marg_mask=g("kinda_marg_mask"),
+              frame_indices=g("frame_indices"))
+    for t_val in [100, 0]:
+        t = torch.tensor([t_val] * 2)
+        close(ora.eps(g("x"), t, kw), rec[f"{name}_t{t_val}_out"], atol=2e-5, rtol=1e-4)
+        if name == "ls":
+            assert str(rec[f"{name}_t{t_val}_psample_error"]) == "AssertionError"      # the reference cannot sample with it
+            continue
+        o = ora.p_sample(g("x"), t, kw, g("noise"))
+        close(o["sample"], rec[f"{name}_t{t_val}_psample"], atol=2e-5, rtol=1e-4)

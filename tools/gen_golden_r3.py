@@ -10,6 +10,8 @@ what (default: all):
                                                  (gaussian_diffusion.py:264-271,350-364): x.grad, mean, sample
   attn       tests/golden/attn_tiny.npz          return_attn_weights=True: the {'temporal': [...], 'spatial': [...]} lists
                                                  (unet.py:457-466,799-836)
+  variants   tests/golden/variants_tiny.npz      cond_emb_type duplicate / all-initzero / t=0 and learn_sigma=True
+                                                 (unet.py:932-947,1014-1019; gaussian_diffusion.py:277-298)
   full       tests/golden/unet_full64.npz, unet_full128.npz   eps of the DEFAULT 116 M (64x64, T=16) and 119 M (128x128,
                                                  T=8) models for one clip, plus reference-vs-oracle seconds per step (the
                                                  `cpu_baseline.kind: "port"` equivalence), printed and stored
@@ -183,6 +185,48 @@ def gen_attn():
     print("attn_tiny.npz written")
 
 
+def gen_variants():
+    """cond_emb_type in {duplicate, all-initzero, t=0} (unet.py:932-947,1014-1019) and learn_sigma=True (LEARNED_RANGE variance,
+    gaussian_diffusion.py:277-298; script_util.py:129-131,424-428): eps at Boundary A, p_sample / ddim_sample / p_mean_variance."""
+    rec = {}
+    for name, over in [("dup", dict(cond_emb_type="duplicate")), ("allz", dict(cond_emb_type="all-initzero")), ("t0", dict(cond_emb_type="t=0")),
+                       ("ls", dict(learn_sigma=True))]:
+        cfg = tiny_cfg(**over)
+        model, diff = build(cfg)
+        inp = make_inputs(2, 4, 32, 2, 41 + len(name), [[0, 1, 2, 3], [5, 6, 9, 12]])
+        inp["obs_mask"][1] = 0                       # batch item 1 has no observed frame ('t=0' writes -1 through an expanded tensor:
+        inp["latent_mask"][1] = 1                    # a whole batch item gets it as soon as one of its frames is observed)
+        inp["x0"][1] = 0
+        rec[name + "_cfg_json"] = json.dumps(cfg)
+        for k, v in inp.items():
+            if k != "noise2":
+                rec[f"{name}_{k}"] = v.numpy()
+        with torch.no_grad():
+            for t_val in [100, 0]:
+                t = torch.tensor([t_val] * 2)
+                tag = f"{name}_t{t_val}"
+                out, _ = diff._wrap_model(model)(inp["x"], t, **kwargs_of(inp))
+                rec[tag + "_out"] = out.numpy()
+                if cfg["learn_sigma"]:
+                    # the reference cannot sample with a learned variance on video tensors: its own assert fails
+                    # (gaussian_diffusion.py:283, C = x.shape[1] = T); record that, it is the behaviour to mirror
+                    try:
+                        diff.p_sample(model, inp["x"], t, clip_denoised=True, model_kwargs=kwargs_of(inp))
+                        rec[tag + "_psample_error"] = "none"
+                    except AssertionError:
+                        rec[tag + "_psample_error"] = "AssertionError"
+                    continue
+                with FixedNoise(inp["noise"]):
+                    o = diff.p_sample(model, inp["x"], t, clip_denoised=True, model_kwargs=kwargs_of(inp))
+                rec[tag + "_psample"], rec[tag + "_pred_xstart"] = o["sample"].numpy(), o["pred_xstart"].numpy()
+                with FixedNoise(inp["noise"]):
+                    o = diff.ddim_sample(model, inp["x"], t, clip_denoised=True, model_kwargs=kwargs_of(inp), eta=1.0)
+                rec[tag + "_ddim_eta1"] = o["sample"].numpy()
+        print(name, "out", rec[f"{name}_t100_out"].shape, "var_type", diff.model_var_type)
+    np.savez_compressed(os.path.join(OUT, "variants_tiny.npz"), **rec)
+    print("variants_tiny.npz written")
+
+
 def gen_full():
     from oracle.unet_ref import UNetRef
     timing = {}
@@ -229,6 +273,6 @@ def gen_full():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["denoised", "grad", "attn", "full"]
+    what = sys.argv[1:] or ["denoised", "grad", "attn", "variants", "full"]
     for w in what:
-        {"denoised": gen_denoised, "grad": gen_grad, "attn": gen_attn, "full": gen_full}[w]()
+        {"denoised": gen_denoised, "grad": gen_grad, "attn": gen_attn, "variants": gen_variants, "full": gen_full}[w]()

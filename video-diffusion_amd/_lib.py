@@ -99,7 +99,8 @@ class VdConfig(ctypes.Structure):
                 ("use_spatial_encoding", ctypes.c_int), ("use_frame_encoding", ctypes.c_int),
                 ("enforce_position_invariance", ctypes.c_int), ("use_rpe_net", ctypes.c_int),
                 ("allow_interactions_between_padding", ctypes.c_int), ("rp_alpha", ctypes.c_float),
-                ("rp_beta", ctypes.c_float), ("rp_gamma", ctypes.c_float), ("time_embed_mult", ctypes.c_int)]
+                ("rp_beta", ctypes.c_float), ("rp_gamma", ctypes.c_float), ("time_embed_mult", ctypes.c_int),
+                ("cond_emb_type", ctypes.c_int), ("learn_sigma", ctypes.c_int)]
 
 
 _P = ctypes.c_void_p

@@ -547,10 +547,12 @@ int launch_out_conv_bwd(const float* deps, const float* w, int nfr, int H, int W
 // onto the 3 image channels and apply the factor with which x enters the network input (assemble_kernel:
 // x*lat + obs_src*obs + x*(1 - any) -> lat + 1 - any).  dx is NCHW like x.
 __global__ __launch_bounds__(256) void stem_col2im_kernel(const float* __restrict__ dcols, const float* __restrict__ obs, const float* __restrict__ lat,
-                                                          const float* __restrict__ km, int H, int Wd, int Kpad, float* __restrict__ dx) {
+                                                          const float* __restrict__ km, int H, int Wd, int Kpad, int cond_mode, float* __restrict__ dx) {
     const int n = blockIdx.y;
     const size_t HW = (size_t)H * Wd;
-    const float any = fminf(obs[n] + lat[n] + km[n], 1.0f), fac = lat[n] + 1.0f - any;
+    const int Cs = cond_mode == 0 ? 5 : (cond_mode == 1 ? 6 : 3);
+    // x enters the first three stem channels as x*lat + x*(1 - any) ('channel', 'duplicate' / 'all') or as x itself ('t=0')
+    const float any = fminf(obs[n] + lat[n] + km[n], 1.0f), fac = cond_mode == 2 ? 1.0f : lat[n] + 1.0f - any;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW * 3; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i / HW); const int q = (int)(i - (size_t)c * HW);
         const int y = q / Wd, x = q - y * Wd;
@@ -558,15 +560,15 @@ __global__ __launch_bounds__(256) void stem_col2im_kernel(const float* __restric
         for (int tap = 0; tap < 9; ++tap) {                           // output pixel p reads input pixel p + (tap/3 - 1, tap%3 - 1)
             const int py = y - (tap / 3 - 1), px = x - (tap % 3 - 1);
             if (py < 0 || py >= H || px < 0 || px >= Wd) continue;
-            acc += dcols[((size_t)n * HW + (size_t)py * Wd + px) * Kpad + tap * 5 + c];
+            acc += dcols[((size_t)n * HW + (size_t)py * Wd + px) * Kpad + tap * Cs + c];
         }
         dx[((size_t)n * 3 + c) * HW + q] = acc * fac;
     }
 }
-int launch_stem_col2im(const float* dcols, const float* obs, const float* lat, const float* km, int nfr, int H, int Wd, int Kpad, float* dx,
-                       hipStream_t s) {
+int launch_stem_col2im(const float* dcols, const float* obs, const float* lat, const float* km, int nfr, int H, int Wd, int Kpad, int cond_mode,
+                       float* dx, hipStream_t s) {
     hipLaunchKernelGGL(stem_col2im_kernel, dim3((unsigned)std::min<size_t>(((size_t)H * Wd * 3 + 255) / 256, 1024), nfr), dim3(256), 0, s, dcols, obs, lat, km, H,
-                       Wd, Kpad, dx);
+                       Wd, Kpad, cond_mode, dx);
     VD_HIP(hipGetLastError());
     return 0;
 }

@@ -407,7 +407,9 @@ int vd_engine::build() {
     };
 
     std::vector<int> chans;
-    input_blocks.push_back({Layer{0, add_conv("input_blocks.0.0", 5, mc, PK_STEM, cfg.image_size)}});
+    VD_REQUIRE(cfg.cond_emb_type >= 0 && cfg.cond_emb_type <= 2, "cond_emb_type: 0 channel, 1 duplicate|all, 2 t=0");
+    const int stem_in = cfg.cond_emb_type == 0 ? 5 : (cfg.cond_emb_type == 1 ? 6 : 3);         // unet.py:932-940
+    input_blocks.push_back({Layer{0, add_conv("input_blocks.0.0", stem_in, mc, PK_STEM, cfg.image_size)}});
     chans.push_back(mc);
     int ch = mc, ds = 1, first_ds = -1, first_ch = -1;
     n_before_attn = -1;
@@ -462,7 +464,8 @@ int vd_engine::build() {
     }
     final_ch = ch;
     p_outgw = add("out.0.weight", {ch}); p_outgb = add("out.0.bias", {ch});
-    p_outw = add("out.2.weight", {3, mc, 3, 3}, PK_OUTCONV); p_outb = add("out.2.bias", {3});
+    const int oc = cfg.learn_sigma ? 6 : 3;                                                    // script_util.py:129-131
+    p_outw = add("out.2.weight", {oc, mc, 3, 3}, PK_OUTCONV); p_outb = add("out.2.bias", {oc});
     VD_REQUIRE(final_ch == mc, "channel_mult[0] must be 1");
 
     // ---- packed layout: [FiLM weights | FiLM biases | rpe-time weights | rpe-time biases | everything else]
@@ -774,7 +777,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
     float* femb = cfg.use_frame_encoding ? ar.get<float>((size_t)N * pos_ch) : nullptr;
     if (!ar.dry) {
         VD_REQUIRE(d_freq_time && n_freq_time == mc / 2, "vd_set_freqs not called (time frequencies)");
-        AssembleArgs aa{in.x, in.obs_src, in.obs, in.lat, in.km, in.t_model, in.obs_mode, B, T, S, S, STEM_KPAD, x8, tfr, amask};
+        AssembleArgs aa{in.x, in.obs_src, in.obs, in.lat, in.km, in.t_model, in.obs_mode, B, T, S, S, STEM_KPAD, cfg.cond_emb_type, x8, tfr, amask};
         if ((rc = launch_assemble(aa, st))) return rc;
         if ((rc = launch_sinus_embed(tfr, N, mc, d_freq_time, tsin, st))) return rc;
         if ((rc = linear(tsin, N, mc, 0, 0, E, W(p_te0w), W(p_te0b), 0, nullptr, e1, st))) return rc;
@@ -862,7 +865,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
     if (!ar.dry) {
         VD_REQUIRE(h.H == S && h.C == final_ch, "output head shape");
         { ProfScope ps(PC_OUT_CONV, 2.0 * N * S * S * h.C * 27.0, 4.0 * N * S * S * (h.C + 3.0), st);
-          rc = launch_out_conv(h.p, A, Bf, W(p_outw), W(p_outb), N, S, S, h.C, 3, in.eps, st); }
+          rc = launch_out_conv(h.p, A, Bf, W(p_outw), W(p_outb), N, S, S, h.C, cfg.learn_sigma ? 6 : 3, in.eps, st); }
         if (rc) return rc;
     }
     return 0;
@@ -881,7 +884,7 @@ int vd_engine::ensure_ws(int B, int T) {
     }
     const size_t tail = (it->second + 255) & ~(size_t)255;
     const size_t tm_bytes = ((size_t)B * sizeof(float) + 255) & ~(size_t)255;
-    const size_t need = tail + tm_bytes + (size_t)B * T * 3 * cfg.image_size * cfg.image_size * sizeof(float);
+    const size_t need = tail + tm_bytes + (size_t)B * T * (cfg.learn_sigma ? 6 : 3) * cfg.image_size * cfg.image_size * sizeof(float);
     if (need > ws_cap) {
         // captured window graphs hold addresses inside the old workspace: they die with it (a window in flight is lost:
         // vd_window_run then reports "window graphs invalidated")
@@ -1045,7 +1048,7 @@ int vd_engine::backward(const FwdIn& in, const float* deps, float* dx, hipStream
                 float* dcols = ar.get<float>((size_t)N * S * S * STEM_KPAD);
                 if (!dry) {
                     if ((rc = bwd_linear(d_out, N * S * S, c.w, nullptr, dcols, st))) return rc;
-                    if ((rc = launch_stem_col2im(dcols, in.obs, in.lat, in.km, N, S, S, STEM_KPAD, dx, st))) return rc;
+                    if ((rc = launch_stem_col2im(dcols, in.obs, in.lat, in.km, N, S, S, STEM_KPAD, cfg.cond_emb_type, dx, st))) return rc;
                 }
                 ar.release(mk);
             } else if (t.type == 3) {                                    // ---- Downsample (stride 2): stride-1 conv of the zero-stuffed gradient
@@ -1403,6 +1406,7 @@ static int sample_impl(vd_engine* e, int mode, int B, int T, const float* x, con
     VD_REQUIRE(x && obs_src && obs && lat && km && fidx && t && sample, "null tensor");
     VD_REQUIRE(obs_mode >= 0 && obs_mode <= 2, "observed_frames must be x_0 / x_t / x_t_minus_1");
     VD_REQUIRE(mode == 0 || eta >= 0.f, "eta");
+    VD_REQUIRE(!e->cfg.learn_sigma, "learn_sigma: the reference's sampler asserts on video tensors (gaussian_diffusion.py:283: model_output.shape == (B, 2*T, ...)); only the network forward is served");
     if ((rc = e->ensure_ws(B, T))) return rc;
     return step_launches(e, mode, B, T, x, obs_src, obs, lat, km, fidx, t, obs_mode, clip, eta, noise, seed, offset, nullptr,
                          sample, xstart, nullptr, eps_out, static_cast<hipStream_t>(stream));
@@ -1687,6 +1691,7 @@ int vd_guided_step(vd_engine* e, int B, int T, const float* x, const float* obs,
     int rc = check_ready(e, B, T);
     if (rc) return rc;
     VD_REQUIRE(e->d_tab, "vd_set_schedule not called");
+    VD_REQUIRE(!e->cfg.learn_sigma, "learn_sigma: the reference's sampler asserts on video tensors (gaussian_diffusion.py:283)");
     VD_REQUIRE(e->wbuf_bwd && !e->wbuf_bwd_on_host, "use_gradient_method: the backward-data weight image is not on the device (vd_set_bwd_weight_storage / vd_load_weight_bwd)");
     VD_REQUIRE(x && obs && lat && km && fidx && t && x_t_minus_1 && noise && (sample == nullptr || noise2 != nullptr), "null tensor");
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -16,10 +16,21 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
     const int HW = a.H * a.W;
     const float om = a.obs_mask[n], lm = a.lat_mask[n], km = a.km_mask[n];
     const float any = fminf(om + lm + km, 1.0f);
+    const int Cs = a.cond_mode == 0 ? 5 : (a.cond_mode == 1 ? 6 : 3);      // stem input channels (unet.py:932-940)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const float t = a.t_model[n / a.T];
         const float tobs = a.obs_t_mode == 0 ? 0.f : (a.obs_t_mode == 1 ? t : t - 1.f);
-        a.t_frames[n] = tobs * om + t * (1.f - om);
+        // 'channel': observed frames carry the timestep of their source (unet.py:991-1013); 'duplicate' / 'all': every frame
+        // keeps t; 't=0' (unet.py:1018-1019): `timesteps[obs_mask == 1] = -1` writes through a (B, 1) -> (B, T) expanded tensor,
+        // i.e. ONE stored value per batch item: all frames of an item with any observed frame get -1 (mirrored as computed)
+        float tf = t;
+        if (a.cond_mode == 0) tf = tobs * om + t * (1.f - om);
+        else if (a.cond_mode == 2) {
+            bool any_obs = false;
+            for (int k = 0; k < a.T; ++k) any_obs |= a.obs_mask[(n / a.T) * a.T + k] == 1.f;
+            if (any_obs) tf = -1.f;
+        }
+        a.t_frames[n] = tf;
         a.amask[n] = any;
     }
     // thread -> (pixel, tap): 16 pixels x 9 taps (+7 idle lanes' worth) per 256 threads would waste lanes; use one thread
@@ -28,22 +39,23 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
     const int p = blockIdx.x * 28 + tp;
     if (tp >= 28 || p >= HW) return;
     const int y = p / a.W + tap / 3 - 1, x = p % a.W + tap % 3 - 1;
-    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
         const int q = y * a.W + x;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float xv = a.x[((size_t)n * 3 + c) * HW + q];
             const float ov = a.obs_src[((size_t)n * 3 + c) * HW + q];
-            v[c] = xv * lm + ov * om + xv * (1.f - any);
+            if (a.cond_mode == 0) v[c] = xv * lm + ov * om + xv * (1.f - any);
+            else if (a.cond_mode == 1) { v[c] = xv * lm + xv * (1.f - any); v[3 + c] = ov * om; }   // obs_src = x0 (unet.py:1014-1017)
+            else v[c] = xv;
         }
-        v[3] = om; v[4] = km;
+        if (a.cond_mode == 0) { v[3] = om; v[4] = km; }
     }
-    float* o = a.x_cols + ((size_t)n * HW + p) * a.Kpad + tap * 5;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) o[c] = v[c];
+    float* o = a.x_cols + ((size_t)n * HW + p) * a.Kpad + tap * Cs;
+    for (int c = 0; c < Cs; ++c) o[c] = v[c];
     if (tap == 8)
-        for (int k = 45; k < a.Kpad; ++k) o[k - 40] = 0.f;            // o + 5 = column 45
+        for (int k = 9 * Cs; k < a.Kpad; ++k) o[k - 8 * Cs] = 0.f;   // o + Cs = column 9*Cs
 }
 
 int launch_assemble(const AssembleArgs& a, hipStream_t s) {
@@ -167,15 +179,18 @@ int launch_posenc_add(const float* x, const float* P, const float* femb, int nfr
 // NHWC in, NCHW out (the caller's layout).  16x16 output pixels per block, the activated halo tile
 // staged through LDS 32 channels at a time; VALU (3 output channels cannot feed a 32x32 MFMA tile).
 constexpr int OT = 16;
+template <int NCO>      // accumulators per pixel: 4 (eps: 3 outputs) or 8 (learn_sigma: eps | variance values, 6 outputs)
 __global__ __launch_bounds__(256) void out_conv_kernel(const float* __restrict__ x, const float* __restrict__ affA,
                                                        const float* __restrict__ affB, const float* __restrict__ w,
                                                        const float* __restrict__ bias, int H, int W, int C, int Cout,
                                                        float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float tile[(OT + 2) * (OT + 2) * 36];
-    __shared__ __attribute__((aligned(16))) float ws[9 * 4 * 32];
+    __shared__ __attribute__((aligned(16))) float ws[9 * NCO * 32];
     const int n = blockIdx.z, y0 = blockIdx.y * OT, x0 = blockIdx.x * OT;
     const int tid = threadIdx.x, ty = tid / OT, tx = tid % OT;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[NCO];
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
     for (int c0 = 0; c0 < C; c0 += 32) {
         __syncthreads();
         for (int i = tid; i < (OT + 2) * (OT + 2) * 8; i += 256) {
@@ -191,8 +206,8 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* __restrict__
             }
             *reinterpret_cast<f32x4*>(tile + pix * 36 + q * 4) = v;
         }
-        for (int i = tid; i < 9 * 4 * 32; i += 256) {
-            const int tap = i / 128, co = (i / 32) % 4, c = i % 32;
+        for (int i = tid; i < 9 * NCO * 32; i += 256) {
+            const int tap = i / (NCO * 32), co = (i / 32) % NCO, c = i % 32;
             ws[i] = co < Cout ? w[((size_t)tap * Cout + co) * C + c0 + c] : 0.f;
         }
         __syncthreads();
@@ -203,8 +218,8 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* __restrict__
             for (int q = 0; q < 8; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tp + q * 4);
 #pragma unroll
-                for (int co = 0; co < 4; ++co) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + (tap * 4 + co) * 32 + q * 4);
+                for (int co = 0; co < NCO; ++co) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + (tap * NCO + co) * 32 + q * 4);
                     acc[co] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
                 }
             }
@@ -217,9 +232,10 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* __restrict__
 
 int launch_out_conv(const float* x, const float* affA, const float* affB, const float* w, const float* bias, int nfr,
                     int H, int W, int C, int Cout, float* out_nchw, hipStream_t s) {
-    VD_REQUIRE(Cout <= 4 && C % 32 == 0, "output head: Cout <= 4, C multiple of 32");
-    hipLaunchKernelGGL(out_conv_kernel, dim3((W + OT - 1) / OT, (H + OT - 1) / OT, nfr), dim3(256), 0, s, x, affA, affB,
-                       w, bias, H, W, C, Cout, out_nchw);
+    VD_REQUIRE(Cout <= 8 && C % 32 == 0, "output head: Cout <= 8, C multiple of 32");
+    const dim3 grid((W + OT - 1) / OT, (H + OT - 1) / OT, nfr);
+    if (Cout <= 4) hipLaunchKernelGGL(out_conv_kernel<4>, grid, dim3(256), 0, s, x, affA, affB, w, bias, H, W, C, Cout, out_nchw);
+    else hipLaunchKernelGGL(out_conv_kernel<8>, grid, dim3(256), 0, s, x, affA, affB, w, bias, H, W, C, Cout, out_nchw);
     VD_HIP(hipGetLastError());
     return 0;
 }

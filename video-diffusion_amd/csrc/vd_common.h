@@ -182,7 +182,8 @@ struct AssembleArgs {
     const float* t_model;// [B] value handed to the network (already mapped / rescaled)
     int obs_t_mode;      // 0: 'x_0' (obs frames see t=0), 1: 'x_t', 2: 'x_t_minus_1'
     int B, T, H, W, Kpad;
-    float* x_cols;       // [B*T*H*W][Kpad]: im2col of the 5-channel input for the 3x3 stem, k = tap*5 + channel
+    int cond_mode;       // vd_config::cond_emb_type: 0 channel (5 stem channels), 1 duplicate|all (6), 2 t=0 (3)
+    float* x_cols;       // [B*T*H*W][Kpad]: im2col of the stem's input for the 3x3 stem, k = tap*Cs + channel
     float* t_frames;     // [B*T]
     float* amask;        // [B*T] anything mask
 };
@@ -256,8 +257,8 @@ int launch_zero_stuff2(const float* x, int nfr, int Ho, int Wo, int C, float* y,
 int launch_sumpool2(const float* x, int nfr, int Ho, int Wo, int C, int accumulate, float* y, hipStream_t s);
 int launch_add(const float* x, size_t n, int accumulate, float* y, hipStream_t s);
 int launch_out_conv_bwd(const float* deps, const float* w, int nfr, int H, int W, int C, int Cout, float* da, hipStream_t s);
-int launch_stem_col2im(const float* dcols, const float* obs, const float* lat, const float* km, int nfr, int H, int W, int Kpad, float* dx,
-                       hipStream_t s);
+int launch_stem_col2im(const float* dcols, const float* obs, const float* lat, const float* km, int nfr, int H, int W, int Kpad, int cond_mode,
+                       float* dx, hipStream_t s);
 // return_attn_weights (unet.py:457-466): softmax weights averaged over the heads, |.|; temporal [B*HW][T][T], spatial [nfr][L][L]
 int launch_attn_temporal_weights(const AttnTemporalArgs& a, float* out, hipStream_t s);
 int launch_attn_spatial_weights(const AttnSpatialArgs& a, float* out, hipStream_t s);

@@ -8,8 +8,10 @@ reference does and uploaded once (as their float32 casts, which is what
 and every tensor operation of a step runs in the HIP engine behind the C ABI.
 The NLL path (`p_mean_variance`, `_vb_terms_bpd`, `_prior_bpd`, `calc_bpd_loop_subsampled`) runs on
 the engine as well: one UNet forward per timestep plus one fused likelihood kernel (csrc/misc.hip: vb_terms_kernel
-restates losses.py's normal_kl / discretized_gaussian_log_likelihood).  Training losses and gradient guidance
-(`use_gradient_method`: a UNet backward w.r.t. the input) are out of scope.
+restates losses.py's normal_kl / discretized_gaussian_log_likelihood).  Gradient guidance (`use_gradient_method`,
+gaussian_diffusion.py:264-271,350-364) runs on the engine too: vd_guided_step = a taped forward, the loss gradient and
+a backward-data pass of the whole UNet w.r.t. its input (csrc/backward.hip); `denoised_fn` and `return_attn_weights`
+are served as well.  Training losses are out of scope.
 """
 import enum
 import math
@@ -98,15 +100,24 @@ class GaussianDiffusion:
         if model_mean_type != ModelMeanType.EPSILON:
             raise NotImplementedError("the HIP engine implements the epsilon-prediction parameterisation "
                                       "(create_gaussian_diffusion default, script_util.py:429-431)")
-        if model_var_type not in (ModelVarType.FIXED_LARGE, ModelVarType.FIXED_SMALL):
-            raise NotImplementedError("learn_sigma=True (LEARNED_RANGE variance) is not supported by the HIP engine")
+        # LEARNED / LEARNED_RANGE (learn_sigma=True) construct fine, as in the reference, and fail at the first step the way
+        # the reference does: see _refuse_learned
 
     # -- schedule upload -------------------------------------------------------------------------
     def _model_log_variance(self):
         """gaussian_diffusion.py:299-317."""
         if self.model_var_type == ModelVarType.FIXED_LARGE:
             return np.log(np.append(self.posterior_variance[1], self.betas[1:]))
-        return self.posterior_log_variance_clipped
+        return self.posterior_log_variance_clipped          # FIXED_SMALL; a learned variance never reads this row
+
+    def _refuse_learned(self, x):
+        """gaussian_diffusion.py:277-285 on a video tensor: `B, C = x.shape[:2]` takes C = T, and the reference asserts
+        `model_output.shape == (B, C * 2, *x.shape[2:])` against the network's (B, T, 6, H, W): learn_sigma cannot sample in
+        the reference either.  Same exception here."""
+        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
+            B, C = x.shape[:2]
+            raise AssertionError(f"model_output.shape == {(B, C * 2, *x.shape[2:])} (gaussian_diffusion.py:283): a learned variance "
+                                 f"is split along dim 1, which is T for video tensors; the reference fails here as well")
 
     def _device_tables(self):
         rows = [self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
@@ -141,6 +152,7 @@ class GaussianDiffusion:
               return_attn_weights=False, use_gradient_method=False):
         if model_kwargs is None:
             model_kwargs = {}
+        self._refuse_learned(x)
         if return_attn_weights and (use_gradient_method or denoised_fn is not None):
             raise NotImplementedError("return_attn_weights together with use_gradient_method / denoised_fn")
         if use_gradient_method:
@@ -245,6 +257,7 @@ class GaussianDiffusion:
                         return_attn_weights=False, use_gradient_method=False):
         """gaussian_diffusion.py:229-372 -> {'mean', 'variance', 'log_variance', 'pred_xstart', 'attn'} (+ 'eps', the raw
         model output, which the NLL loop reuses)."""
+        self._refuse_learned(x)
         if return_attn_weights and (use_gradient_method or denoised_fn is not None):
             raise NotImplementedError("return_attn_weights together with use_gradient_method / denoised_fn")
         if use_gradient_method:

@@ -40,14 +40,14 @@ def create_video_model(T, image_size, num_channels, num_res_blocks, learn_sigma,
     """script_util.py:229-300."""
     if image_size not in _CHANNEL_MULT:
         raise ValueError(f"unsupported image size: {image_size}")
-    if learn_sigma or class_cond:
-        raise NotImplementedError("learn_sigma / class_cond are not supported by the HIP engine")
+    if class_cond:
+        raise NotImplementedError("class_cond is not supported by the HIP engine")
     if not do_cond_marg:
         raise NotImplementedError("do_cond_marg=False (plain UNetVideoModel)")
     attention_ds = tuple(image_size // int(res) for res in attention_resolutions.split(","))
     bucket_params = dict(alpha=rp_alpha, beta=rp_beta, gamma=rp_gamma) if any([rp_alpha, rp_beta, rp_gamma]) else None
     return CondMargVideoModel(
-        T=T, in_channels=3, model_channels=num_channels, out_channels=3, num_res_blocks=num_res_blocks,
+        T=T, in_channels=3, model_channels=num_channels, out_channels=(3 if not learn_sigma else 6), num_res_blocks=num_res_blocks,
         attention_resolutions=attention_ds, dropout=dropout, channel_mult=_CHANNEL_MULT[image_size], num_classes=None,
         use_checkpoint=use_checkpoint, num_heads=num_heads, num_heads_upsample=num_heads_upsample,
         use_scale_shift_norm=use_scale_shift_norm, use_spatial_encoding=use_spatial_encoding,

@@ -25,12 +25,21 @@ class CondMargVideoModel:
                  bucket_params=None, cond_emb_type="channel", allow_interactions_between_padding=False,
                  in_channels=3, out_channels=3, dropout=0, num_classes=None, num_heads_upsample=-1,
                  use_checkpoint=False, temporal_augment_type=None, channel_mult=None, **unused):
-        if cond_emb_type.replace("-initzero", "") != "channel":
-            raise NotImplementedError(f"cond_emb_type={cond_emb_type!r}: the HIP engine implements 'channel'")
+        # unet.py:932-947: how the conditioning frames enter the stem ('-initzero' differs at initialisation only)
+        cond = cond_emb_type.replace("-initzero", "")
+        if cond == "channel":
+            cond_mode = 0
+        elif "duplicate" in cond_emb_type or "all" in cond_emb_type:
+            cond_mode = 1
+        elif cond_emb_type == "t=0":
+            cond_mode = 2
+        else:
+            raise NotImplementedError(cond_emb_type)
+        self.cond_emb_type = cond
         if not cross_frame_attention:
             raise NotImplementedError("cross_frame_attention=False")
-        if num_classes is not None or out_channels != 3 or in_channels != 3:
-            raise NotImplementedError("class conditioning / learn_sigma / non-RGB inputs")
+        if num_classes is not None or out_channels not in (3, 6) or in_channels != 3:
+            raise NotImplementedError("class conditioning / non-RGB inputs")
         if num_heads_upsample not in (-1, num_heads):
             raise NotImplementedError("num_heads_upsample != num_heads")
         self.T = T
@@ -56,6 +65,8 @@ class CondMargVideoModel:
         assert bucket_params is not None                          # unet.py:423-427
         cfg.rp_alpha, cfg.rp_beta, cfg.rp_gamma = float(bp["alpha"]), float(bp["beta"]), float(bp["gamma"])
         cfg.time_embed_mult = 4
+        cfg.cond_emb_type = cond_mode
+        cfg.learn_sigma = int(out_channels == 6)
         self._cfg = cfg
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().vd_create(ctypes.byref(cfg), ctypes.byref(h)))
@@ -282,7 +293,12 @@ class CondMargVideoModel:
         mode = kw["observed_frames"]
         if mode not in _OBS_MODES:
             raise NotImplementedError(f"observed_frames={mode!r} (training-only option)")
-        src = {"x_0": kw["x0"], "x_t": x, "x_t_minus_1": kw["x_t_minus_1"]}[mode]   # KeyError like unet.py:961
+        if self.cond_emb_type in ("duplicate", "all"):
+            src = kw["x0"]                                                           # unet.py:1014-1017: x0 * obs_mask, whatever the mode
+        elif self.cond_emb_type == "t=0":
+            src = x
+        else:
+            src = {"x_0": kw["x0"], "x_t": x, "x_t_minus_1": kw["x_t_minus_1"]}[mode]   # KeyError like unet.py:961
         f32 = lambda t: t.to(device=dev, dtype=th.float32).contiguous()  # noqa: E731
         fi = kw.get("frame_indices")
         if fi is None:
@@ -323,7 +339,7 @@ class CondMargVideoModel:
         xs = x.to(device=self.device, dtype=th.float32).contiguous()
         kw = self._pack_kwargs(xs, kwargs)
         tm = timesteps.to(device=self.device, dtype=th.float32).reshape(B).contiguous()
-        eps = th.empty_like(xs)
+        eps = th.empty(B, T, self.out_channels, H, W, dtype=th.float32, device=self.device)
         attn = self._attn_capture(B, T) if return_attn_weights else None
         try:
             _lib.check(_lib.lib().vd_unet_forward(self._handle, B, T, _lib.ptr(xs), _lib.ptr(kw["obs_src"]),
