@@ -22,7 +22,6 @@ namespace vd {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
 #ifndef VD_GS_PF3
 #define VD_GS_PF3 1        // 0: the A operand one chunk ahead for every tile (A/B)
@@ -277,194 +276,6 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
 }
 
 
-// ------------------------------------------------------------------------------------------------ register-split variant
-// The same product with NO LDS and NO block barrier: every wave reads the rows of its own M-tiles straight into the MFMA
-// fragment layout -- lane (row r, k-half h) takes k = 16*ks + 8*h .. +8 of its row for both k-steps of a 32-wide chunk, four
-// 16-byte loads; the two half-lanes and the two k-steps together consume each row's 128-byte line -- and splits them in its
-// own registers (the split is 5.5 instructions per value and a fragment feeds NI * 6 MFMAs: 1.8 .. 2.7 vector instructions
-// per MFMA, all hidden).  The two waves of a row group split the same rows twice; in exchange the block's waves are free
-// of one another: no staging threads, no ds_write / ds_read, no lockstep -- one wave's residual loads and output stores run
-// under the others' MFMAs.  Plain GEMM only (the implicit-im2col mode and the 128x192 tile stay on gemm_split_kernel).
-#ifndef VD_GS_RS
-#define VD_GS_RS 1         // 0: every shape on gemm_split_kernel (A/B)
-#endif
-__device__ __forceinline__ void split3_frag(const f32x4& lo, const f32x4& hi, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-    u32x4s a, b, c;
-    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {
-        unsigned q1, q2, q3; float r0, r1;
-        split_a(v[2 * pr], v[2 * pr + 1], q1, r0, r1, 0x07060302u);
-        split_b(r0, r1, q2, q3, 0x07060302u);
-        a[pr] = q1; b[pr] = q2; c[pr] = q3;
-    }
-    p1 = __builtin_bit_cast(bf16x8, a); p2 = __builtin_bit_cast(bf16x8, b); p3 = __builtin_bit_cast(bf16x8, c);
-}
-
-template <int BM, int BN, bool ACT>
-__global__ __launch_bounds__(256, 2) void gemm_split_rs_kernel(IgemmArgs a) {
-    constexpr int MI = BM / 64, NI = BN / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int nchunk = a.Cin >> 5, ncoblk = a.Cout >> 5;
-    const int C1 = a.Cin - a.C0;
-    if (a.zcount > 1) {
-        const int z = blockIdx.z;
-        a.src0 += (size_t)z * a.zs_a; a.wfrag += (size_t)z * a.zs_w; a.out += (size_t)z * a.zs_out;
-        if (a.bias) a.bias += (size_t)z * a.zs_bias;
-    }
-    const auto asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.M * a.C0 * 4, 0x00020000);
-    const auto asrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.M * C1 * 4 : 0, 0x00020000);
-    unsigned ao0[MI], ao1[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const unsigned row = (unsigned)min(m0 + wm * (BM / 2) + i * 32 + lr, a.M - 1);
-        ao0[i] = row * (unsigned)(a.C0 * 4) + lh * 32u;
-        ao1[i] = row * (unsigned)(C1 * 4) + lh * 32u;
-    }
-    const auto bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, a.Cin * a.Cout * 6, 0x00020000);
-    unsigned bo[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) bo[j] = (unsigned)min((int)blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1) * 3072u + lane * 16u;
-
-    f32x4 ra[2][MI][4];                           // [prefetch slot][M-tile][k-step ks: lo = 2*ks, hi = 2*ks + 1]
-    bf16x8 bfr[3][NI][3], afr[MI][3];
-    auto a_load = [&](int chunk, int slot) {
-        const int c = chunk * 32;
-        const bool first = c < a.C0;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int so = ((first ? c : c - a.C0) + 16 * ks) * 4 + q * 16;
-                    ra[slot][i][2 * ks + q] = first ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc0, ao0[i], so, 0))
-                                                    : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc1, ao1[i], so, 0));
-                }
-    };
-    auto b_load = [&](int slot, int kstep) {
-        const int so = kstep * ncoblk * 3072;
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                bfr[slot][j][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p * 1024, so, 0));
-    };
-    auto a_split = [&](int slot, int ks) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            f32x4 lo = ra[slot][i][2 * ks], hi = ra[slot][i][2 * ks + 1];
-            if constexpr (ACT) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { lo[e] = silu_f(lo[e]); hi[e] = silu_f(hi[e]); }
-            }
-            split3_frag(lo, hi, afr[i][0], afr[i][1], afr[i][2]);
-        }
-    };
-
-    const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.ldo * 4, 0x00020000);
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? a.M * a.ldo * 4 : 0, 0x00020000);
-    unsigned vb[MI][NI];
-    float bv[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int co = n0 + wn * (BN / 2) + j * 32 + lr;
-        bv[j] = a.bias && co < a.Cout ? a.bias[co] : 0.f;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-            vb[i][j] = co < a.Cout ? (unsigned)((m0 + wm * (BM / 2) + i * 32 + 4 * lh) * a.ldo + co) * 4u : 0x80000000u;
-    }
-    const int nks = 2 * nchunk;
-    a_load(0, 0);
-    b_load(0, 0);
-    b_load(1, min(1, nks - 1));
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];
-    if (a.res) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int srow = ((r & 3) + 8 * (r >> 2)) * a.ldo * 4;
-                    acc[i][j][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vb[i][j] + srow, 0, 0));
-                }
-    }
-    auto kstep = [&](int chunk, int ks, int gslot, int aslot) {
-        const int g = 2 * chunk + ks;
-        b_load((gslot + 2) % 3, min(g + 2, nks - 1));
-        a_split(aslot, ks);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][0], bfr[gslot][j][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][1], bfr[gslot][j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][2], bfr[gslot][j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][0], bfr[gslot][j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][1], bfr[gslot][j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][0], bfr[gslot][j][0], c, 0, 0, 0);
-                acc[i][j] = c;
-            }
-    };
-    // 6 chunks per trip: weight ring slots (k-step % 3) and A prefetch slots (chunk % 2) are compile-time constants
-    for (int chunk0 = 0; chunk0 < nchunk; chunk0 += 6) {
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) {
-            const int chunk = chunk0 + cc;
-            if (chunk < nchunk) {
-                a_load(min(chunk + 1, nchunk - 1), (cc + 1) & 1);
-                kstep(chunk, 0, (2 * cc) % 3, cc & 1);
-                kstep(chunk, 1, (2 * cc + 1) % 3, cc & 1);
-            }
-        }
-    }
-    if (a.stats) {
-        const int row0 = m0 + wm * (BM / 2);
-        if (row0 < a.M) {
-            const int fr = row0 / a.stats_hw, sp = (row0 - fr * a.stats_hw) / (BM / 2);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { const double v = (double)acc[i][j][r]; d0 += v; d1 += v * v; }
-                d0 += __shfl_xor(d0, 32);
-                d1 += __shfl_xor(d1, 32);
-                const int co = n0 + wn * (BN / 2) + j * 32 + lr;
-                if (lh == 0 && co < a.Cout) {
-                    double* o = a.stats + (((size_t)fr * a.stats_split + sp) * a.Cout + co) * 2;
-                    o[0] = d0; o[1] = d1;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            unsigned vbe = vb[i][j];
-            asm volatile("" : "+v"(vbe));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int srow = ((r & 3) + 8 * (r >> 2)) * a.ldo * 4;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[i][j][r]), osrc, vbe + srow, 0, 0);
-            }
-        }
-}
-
 // 3x3 convolutions whose weights came from pack_conv3_split (the stride-2 Downsample convs, unet.py:98)
 bool conv_split_supported(const IgemmArgs& a) {
     return a.wsplit && a.wfrag != nullptr && a.ksz == 3 && a.pad == 1 && (a.stride == 1 || a.stride == 2) && a.ups == 0 &&
@@ -483,15 +294,6 @@ template <int BM, int BN>
 static int launch_gs(const IgemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * 3 * BM * SROW;
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.zcount > 1 ? a.zcount : 1);
-    static const bool rs_on = [] { const char* e = getenv("VD_GS_RS"); return VD_GS_RS && !(e && e[0] == '0'); }();
-    if constexpr (BN <= 128) {
-        if (rs_on && a.ksz == 1 && (a.C0 * 4) % 128 == 0 && ((a.Cin - a.C0) * 4) % 128 == 0) {       // register-split variant: plain GEMM
-            if (a.act) hipLaunchKernelGGL((gemm_split_rs_kernel<BM, BN, true>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((gemm_split_rs_kernel<BM, BN, false>), grid, dim3(256), 0, s, a);
-            VD_HIP(hipGetLastError());
-            return 0;
-        }
-    }
     if (a.ksz == 3) {
         if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, true>), grid, dim3(256), lds, s, a);
