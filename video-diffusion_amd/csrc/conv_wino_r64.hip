@@ -73,6 +73,15 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #ifndef VD_R64_ZERO_EARLY
 #define VD_R64_ZERO_EARLY 1 // accumulators zeroed between the prologue's requests and its wait (0: wherever the compiler puts them)
 #endif
+#ifndef VD_R64_DMA_SPREAD
+#define VD_R64_DMA_SPREAD 1 // the patch requests of a chunk pair one per slot (0: all in one slot; same-box A/B of the conv class 18.41 -> 18.07 ms)
+#endif
+#ifndef VD_R64_WSPREAD
+#define VD_R64_WSPREAD 1    // one weight load per slot (k = 0..5) instead of three in slots 0 and 3 (18.07 -> 17.97 ms)
+#endif
+#ifndef VD_R64_BLATE
+#define VD_R64_BLATE 0      // experiment: weight fragments reloaded 8 slots later (a shorter reload distance: is the loop sensitive to it?)
+#endif
 #ifndef VD_R64_SKIP
 #define VD_R64_SKIP 0      // timing-only builds (results wrong): 1 no split, 2 no transform at all, 4 no weight loads, 16 no patch DMA,
 #endif                     // 64 no MFMA, 128 no patch reads
@@ -133,6 +142,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     // positions behind each request pair: the HBM round trip of the patch, every second chunk).  The request always issues;
     // when it is late it goes through a descriptor of zero records (no memory access, zeros) into the spare fifth buffer.
     const auto xnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, 0, 0x00020000);
+    auto x_dma_one = [&](int chunk, int e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (VD_R64_SKIP & 16) return;
+        const bool live = chunk < nchunk;
+        const int bufi = live ? (chunk & (NB - 1)) : NB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? xsrc : xnull, (lds_ptr)(lds + bufi * XBUF + e * 4096 + wi * 1024), 16, xo[e], chunk * 64, 0, 0);
+#endif
+    };
     auto x_dma = [&](int chunk) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (VD_R64_SKIP & 16) return;
@@ -211,6 +228,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             bfr[j][n][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, so + p * 1024, 0));
+    };
+
+    auto b_load_one = [&](int chunk, int j, int n, int p) {
+        if (VD_R64_SKIP & 4) return;
+        bfr[j][n][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, chunk * ustride + bsb + j * bstep + n * 3072 + p * 1024, 0));
     };
 
     f32x16 acc[2][4][2];                                              // [m][j][n]; zeroed behind the prologue's requests
@@ -310,7 +332,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #if VD_R64_DMA_LATE
                     // the two patches are requested BEHIND this chunk pair's last weight loads: loads return in order, and a
                     // weight fragment requested behind a patch waits for it
+#if VD_R64_DMA_SPREAD == 1
+                    // one request instruction per slot (an LDS-DMA request blocks the wave's issue for ~63 cycles: twelve in one
+                    // slot starve the matrix pipe for the length of eleven MFMAs)
+                    if (m == 0 && cpar == 1 && (j == 0 || j == 1) && k >= 12 - NX) x_dma_one(chunk + 2 + j, k - (12 - NX));   // the last NX slots of positions 0, 1
+#elif VD_R64_DMA_SPREAD == 2
+                    // ... every second slot, over the four positions of group (odd chunk, 0): e = 3 * (j & 1) + (k - 6) / 2
+                    if (m == 0 && cpar == 1 && k >= 6 && !(k & 1) && 3 * (j & 1) + (k - 6) / 2 < NX) x_dma_one(chunk + 2 + (j >> 1), 3 * (j & 1) + (k - 6) / 2);
+#else
                     if (m == 0 && j == 0 && k == 4 && cpar == 1) { x_dma(chunk + 2); x_dma(chunk + 3); }
+#endif
 #endif
                     if (!(VD_R64_SKIP & 64))
                         acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][PA[q]], bfr[j][n][PB[q]], acc[m][j][n], 0, 0, 0);
@@ -330,11 +361,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
                         }
                     }
                     // weights: (j - 1, n) of the next chunk once its last product has issued; (3, n) in position 0 of the next group
-                    if (k == 0 || k == 3) {
-                        const int nn = k == 0 ? 0 : 1;
+#if VD_R64_WSPREAD
+                    if (k < 6) {                                      // one weight load per slot: (n, piece) = (k / 3, k % 3)
+                        if (m == 1 && j > 0) b_load_one(chunk + 1, j - 1, k / 3, k % 3);
+                        if (m == 0 && j == 0) b_load_one(chunk, 3, k / 3, k % 3);
+                    }
+#else
+                    if (k == (VD_R64_BLATE ? 8 : 0) || k == (VD_R64_BLATE ? 11 : 3)) {
+                        const int nn = k == (VD_R64_BLATE ? 8 : 0) ? 0 : 1;
                         if (m == 1 && j > 0) b_load(chunk + 1, j - 1, nn);
                         if (m == 0 && j == 0) b_load(chunk, 3, nn);
                     }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
