@@ -79,9 +79,6 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #ifndef VD_R64_WSPREAD
 #define VD_R64_WSPREAD 1    // one weight load per slot (k = 0..5) instead of three in slots 0 and 3 (18.07 -> 17.97 ms)
 #endif
-#ifndef VD_R64_BLATE
-#define VD_R64_BLATE 0      // experiment: weight fragments reloaded 8 slots later (a shorter reload distance: is the loop sensitive to it?)
-#endif
 #ifndef VD_R64_SKIP
 #define VD_R64_SKIP 0      // timing-only builds (results wrong): 1 no split, 2 no transform at all, 4 no weight loads, 16 no patch DMA,
 #endif                     // 64 no MFMA, 128 no patch reads
@@ -336,9 +333,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
                     // one request instruction per slot (an LDS-DMA request blocks the wave's issue for ~63 cycles: twelve in one
                     // slot starve the matrix pipe for the length of eleven MFMAs)
                     if (m == 0 && cpar == 1 && (j == 0 || j == 1) && k >= 12 - NX) x_dma_one(chunk + 2 + j, k - (12 - NX));   // the last NX slots of positions 0, 1
-#elif VD_R64_DMA_SPREAD == 2
-                    // ... every second slot, over the four positions of group (odd chunk, 0): e = 3 * (j & 1) + (k - 6) / 2
-                    if (m == 0 && cpar == 1 && k >= 6 && !(k & 1) && 3 * (j & 1) + (k - 6) / 2 < NX) x_dma_one(chunk + 2 + (j >> 1), 3 * (j & 1) + (k - 6) / 2);
 #else
                     if (m == 0 && j == 0 && k == 4 && cpar == 1) { x_dma(chunk + 2); x_dma(chunk + 3); }
 #endif
@@ -367,8 +361,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
                         if (m == 0 && j == 0) b_load_one(chunk, 3, k / 3, k % 3);
                     }
 #else
-                    if (k == (VD_R64_BLATE ? 8 : 0) || k == (VD_R64_BLATE ? 11 : 3)) {
-                        const int nn = k == (VD_R64_BLATE ? 8 : 0) ? 0 : 1;
+                    if (k == 0 || k == 3) {
+                        const int nn = k == 0 ? 0 : 1;
                         if (m == 1 && j > 0) b_load(chunk + 1, j - 1, nn);
                         if (m == 0 && j == 0) b_load(chunk, 3, nn);
                     }
