@@ -197,16 +197,53 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
 
     // k-steps in a ring of 3 weight slots (two steps ahead; 2 slots, one step ahead, for the 128x192 tile) and 2 fragment slots (one step ahead); the six piece
     // products of a tile go into its accumulator back to back, small terms first
-    auto kstep = [&](int chunk, int ks, int gslot, int aslot) {          // gslot = (2*chunk + ks) % 3, compile time
+    // Every memory request of a k-step goes out behind its own tile's MFMAs, never in bursts (conv_wino_r64.hip: a burst of
+    // requests blocks the wave's issue and starves the matrix pipe): the weight loads of the step RING - 1 ahead, and in the
+    // first k-step of a chunk the A prefetch and the fragment reads of the second k-step; the second k-step carries the
+    // split + store of the next chunk's rows, one row slice per tile.  (r03n, same-box A/B against the compiler-scheduled loop
+    // with its bursts of 9 + 4 loads: qkv 163 -> 154 us, proj 56.6 -> 52.7, class 6.59 -> 6.30 ms; the 128x192 tile also
+    // stops spilling: 256 registers + 44 bytes of scratch -> 236, none.)
+    auto b_load_one = [&](int slot, int kstep, int idx) {                // idx = j * 3 + p
+        const int j = idx / 3, p2 = idx - 3 * j;
+        bfr[slot][j][p2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p2 * 1024, kstep * ncoblk * 3072, 0));
+    };
+    auto a_prefetch_one = [&](int chunk, int rs, int j) {
+        if constexpr (CONV) {
+            const int tap = chunk / cpt, c = (chunk - tap * cpt) * 32;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const unsigned shift = (unsigned)((kh * a.Ws + kw) * a.Cin * 4);
+            const bool ok = (unsigned)(iy0[j] + kh) < (unsigned)a.Hs && (unsigned)(ix0[j] + kw) < (unsigned)a.Ws;
+            ra[rs][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc0, ok ? ao0[j] + shift : 0x80000000u, c * 4, 0));
+        } else {
+            const int c = chunk * 32;
+            ra[rs][j] = c < a.C0 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc0, ao0[j], c * 4, 0))
+                                 : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc1, ao1[j], (c - a.C0) * 4, 0));
+        }
+    };
+    auto a_frag_one = [&](int slot, const char* Ab, int ks, int idx) {   // idx = i * 3 + p
+        const int i = idx / 3, p2 = idx - 3 * i;
+        afr[slot][i][p2] = *reinterpret_cast<const bf16x8*>(Ab + p2 * PLANE + aoff + i * 32 * SROW + ks * 32);
+    };
+    auto a_store_one = [&](char* Ad, int rs, int j) {
+        f32x4 v = ra[rs][j];
+        if constexpr (ACT) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        bf16x4 p1, p2, p3;
+        split3(v, p1, p2, p3);
+        char* d = Ad + (lrow + 32 * j) * SROW + lq * 8;
+        *reinterpret_cast<bf16x4*>(d) = p1;
+        *reinterpret_cast<bf16x4*>(d + PLANE) = p2;
+        *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = p3;
+    };
+    constexpr int NT = MI * NI;                                            // tiles = slots per k-step
+    auto kstep = [&](int chunk, int ks, int gslot, int aslot, int pf_chunk, int pf_slot, int st_slot) {
         const int g = 2 * chunk + ks;
         const char* Acur = smem_c + (chunk & 1) * ABUF;
-        if (!(VD_GS_SKIP & 1)) b_load((gslot + RING - 1) % RING, min(g + RING - 1, nks - 1));
-        if (ks == 0) a_frags(aslot ^ 1, Acur, 1);
-        __builtin_amdgcn_sched_barrier(0);
+        char* Anext = smem_c + ((chunk + 1) & 1) * ABUF;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
+                const int t = i * NI + j;
                 f32x16 c = acc[i][j];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][1], bfr[gslot][j][1], c, 0, 0, 0);
@@ -215,20 +252,30 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][1], bfr[gslot][j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][0], c, 0, 0, 0);
                 acc[i][j] = c;
+                // this tile's share of the step's requests
+#pragma unroll
+                for (int q = t; q < NI * 3; q += NT)
+                    if (!(VD_GS_SKIP & 1)) b_load_one((gslot + RING - 1) % RING, min(g + RING - 1, nks - 1), q);
+                if (ks == 0) {
+#pragma unroll
+                    for (int q = t; q < AR; q += NT) if (!(VD_GS_SKIP & 2)) a_prefetch_one(pf_chunk, pf_slot, q);
+#pragma unroll
+                    for (int q = t; q < MI * 3; q += NT) a_frag_one(aslot ^ 1, Acur, 1, q);
+                } else {
+#pragma unroll
+                    for (int q = t; q < AR; q += NT) if (!(VD_GS_SKIP & 6)) a_store_one(Anext, st_slot, q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
     };
-    // 3 chunks = 6 k-steps per trip so that ring slots are compile-time constants
     for (int chunk0 = 0; chunk0 < nchunk; chunk0 += 3) {
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
             const int chunk = chunk0 + cc;
             if (chunk < nchunk) {
-                // PF == 3: chunk0 is a multiple of 3, so register slot chunk % 3 == cc; it held this chunk (already in LDS)
                 const int nxt = min(chunk + PF, nchunk - 1);
-                if (!(VD_GS_SKIP & 2)) a_prefetch(nxt, PF == 3 ? cc : 0);
-                kstep(chunk, 0, RING == 2 ? 0 : (2 * cc) % RING, 0);
-                kstep(chunk, 1, RING == 2 ? 1 : (2 * cc + 1) % RING, 1);
-                if (!(VD_GS_SKIP & 6)) a_store(smem_c + ((chunk + 1) & 1) * ABUF, PF == 3 ? (cc + 1) % 3 : 0);
+                kstep(chunk, 0, RING == 2 ? 0 : (2 * cc) % RING, 0, nxt, PF == 3 ? cc : 0, 0);
+                kstep(chunk, 1, RING == 2 ? 1 : (2 * cc + 1) % RING, 1, 0, 0, PF == 3 ? (cc + 1) % 3 : 0);
                 __syncthreads();
                 a_frags(0, smem_c + ((chunk + 1) & 1) * ABUF, 0);
             }
