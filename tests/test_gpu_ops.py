@@ -611,3 +611,27 @@ def test_conv3x3_split_gemm_bf16x6_is_fp32_accurate(N, Cin, Cout, H, stride, res
     e_split, e_fp32 = (got.double() - ref64).abs(), (out_f.double() - ref64).abs()
     assert e_split.max() <= 1.5 * e_fp32.max() + 1e-7, (e_split.max(), e_fp32.max())
     assert e_split.mean() <= 1.5 * e_fp32.mean() + 1e-8, (e_split.mean(), e_fp32.mean())
+
+
+def test_declared_bf16x3_mode_error_bounds():
+    """VD_MATH=bf16x3 (verdict r2 #10): the DECLARED reduced mode -- three of the six piece products, operands effectively
+    rounded to 16 significant bits -- is never the default and never the benchmarked arithmetic; this pins what it costs.
+    The mode is read once per process, so tools/x3_check.py runs as ONE child process: a linear layer and a 3x3 conv
+    against fp64 (relative to the output's RMS: a few 1e-5, i.e. 2^-15-ish per product, averaged down by the
+    contraction), and the whole network -- tiny config and the default 116 M model -- against the reference's goldens at
+    5e-4 of the output's magnitude (the exact mode's tolerance is 1e-4 absolute + relative)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "x3_check.py")], env={**os.environ, "VD_MATH": "bf16x3"},
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "bf16x3" in rep["version"]
+    for op in ("linear", "conv"):
+        assert rep[op]["max_err"] < 3e-4 * rep[op]["ref_rms"] and rep[op]["mean_err"] < 3e-5 * rep[op]["ref_rms"], rep[op]
+        assert rep[op]["mean_err"] > 1e-7 * rep[op]["ref_rms"], "this IS a reduced mode: an error at the exact mode's level means it did not run"
+    for net in ("eps_tiny", "eps_full64"):
+        assert rep[net]["max_err"] < 5e-4 * max(rep[net]["eps_max"], 1.0), rep[net]

@@ -83,7 +83,7 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #define VD_R64_SKIP 0      // timing-only builds (results wrong): 1 no split, 2 no transform at all, 4 no weight loads, 16 no patch DMA,
 #endif                     // 64 no MFMA, 128 no patch reads
 
-template <bool TF4>
+template <bool TF4, bool X3 = false>       // X3: VD_MATH=bf16x3, three of the six piece products (vd_common.h)
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, WinoR64Geom g) {
     using namespace r64;
     using G = R64G<TF4>;
@@ -206,6 +206,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     };
     auto t_split_b = [&](int buf, int pr) {
         if (VD_R64_SKIP & 2) return;
+        if constexpr (X3) {                                           // second piece only: the top halves of the remainders
+            unsigned p2;
+            asm("v_perm_b32 %0, %2, %1, %3" : "=v"(p2) : "v"(rr[2 * pr]), "v"(rr[2 * pr + 1]), "s"(0x07060302u));
+            piece(af[buf][1], pr, p2);
+            return;
+        }
         if (VD_R64_SKIP & 1) { piece(af[buf][1], pr, __builtin_bit_cast(unsigned, tv[2 * pr])); piece(af[buf][2], pr, __builtin_bit_cast(unsigned, tv[2 * pr + 1])); return; }
         unsigned p2, p3;
         split_b(rr[2 * pr], rr[2 * pr + 1], p2, p3, 0x07060302u);
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     };
 
     auto b_load_one = [&](int chunk, int j, int n, int p) {
-        if (VD_R64_SKIP & 4) return;
+        if ((VD_R64_SKIP & 4) || (X3 && p == 2)) return;             // bf16x3 never reads the third weight piece
         bfr[j][n][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, chunk * ustride + bsb + j * bstep + n * 3072 + p * 1024, 0));
     };
 
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
                     if (m == 0 && j == 0 && k == 4 && cpar == 1) { x_dma(chunk + 2); x_dma(chunk + 3); }
 #endif
 #endif
-                    if (!(VD_R64_SKIP & 64))
+                    if (!(VD_R64_SKIP & 64) && !(X3 && (q == 0 || q == 1 || q == 3)))      // bf16x3: (A1,B0) (A0,B1) (A0,B0) only
                         acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][PA[q]], bfr[j][n][PB[q]], acc[m][j][n], 0, 0, 0);
                     // the next position's fragment: position j + 1 of this group, or position 0 of the next one
                     const int jn = (j + 1) & 3;
@@ -562,7 +568,16 @@ int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
         k.out = a.ksplit_ws; k.ldo = a.Cout; k.bias = nullptr; k.fbias = nullptr; k.res = nullptr; k.stats = nullptr;
     }
     const dim3 grid(g.nitems, g.ksplit);
-    if (tf4) hipLaunchKernelGGL(conv3x3_wino_r64_kernel<true>, grid, dim3(256), r64::lds_bytes<true>(), s, k, g);
+    if (x3_math()) {
+        static bool attr3 = false;
+        if (!attr3) {
+            VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr3 = true;
+        }
+        if (tf4) hipLaunchKernelGGL((conv3x3_wino_r64_kernel<true, true>), grid, dim3(256), r64::lds_bytes<true>(), s, k, g);
+        else hipLaunchKernelGGL((conv3x3_wino_r64_kernel<false, true>), grid, dim3(256), r64::lds_bytes<false>(), s, k, g);
+    } else if (tf4) hipLaunchKernelGGL(conv3x3_wino_r64_kernel<true>, grid, dim3(256), r64::lds_bytes<true>(), s, k, g);
     else hipLaunchKernelGGL(conv3x3_wino_r64_kernel<false>, grid, dim3(256), r64::lds_bytes<false>(), s, k, g);
     VD_HIP(hipGetLastError());
     if (g.ksplit > 1) {

@@ -1104,7 +1104,8 @@ extern "C" {
 
 const char* vd_last_error(void) { return g_last_error.c_str(); }
 const char* vd_version(void) {
-    return split_conv() ? "vdamd 0.2 (gfx950; fp32 operands, matrix products as six bf16 piece products with fp32 accumulation)"
+    return x3_math() ? "vdamd 0.2 (gfx950; DECLARED REDUCED MODE VD_MATH=bf16x3: matrix products as three bf16 piece products, operands ~16 significant bits)"
+           : split_conv() ? "vdamd 0.2 (gfx950; fp32 operands, matrix products as six bf16 piece products with fp32 accumulation)"
            : split_math() ? "vdamd 0.2 (gfx950; linear layers as six bf16 piece products, 3x3 convs on the fp32 MFMA)"
                           : "vdamd 0.2 (gfx950, fp32 MFMA)";
 }

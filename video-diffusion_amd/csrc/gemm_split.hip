@@ -45,7 +45,7 @@ __device__ __forceinline__ void split3(f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& 
 // CONV: the A operand is the implicit im2col matrix of a 3x3 convolution (any stride, zero padding 1) over one NHWC
 // source: K runs tap-major (k = tap*Cin + c, the order pack_conv3_split stores), the row of an output pixel moves with
 // the tap, and a tap that falls outside the image reads zeros through the descriptor's range check.
-template <int BM, int BN, bool ACT, bool CONV>
+template <int BM, int BN, bool ACT, bool CONV, bool X3 = false>      // X3: VD_MATH=bf16x3, three of the six piece products (vd_common.h)
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
     // weight ring slots (k-steps ahead = RING - 1): 2 for the 128x192 tile (256 registers per wave), 3 for the others -- and 6
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     // stops spilling: 256 registers + 44 bytes of scratch -> 236, none.)
     auto b_load_one = [&](int slot, int kstep, int idx) {                // idx = j * 3 + p
         const int j = idx / 3, p2 = idx - 3 * j;
+        if (X3 && p2 == 2) return;
         bfr[slot][j][p2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p2 * 1024, kstep * ncoblk * 3072, 0));
     };
     auto a_prefetch_one = [&](int chunk, int rs, int j) {
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     };
     auto a_frag_one = [&](int slot, const char* Ab, int ks, int idx) {   // idx = i * 3 + p
         const int i = idx / 3, p2 = idx - 3 * i;
+        if (X3 && p2 == 2) return;
         afr[slot][i][p2] = *reinterpret_cast<const bf16x8*>(Ab + p2 * PLANE + aoff + i * 32 * SROW + ks * 32);
     };
     auto a_store_one = [&](char* Ad, int rs, int j) {
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         char* d = Ad + (lrow + 32 * j) * SROW + lq * 8;
         *reinterpret_cast<bf16x4*>(d) = p1;
         *reinterpret_cast<bf16x4*>(d + PLANE) = p2;
-        *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = p3;
+        if (!X3) *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = p3;
     };
     constexpr int NT = MI * NI;                                            // tiles = slots per k-step
     auto kstep = [&](int chunk, int ks, int gslot, int aslot, int pf_chunk, int pf_slot, int st_slot) {
@@ -245,9 +247,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
             for (int j = 0; j < NI; ++j) {
                 const int t = i * NI + j;
                 f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][1], bfr[gslot][j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][2], bfr[gslot][j][0], c, 0, 0, 0);
+                if constexpr (!X3) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][1], bfr[gslot][j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][2], bfr[gslot][j][0], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][1], bfr[gslot][j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][0], c, 0, 0, 0);
@@ -341,7 +345,13 @@ template <int BM, int BN>
 static int launch_gs(const IgemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * 3 * BM * SROW;
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.zcount > 1 ? a.zcount : 1);
-    if (a.ksz == 3) {
+    if (x3_math()) {                         // the declared three-product mode (vd_common.h)
+        if (a.ksz == 3) {
+            if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, true, true>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, true, true>), grid, dim3(256), lds, s, a);
+        } else if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, false, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, false, true>), grid, dim3(256), lds, s, a);
+    } else if (a.ksz == 3) {
         if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, true>), grid, dim3(256), lds, s, a);
     } else if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, false>), grid, dim3(256), lds, s, a);

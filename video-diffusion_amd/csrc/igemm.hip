@@ -19,6 +19,8 @@
 //   barrier per K-step.
 #include <algorithm>
 
+#include <string>
+
 #include "vd_common.h"
 
 namespace vd {
@@ -196,6 +198,11 @@ static int launch_t(const IgemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((igemm_kernel<BM, BN>), grid, dim3(256), lds, s, a);
     VD_HIP(hipGetLastError());
     return 0;
+}
+
+bool x3_math() {
+    static const bool v = [] { const char* e = getenv("VD_MATH"); return e && std::string(e) == "bf16x3"; }();
+    return v;
 }
 
 // One launch: every operand of `a` is small enough for the 32-bit byte offsets the kernels address with.

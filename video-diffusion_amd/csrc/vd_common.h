@@ -135,6 +135,10 @@ __device__ __forceinline__ void split_b(float r0, float r1, unsigned& p2, unsign
         : "v"(r0), "v"(r1), "s"(sel));
 }
 
+// VD_MATH=bf16x3: the DECLARED reduced mode (never the default, never the headline): only the three piece products
+// a1*b1 + a1*b2 + a2*b1 of the six -- operands effectively rounded to 16 significant bits (relative error per product
+// <= ~2^-15; the reference itself samples with TF32, 10 bits, allowed: scripts/video_sample.py:21-22).  Read once per process.
+bool x3_math();
 // fp32-accurate Winograd conv on the bf16 matrix cores (conv_wino_s64.hip); weights: [Cin/16][16][Cout/32][3][64][8] bf16
 bool conv_wino_s64_supported(const IgemmArgs& a);        // wsplit == 2
 int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s);
