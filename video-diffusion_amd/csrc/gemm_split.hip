@@ -62,7 +62,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int lrow = tid >> 3, lq = tid & 7;
+    // staging thread -> (row of the tile, 16-byte quad of the 32-wide chunk).  The two 8-lane groups of a 16-lane ds_write_b64
+    // unit take rows FOUR apart (80-byte rows: 4 * 80 B = 16 banks mod 32, i.e. disjoint bank halves); with adjacent rows the
+    // second row wrapped onto four banks of the first and a third of the LDS cycles were conflict cycles (PMC r02l / r03p:
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.34; no measurable time, but it was the one conflict left in the step)
+    const int lgrp = tid >> 3, lrow = ((lgrp >> 1) & 3) + 8 * (lgrp >> 3) + 4 * (lgrp & 1), lq = tid & 7;
     const int cpt = a.Cin >> 5;                                            // chunks per tap
     const int nchunk = CONV ? 9 * cpt : cpt, ncoblk = a.Cout >> 5;
     const int C1 = a.Cin - a.C0;
