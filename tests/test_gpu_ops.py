@@ -359,9 +359,20 @@ def test_attention_spatial_peaked_scores():
 
 @pytest.mark.parametrize("B,T,HW,C,heads,rpe,mask,allow", [(2, 4, 64, 64, 4, True, False, 1), (1, 16, 16, 384, 4, True, True, 1),
                                                            (2, 20, 9, 96, 4, True, True, 0), (1, 5, 33, 32, 4, False, True, 1),
-                                                           (1, 32, 4, 128, 4, True, False, 1), (1, 1, 7, 32, 2, True, False, 1)])
-def test_attention_temporal(B, T, HW, C, heads, rpe, mask, allow):
-    """unet.py:486-536 + RPE einsums :357-378 + mask rule :511-524."""
+                                                           (1, 32, 4, 128, 4, True, False, 1), (1, 1, 7, 32, 2, True, False, 1),
+                                                           # the matrix-pipe kernel (16-pixel blocks, head dim % 16 == 0): one / two frame tiles, ragged T
+                                                           (2, 20, 32, 384, 4, True, True, 0), (1, 16, 64, 512, 4, True, True, 1),
+                                                           (2, 7, 16, 128, 2, False, True, 1), (1, 32, 16, 256, 4, True, False, 1),
+                                                           (1, 17, 48, 192, 4, True, True, 0), (1, 3, 16, 64, 4, True, True, 1),
+                                                           (8, 16, 256, 384, 4, True, False, 1), (2, 20, 64, 512, 4, False, True, 1)])
+@pytest.mark.parametrize("kernel", ["auto", "mfma"])
+def test_attention_temporal(B, T, HW, C, heads, rpe, mask, allow, kernel, monkeypatch):
+    """unet.py:486-536 + RPE einsums :357-378 + mask rule :511-524.  `auto`: the launcher's choice (4-pixel VALU blocks for
+    grids that would not fill the chip, ragged pixel counts or head dims); `mfma`: the 16-pixel matrix-pipe kernel forced."""
+    if kernel == "mfma":
+        if HW % 16 or (C // heads) % 16 or C // heads > 128:
+            pytest.skip("shape not served by the matrix-pipe kernel")
+        monkeypatch.setenv("VD_ATTN_T", "mfma")
     qkv = rnd(B, T, HW, 3 * C) * 1.5
     Rk, Rq, Rv = (rnd(B, T, T, C, seed=s) for s in (1, 2, 3))
     m = None

@@ -14,6 +14,8 @@
 // keeps Rv[t, :, f4] in registers.  RPE is a template parameter: no branch around a load in any loop.
 // VALU kernel: T*T*F per (pixel, head) is too ragged for 32x32 MFMA tiles and is 0.2 % of step FLOPs.
 #include "vd_common.h"
+#include <cstdlib>
+#include <string>
 
 namespace vd {
 
@@ -124,6 +126,363 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(AttnTemporalArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same operator on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, 32 cycles per 16x16x4).
+//
+// The three relative-position contractions are GEMMs once the PIXELS are the M dimension: for a fixed query frame t,
+// q'[t, px, :] . Rk[t, s, :] is (16 px x F) x (F x T); for a fixed key frame s, k[s, px, :] . Rq[s, t, :] likewise, and
+// for a fixed t  a[px, t, :] . Rv[t, :, f]  is (16 px x T) x (T x F).  q k^T and a v are per-pixel (T x F) x (F x T) /
+// (T x T) x (T x F) products.  One block = 16 pixels of one (batch, head), four waves:
+//
+//   A1  wave w: q' k^T of pixels 4w..4w+3 (M = t, N = s)                       -> LDS  w[px][t][s]
+//   A2  wave w: frames t = w, w+4, ..: accumulator preloaded from w[.][t][.] (M = px, N = s), + q'.Rk, stored back
+//   A3  wave w: frames s = w, w+4, ..: the same with M = px, N = t, + k.Rq'
+//   softmax over s, one (px, t) row per thread (mask rule of unet.py:511-524), probabilities back into w
+//   B   wave w: feature tiles w, w+4, .. of 16: a v for all 16 pixels (M = t, N = f; 16 independent accumulators), then the
+//       (tile = px, lane group = t/4, register = t%4) image is turned into (tile = t, lane group = px/4, register = px%4)
+//       in registers -- a 4x4 transpose between lane rows and registers, v_permlane16_swap + v_permlane32_swap -- which is
+//       the accumulator layout of the a.Rv product (M = px) of every frame t; its result goes to HBM (64-byte runs).
+//
+// Operands are read from L2 straight into fragment layout.  The k index of an MFMA step is free to permute as long as A
+// and B agree, so a lane reads 16 bytes (features 16j + 4*(lane/16) .. +3) and feeds one element to each of four steps.
+// Frames past T (T not a multiple of 16) are clamped on load and carry probability 0.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef VD_ATT_TIMING
+__device__ unsigned long long g_att_stamp[16];
+#define ATT_STAMP(i)                                                                                   \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x == 3 && blockIdx.y == 1 && blockIdx.z == 2) {               \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            g_att_stamp[i] = __builtin_amdgcn_s_memrealtime();                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+        }                                                                                              \
+    } while (0)
+extern "C" int vd_debug_att_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_att_stamp), sizeof(g_att_stamp));
+}
+#else
+#define ATT_STAMP(i)
+#endif
+
+__device__ __forceinline__ f32x4 mfma4(float x, float y, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c, 0, 0, 0); }
+
+// X[a] (register a, lane row c) -> X[c] (register c, lane row a): rows of 16 lanes
+__device__ __forceinline__ void rows_regs_transpose(float& x0, float& x1, float& x2, float& x3) {
+    auto u = [](float f) { return __builtin_bit_cast(unsigned, f); };
+    auto f = [](unsigned v) { return __builtin_bit_cast(float, v); };
+    auto p01 = __builtin_amdgcn_permlane16_swap(u(x0), u(x1), false, false);
+    auto p23 = __builtin_amdgcn_permlane16_swap(u(x2), u(x3), false, false);
+    auto q02 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+    auto q13 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+    x0 = f(q02[0]); x2 = f(q02[1]); x1 = f(q13[0]); x3 = f(q13[1]);
+}
+
+template <int NT, int JM, bool RPE, bool EXACT>            // EXACT: F == 16*JM and T == 16*NT -- no guard around any request (a
+// conditional request makes hipcc wait for ALL outstanding loads at the next use, which voids the requests made ahead)
+__global__ __launch_bounds__(512) void attn_temporal_mfma_kernel(AttnTemporalArgs a) {
+    constexpr int TP = 16 * NT, RS = TP + 1, PS = TP * RS + (NT == 1 ? 1 : 17);   // pixel stride = 17 mod 32 banks
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* w = smem;                                        // [16 px][PS]: row (t) stride RS
+    const int T = EXACT ? 16 * NT : a.T, C = a.C, HW = a.HW, C3 = 3 * a.C;
+    const int F = C / a.heads, NJ = EXACT ? JM : F >> 4;    // <= JM
+    const int b = blockIdx.z, h = blockIdx.y, p0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, i16 = l & 15, g = l >> 4;
+    const float* qb = a.qkv + ((size_t)b * T * HW + p0) * C3 + h * F;
+    auto row = [&](int t, int px) { return qb + ((size_t)t * HW + px) * C3; };
+    auto ld4 = [](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
+    const int tcl[2] = {min(i16, T - 1), min(16 + i16, T - 1)};                    // this lane's frame in tile 0 / 1, clamped
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- A: the three score terms, all in ONE walk over the features.  Each wave owns pixels 2w, 2w+1 of q' k^T (M = t, N = s)
+    //      and frames w, w+8 (, w+16, w+24) of q'.Rk (M = px, N = s) and of k.Rq' (M = px, N = t): q and k are needed in two
+    //      fragment layouts, and requesting both inside the same feature group makes the second request an L2 hit (first
+    //      build, term after term: 70 % L2 misses, the tensor fetched from HBM / MALL twice).  The operands of a feature
+    //      group are requested together and, for one frame tile, one group ahead of their MFMAs.
+    ATT_STAMP(0);
+    constexpr int JG = NT == 1 ? 2 : 1, NG = JM / JG, NU = 2 * NT;
+    constexpr bool AHEAD = NT == 1;
+    struct Ops { f32x4 qa1[2][NT][JG], kb1[2][NT][JG], xa2[NU][JG], rb2[NU][NT][JG], xa3[NU][JG], rb3[NU][NT][JG]; };
+    f32x4 acc1[2][NT][NT], acc2[NU][NT], acc3[NU][NT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc1[u][m][n] = zero4;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { acc2[u][n] = zero4; acc3[u][n] = zero4; }
+    const float* q1[2][NT];                                  // row (frame tcl[m], pixel 2w+u): q at +0, k at +C
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) q1[u][m] = row(tcl[m], 2 * wv + u) + 4 * g;
+    const float* rkq[NT];                                    // + t*T*C: row (t, s = tcl[n]) of Rk / (s, t = tcl[n]) of Rq
+#pragma unroll
+    for (int n = 0; n < NT; ++n) rkq[n] = (size_t)b * T * T * C + (size_t)tcl[n] * C + h * F + 4 * g + (const float*)nullptr;
+    auto request = [&](Ops& o, int grp, bool own, bool rel) {   // own: q' k^T operands; rel: those of the two relative-position terms
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) {
+            const int j = grp * JG + jj;
+            if (EXACT || j < NJ) {
+                if (own) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) { o.qa1[u][m][jj] = ld4(q1[u][m] + 16 * j); o.kb1[u][m][jj] = ld4(q1[u][m] + C + 16 * j); }
+                }
+                if constexpr (RPE) {
+#pragma unroll
+                    for (int u = 0; u < (rel ? NU : 0); ++u) {
+                        const int t = wv + 8 * u;
+                        if (EXACT || t < T) {
+                            const float* xr = row(t, i16) + 4 * g + 16 * j;
+                            o.xa2[u][jj] = ld4(xr);
+                            o.xa3[u][jj] = ld4(xr + C);
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) {
+                                const size_t ro = (size_t)(rkq[n] - (const float*)nullptr) + (size_t)t * T * C + 16 * j;
+                                o.rb2[u][n][jj] = ld4(a.Rk + ro);
+                                o.rb3[u][n][jj] = ld4(a.Rq + ro);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    auto products = [&](const Ops& o, int grp, bool own, bool rel) {
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) {
+            if (EXACT || grp * JG + jj < NJ) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int u = 0; u < (own ? 2 : 0); ++u)
+#pragma unroll
+                        for (int m = 0; m < NT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) acc1[u][m][n] = mfma4(o.qa1[u][m][jj][e] * a.scale, o.kb1[u][n][jj][e], acc1[u][m][n]);
+                    if constexpr (RPE) {
+#pragma unroll
+                        for (int u = 0; u < (rel ? NU : 0); ++u)
+                            if (EXACT || wv + 8 * u < T) {
+#pragma unroll
+                                for (int n = 0; n < NT; ++n) {
+                                    acc2[u][n] = mfma4(o.xa2[u][jj][e] * a.scale, o.rb2[u][n][jj][e], acc2[u][n]);
+                                    acc3[u][n] = mfma4(o.xa3[u][jj][e], o.rb3[u][n][jj][e] * a.scale, acc3[u][n]);
+                                }
+                            }
+                    }
+                }
+            }
+        }
+    };
+    if constexpr (AHEAD) {
+        Ops o[2];
+        request(o[0], 0, true, true);
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            if (grp + 1 < NG) request(o[(grp + 1) & 1], grp + 1, true, true);
+            __builtin_amdgcn_sched_barrier(0);               // the scheduler otherwise sinks every request to two loads before its use
+            products(o[grp & 1], grp, true, true);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {                                                 // two frame tiles: the registers hold one half of a group's operands at a time
+#pragma unroll 1
+        for (int grp = 0; grp < NG; ++grp) {
+            Ops o;
+            request(o, grp, true, false);
+            products(o, grp, true, false);
+            if constexpr (RPE) {
+                request(o, grp, false, true);
+                products(o, grp, false, true);
+            }
+        }
+    }
+    ATT_STAMP(1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[(2 * wv + u) * PS + (16 * m + 4 * g + r) * RS + 16 * n + i16] = acc1[u][m][n][r];
+    __syncthreads();
+    if constexpr (RPE) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int t = wv + 8 * u;
+            if (t < T) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[(4 * g + r) * PS + t * RS + 16 * n + i16] += acc2[u][n][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int sk = wv + 8 * u;
+            if (sk < T) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[(4 * g + r) * PS + (16 * n + i16) * RS + sk] += acc3[u][n][r];
+            }
+        }
+        __syncthreads();
+    }
+
+    ATT_STAMP(2);
+    // ---- row softmax (fp32, like th.softmax(w.float())); columns T..TP-1 and rows >= T become 0
+    for (int rix = tid; rix < 16 * TP; rix += 512) {
+        const int px = rix / TP, t = rix - px * TP;
+        float* r = w + px * PS + t * RS;
+        if (t >= T) {
+            for (int s = 0; s < TP; ++s) r[s] = 0.f;
+            continue;
+        }
+        float mx = -INFINITY;
+        const float mt = a.mask ? a.mask[b * T + t] : 1.f;
+        for (int s = 0; s < T; ++s) {
+            float v = r[s];
+            if (a.mask) {
+                const float ms = a.mask[b * T + s];
+                float allowed = mt * ms;
+                if (a.allow_pad) allowed += (1.f - mt) * (1.f - ms);
+                else if (t == s) allowed = 1.f;
+                if (allowed == 0.f) v = -INFINITY;
+            }
+            r[s] = v;
+            mx = fmaxf(mx, v);
+        }
+        float sum = 0.f;
+        for (int s = 0; s < T; ++s) { const float e = __expf(r[s] - mx); r[s] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int s = 0; s < T; ++s) r[s] *= inv;
+        for (int s = T; s < TP; ++s) r[s] = 0.f;
+    }
+    __syncthreads();
+
+    ATT_STAMP(3);
+    // ---- B: o[t] = sum_s a[t,s] (v_s + Rv[t,s]); wave w owns features 16w .. 16w+15 of the head
+    const int KS = (T + 3) >> 2;                                                           // k steps of the probability products
+    if (EXACT ? wv < JM : wv < NJ) {
+        const int f0 = 16 * wv + i16;
+        const float* vb = qb + 2 * C + f0;                                                 // + (s*HW + px)*C3
+        const float* rvb = RPE ? a.Rv + ((size_t)b * T) * T * C + h * F + f0 : nullptr;    // + (t*T + s)*C
+#pragma unroll 1
+        for (int m = 0; m < NT; ++m) {
+            if (16 * m >= T) break;
+            float rr[NT == 1 ? 4 : 1][16];
+            f32x4 acc[16];
+#pragma unroll
+            for (int px = 0; px < 16; ++px) acc[px] = zero4;
+#pragma unroll 1
+            for (int kc = 0; kc < NT; ++kc) {                                              // four k steps (16 key frames) at a time
+                if (16 * kc >= T) break;
+                float vr[4][16];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+                    if (EXACT || 4 * kc + k4 < KS) {
+                        const float* vs = vb + (size_t)min(16 * kc + 4 * k4 + g, T - 1) * HW * C3;
+#pragma unroll
+                        for (int px = 0; px < 16; ++px) vr[k4][px] = vs[(size_t)px * C3];
+                    }
+                if constexpr (RPE && NT == 1) {                                            // the a.Rv operands ride along (registers allow it for one frame tile)
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4)
+                        if (EXACT || k4 < KS) {
+                            const float* rv = rvb + (size_t)min(4 * k4 + g, T - 1) * C;
+#pragma unroll
+                            for (int tl = 0; tl < 16; ++tl) rr[k4][tl] = rv[(size_t)min(tl, T - 1) * T * C];
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+                    if (EXACT || 4 * kc + k4 < KS) {
+                        const float* ar = w + (16 * m + i16) * RS + 16 * kc + 4 * k4 + g;
+#pragma unroll
+                        for (int px = 0; px < 16; ++px) acc[px] = mfma4(ar[px * PS], vr[k4][px], acc[px]);
+                    }
+            }
+            ATT_STAMP(4);
+            // (tile px = 4A+Bq, row c, reg d) = o[px][t = 16m + 4c + d]  ->  (tile tl = 4c+d, row A, reg Bq) = o[px = 4A+Bq][t = 16m + tl]
+            f32x4 res[16];
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    float x0 = acc[bq][d], x1 = acc[4 + bq][d], x2 = acc[8 + bq][d], x3 = acc[12 + bq][d];
+                    rows_regs_transpose(x0, x1, x2, x3);
+                    res[d][bq] = x0; res[4 + d][bq] = x1; res[8 + d][bq] = x2; res[12 + d][bq] = x3;
+                }
+            if constexpr (RPE) {
+                if constexpr (NT == 1) {
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4)
+                        if (EXACT || k4 < KS) {
+                            const float* ar = w + i16 * PS + 4 * k4 + g;
+#pragma unroll
+                            for (int tl = 0; tl < 16; ++tl) res[tl] = mfma4(ar[tl * RS], rr[k4][tl], res[tl]);
+                        }
+                } else {
+#pragma unroll 1
+                    for (int kc = 0; kc < NT; ++kc) {
+                        if (16 * kc >= T) break;
+                        float r4[4][16];
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4)
+                            if (4 * kc + k4 < KS) {
+                                const float* rv = rvb + (size_t)min(16 * kc + 4 * k4 + g, T - 1) * C;
+#pragma unroll
+                                for (int tl = 0; tl < 16; ++tl) r4[k4][tl] = rv[(size_t)min(16 * m + tl, T - 1) * T * C];
+                            }
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4)
+                            if (4 * kc + k4 < KS) {
+                                const float* ar = w + i16 * PS + (16 * m) * RS + 16 * kc + 4 * k4 + g;
+#pragma unroll
+                                for (int tl = 0; tl < 16; ++tl) res[tl] = mfma4(ar[tl * RS], r4[k4][tl], res[tl]);
+                            }
+                    }
+                }
+            }
+            ATT_STAMP(5);
+#pragma unroll
+            for (int tl = 0; tl < 16; ++tl) {
+                const int t = 16 * m + tl;
+                if (t < T) {
+                    float* o = a.out + (((size_t)b * T + t) * HW + p0 + 4 * g) * C + h * F + f0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[(size_t)r * C] = res[tl][r];
+                }
+            }
+        }
+    }
+    ATT_STAMP(6);
+}
+
+template <int NT, int JM, bool RPE, bool EXACT>
+static int launch_tm(const AttnTemporalArgs& a, hipStream_t s) {
+    constexpr int TP = 16 * NT, PS = TP * (TP + 1) + (NT == 1 ? 1 : 17);
+    constexpr size_t lds = (size_t)16 * PS * sizeof(float);
+    static bool attr = false;
+    if (!attr && lds > 48 * 1024) {
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_mfma_kernel<NT, JM, RPE, EXACT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    dim3 grid(a.HW / 16, a.heads, a.B);
+    hipLaunchKernelGGL((attn_temporal_mfma_kernel<NT, JM, RPE, EXACT>), grid, dim3(512), lds, s, a);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int PB, int TMAX, bool RPE>
 static int launch_tt(const AttnTemporalArgs& a, size_t lds, hipStream_t s) {
     static size_t attr = 0;
@@ -143,6 +502,21 @@ int launch_attn_temporal(const AttnTemporalArgs& a, hipStream_t s) {
     VD_REQUIRE(a.C % a.heads == 0 && (a.C / a.heads) % 8 == 0, "head dim multiple of 8");
     VD_REQUIRE((a.Rk == nullptr) == (a.Rq == nullptr) && (a.Rk == nullptr) == (a.Rv == nullptr), "all or no RPE terms");
     const int F = a.C / a.heads;
+    static const bool valu_only = [] { const char* e = getenv("VD_ATTN_T"); return e && std::string(e) == "valu"; }();   // A/B switch
+    // 16-pixel blocks: a B = 1 shard has 64 of them at 16x16 and the VALU kernel's 4-pixel blocks fill the chip better
+    // (same-box A/B, B = 1 x T = 16 step: 5.87 ms against 5.95 with this kernel)
+    const bool fills = (long)(a.HW / 16) * a.heads * a.B >= 128 || (getenv("VD_ATTN_T") && std::string(getenv("VD_ATTN_T")) == "mfma");
+    if (!valu_only && fills && a.HW % 16 == 0 && F % 16 == 0 && F <= 128) {           // the matrix-pipe kernel: 16-pixel blocks, 16-feature k steps, one feature tile per wave
+        const bool rpe = a.Rk != nullptr;
+        if (a.T == 16 && F == 96) return rpe ? launch_tm<1, 6, true, true>(a, s) : launch_tm<1, 6, false, true>(a, s);     // the default models' two shapes
+        if (a.T == 16 && F == 128) return rpe ? launch_tm<1, 8, true, true>(a, s) : launch_tm<1, 8, false, true>(a, s);
+        if (a.T <= 16) {
+            if (F <= 64) return rpe ? launch_tm<1, 4, true, false>(a, s) : launch_tm<1, 4, false, false>(a, s);
+            return rpe ? launch_tm<1, 8, true, false>(a, s) : launch_tm<1, 8, false, false>(a, s);
+        }
+        if (F <= 64) return rpe ? launch_tm<2, 4, true, false>(a, s) : launch_tm<2, 4, false, false>(a, s);
+        return rpe ? launch_tm<2, 8, true, false>(a, s) : launch_tm<2, 8, false, false>(a, s);
+    }
     auto lds_for = [&](int pb) { return ((size_t)2 * pb * a.T * (F + 4) + (size_t)pb * a.T * (a.T + 1)) * sizeof(float); };
     const bool rpe = a.Rk != nullptr;
     const bool big = lds_for(4) > 96 * 1024;
