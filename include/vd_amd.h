@@ -171,6 +171,19 @@ int vd_window_run(vd_engine* e, int n_steps, void* stream);
 unsigned long long vd_window_generation(vd_engine* e);
 int vd_window_graphs(vd_engine* e);            /* captured graphs held by the engine */
 
+/* Window prefix cache (opt-in, off by default; a host-side choice like the executor itself).  The reference recomputes the
+ * whole UNet for every frame at every step (unet.py:838-846).  Before the first attention layer the network treats frames as
+ * independent batch entries (input_blocks 0 .. first attention block - 1: ResBlocks / Downsample, per-frame GroupNorm), and in
+ * 'x_0' mode with the default cond_emb_type='channel' an OBSERVED frame's input there never changes during a window: its x0
+ * pixels, the indicator channels and the timestep-0 embedding (unet.py:991-1013).  With the cache on, vd_window_begin runs
+ * those blocks for the observed frames (obs_mask = 1, latent_mask = 0) once, into persistent full-size tensors, and the
+ * captured step runs them on the remaining frames only (a compact batch), scatters each block output and its GroupNorm
+ * partial sums beside the cached rows and continues with the full batch (attention, decoder skips).  Same arithmetic per
+ * frame; the GroupNorm partial sums of a tensor are folded in a different (fp64) grouping.  The set of cached frames is part
+ * of the graph signature.  vd_window_prefix_frames: how many frames of the armed window are served from the cache. */
+int vd_set_window_prefix_cache(vd_engine* e, int on);
+int vd_window_prefix_frames(vd_engine* e);
+
 /* The posterior arithmetic alone, given eps (same formulas; mode 0 p_sample, 1 ddim). */
 int vd_posterior_update(vd_engine* e, int mode, int B, long long per_sample, const float* x, const float* eps,
                         const long long* t, int clip_denoised, float eta, const float* noise,

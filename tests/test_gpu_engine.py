@@ -707,6 +707,45 @@ def test_window_executor_equals_eager_steps_bit_for_bit():
     model.check_device_errors()
 
 
+def test_window_prefix_cache_matches_the_uncached_window():
+    """vd_set_window_prefix_cache (opt-in): the observed frames' activations before the first attention layer are computed
+    once per window, the captured step runs those blocks on the other frames only.  Per frame it is the same arithmetic
+    (the GroupNorm partial sums are folded in another fp64 grouping): every window must follow the uncached executor's
+    trajectory (same Philox stream) far inside the 1e-4 parity tolerance.  Covered: a second window with the same frame
+    set but new contents (same graph, cache rebuilt), another frame set (new graph), per-item frame sets, a padding frame
+    (any = 0: depends on x, not cacheable), 'x_t' mode and a window without observed frames (cache not applicable), and a
+    model with the skip convolutions / scale-shift off."""
+    from video_diffusion_amd.executor import WindowExecutor
+    for extra in (dict(), dict(use_scale_shift_norm=False)):
+        cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=6, image_size=32, num_channels=64, num_res_blocks=1,
+                                                                  rp_alpha=6, rp_beta=6, rp_gamma=6, timestep_respacing="ddim10"), **extra}
+        model, diff = engine(cfg)
+        plain, cached = WindowExecutor(model, diff), WindowExecutor(model, diff, prefix_cache=True)
+        for wi, (B, T, n_obs, obsf, tweak) in enumerate([(2, 6, 2, "x_0", None), (2, 6, 2, "x_0", None), (2, 6, 3, "x_0", None),
+                                                         (2, 6, 2, "x_0", "per_item"), (2, 6, 2, "x_0", "padding"),
+                                                         (2, 6, 2, "x_t", None), (2, 6, 0, "x_0", None), (3, 5, 4, "x_0", None)]):
+            c = _rand_window(B, T, 32, n_obs, seed=70 + wi)
+            n_cached = B * n_obs
+            if tweak == "per_item":                                    # item 1 also observes frame 4
+                c["obs_mask"][1, 4] = 1; c["latent_mask"][1, 4] = 0
+                c["x0"][1, 4] = torch.rand(3, 32, 32) * 2 - 1
+                n_cached += 1
+            if tweak == "padding":                                     # frame 5 of item 0 is in no mask
+                c["latent_mask"][0, 5] = 0
+            if obsf == "x_t":
+                n_cached = 0
+            kw = kwargs_of(c, observed_frames=obsf)
+            x_init = c["x"].cuda().clone()
+            want = plain.begin(x_init, kw, seed=900 + wi).run().clone()
+            cached.begin(x_init, kw, seed=900 + wi)
+            assert cached.cached_frames == n_cached, (wi, cached.cached_frames, n_cached)
+            mid = cached.run(4).clone()
+            got = cached.run().clone()
+            assert torch.isfinite(got).all() and not torch.equal(mid, got)
+            close(got.cpu(), want.cpu(), atol=2e-6, rtol=2e-6)
+    model.check_device_errors()
+
+
 def test_window_executor_survives_a_rebound_schedule_and_refuses_interleaving():
     """One model, two diffusions (ddim10, then ddim5, then ddim10 again): vd_set_schedule frees the tables a captured
     graph holds as kernel arguments, so it must drop the graphs; same-size executor buffers land on the same addresses,

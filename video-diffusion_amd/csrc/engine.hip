@@ -185,6 +185,20 @@ struct FwdIn {
     float* eps;
 };
 
+// Window prefix cache (vd_window_begin, opt-in).  The input blocks before the first attention layer treat frames as
+// independent batch entries, and in 'x_0' mode an observed frame's network input (its x0 pixels, the indicator channels, the
+// timestep 0 embedding) does not change over the steps of a window: its activations there are computed once per window.
+// A forward with a plan runs those blocks on the `n` listed frames only (a compact batch), scatters every block output --
+// and its GroupNorm partial sums -- into a persistent full-size tensor that already holds the other frames' rows, and
+// carries on from there with the full batch.
+struct PrefixStore { std::vector<float*> tens; std::vector<double*> parts; std::vector<size_t> floats; };
+struct PrefixPlan {
+    int n = 0;                       // frames in the list
+    const int* list = nullptr;       // device: compact index -> frame
+    bool build_only = false;         // stop behind the prefix (the once-per-window pass over the observed frames)
+    PrefixStore* store = nullptr;
+};
+
 }  // namespace vd
 
 using namespace vd;
@@ -235,7 +249,20 @@ struct vd_engine {
         const void *x, *obs_src, *obs, *lat, *km, *fidx;
         bool operator==(const WinKey& o) const { return std::memcmp(this, &o, sizeof(WinKey)) == 0; }
     };
-    struct WinGraph { WinKey key; hipGraph_t graph; hipGraphExec_t exec; };
+    struct WinGraph {
+        WinKey key; hipGraph_t graph; hipGraphExec_t exec;
+        // window prefix cache: which frames are step-invariant (part of the signature: the compact batch size is baked into the
+        // captured launches), the two device lists and the persistent tensors the captured step reads and writes
+        std::vector<unsigned char> inv; int n_inv = 0;
+        int* d_lists = nullptr;                  // [n_act active frames | n_inv invariant frames]
+        PrefixStore* store = nullptr;
+    };
+    bool prefix_cache_on = false;                // vd_set_window_prefix_cache
+    static void free_graph(WinGraph& g) {
+        (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph);
+        if (g.d_lists) (void)hipFree(g.d_lists);
+        if (g.store) { for (float* p : g.store->tens) if (p) (void)hipFree(p); for (double* p : g.store->parts) if (p) (void)hipFree(p); delete g.store; }
+    }
     std::vector<WinGraph> win_graphs;
     int win_cur = -1;
     bool win_lost = false;                               // the armed window's graph was dropped (workspace growth / new schedule)
@@ -254,7 +281,7 @@ struct vd_engine {
         if (d_part) (void)hipFree(d_part);
         if (d_win_t) (void)hipFree(d_win_t);
         if (d_win_rng) (void)hipFree(d_win_rng);
-        for (auto& g : win_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+        for (auto& g : win_graphs) free_graph(g);
     }
 
     // Captured window graphs bake addresses (workspace, schedule tables, step counters) and values (num_timesteps, rescale)
@@ -263,7 +290,7 @@ struct vd_engine {
     void drop_window_graphs() {
         if (win_graphs.empty()) { win_cur = -1; return; }
         (void)hipDeviceSynchronize();
-        for (auto& g : win_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+        for (auto& g : win_graphs) free_graph(g);
         win_graphs.clear();
         win_cur = -1;
     }
@@ -297,7 +324,7 @@ struct vd_engine {
     }
 
     int build();
-    int forward(const FwdIn& in, hipStream_t st, Arena& ar);
+    int forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixPlan* pp = nullptr);
     int ensure_ws(int B, int T);
     int res_block(const ResP& r, Tens x0, const Tens* x1, int N, const float* film_all, const float* emb_unused,
                   hipStream_t st, Arena& ar, Tens* out);
@@ -762,10 +789,12 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
 }
 
 // ------------------------------------------------------------------------------------------ forward
-int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
+int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixPlan* pp) {
     const int B = in.B, T = in.T, N = B * T, S = cfg.image_size, mc = cfg.num_channels;
     int rc;
-    float* x8 = ar.get<float>((size_t)N * S * S * STEM_KPAD);       // im2col of the network input
+    VD_REQUIRE(!pp || (!tape && !ar.dry && pp->store && n_before_attn > 0), "prefix plan: executor steps only");
+    const int Npre = pp ? pp->n : N;                                 // frames the blocks before the first attention layer run on
+    float* x8 = ar.get<float>((size_t)Npre * S * S * STEM_KPAD);    // im2col of the network input
     float* tfr = ar.get<float>(N);
     float* amask = ar.get<float>(N);
     float* tsin = ar.get<float>((size_t)N * mc);
@@ -778,6 +807,11 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
     if (!ar.dry) {
         VD_REQUIRE(d_freq_time && n_freq_time == mc / 2, "vd_set_freqs not called (time frequencies)");
         AssembleArgs aa{in.x, in.obs_src, in.obs, in.lat, in.km, in.t_model, in.obs_mode, B, T, S, S, STEM_KPAD, cfg.cond_emb_type, x8, tfr, amask};
+        if (pp) {                                                    // per-frame scalars of every frame, im2col of the listed ones
+            AssembleArgs sc = aa; sc.scalars_only = 1;
+            if ((rc = launch_assemble(sc, st))) return rc;
+            aa.frame_list = pp->list; aa.n_list = pp->n;
+        }
         if ((rc = launch_assemble(aa, st))) return rc;
         if ((rc = launch_sinus_embed(tfr, N, mc, d_freq_time, tsin, st))) return rc;
         if ((rc = linear(tsin, N, mc, 0, 0, E, W(p_te0w), W(p_te0b), 0, nullptr, e1, st))) return rc;
@@ -795,7 +829,15 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
     attn_seq = 0;
     std::vector<Tens> hs;
     Tens h{x8, STEM_KPAD, S};
+    int Nrun = Npre;                                                 // batch of the block being run: Npre in the prefix, N behind it
+    const float* film_full = film;
+    if (pp) {                                                        // FiLM rows of the listed frames, compactly
+        float* fc = ar.get<float>((size_t)std::max(Npre, 1) * film_total);
+        if ((rc = launch_gather_rows(film_full, pp->list, Npre, film_total, fc, st))) return rc;
+        film = fc;
+    }
     auto run = [&](const std::vector<Layer>& blk, Tens in0, const Tens* in1, Tens* outp) -> int {
+        const int N = Nrun;
         Tens cur = in0;
         const Tens* second = in1;
         for (const Layer& L : blk) {
@@ -839,8 +881,38 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar) {
         return 0;
     };
     for (size_t i = 0; i < input_blocks.size(); ++i) {
-        if ((rc = run(input_blocks[i], h, nullptr, &h))) return rc;
-        hs.push_back(h);
+        if (pp && (int)i < n_before_attn) {
+            // compact batch -> this block's persistent full-size tensor (allocated by the window's first pass, outside the arena)
+            Tens hc{};
+            if (Npre > 0 && (rc = run(input_blocks[i], h, nullptr, &hc))) return rc;
+            PrefixStore& ps = *pp->store;
+            if (ps.tens.size() <= i) { ps.tens.resize(i + 1, nullptr); ps.parts.resize(i + 1, nullptr); ps.floats.resize(i + 1, 0); }
+            if (Npre == 0) { VD_REQUIRE(ps.tens[i], "prefix cache: no tensor to reuse"); }
+            else {
+                const size_t per = (size_t)hc.H * hc.H * hc.C;
+                if (!ps.tens[i]) {
+                    VD_REQUIRE(pp->build_only, "prefix cache: the window's first pass allocates");
+                    VD_HIP(hipMalloc(reinterpret_cast<void**>(&ps.tens[i]), (size_t)N * per * sizeof(float)));
+                    ps.floats[i] = per | ((size_t)hc.C << 40) | ((size_t)hc.H << 52);
+                    if (hc.part) VD_HIP(hipMalloc(reinterpret_cast<void**>(&ps.parts[i]), (size_t)N * hc.C * 2 * sizeof(double)));
+                }
+                VD_REQUIRE((ps.parts[i] != nullptr) == (hc.part != nullptr), "prefix cache: statistics table");
+                if ((rc = launch_scatter_rows(hc.p, pp->list, Npre, per, ps.tens[i], st))) return rc;
+                if (hc.part && (rc = launch_scatter_stats(hc.part, hc.split, hc.C, pp->list, Npre, ps.parts[i], st))) return rc;
+            }
+            const int Cc = (int)((ps.floats[i] >> 40) & 0xfff), Hc = (int)(ps.floats[i] >> 52);
+            Tens full{ps.tens[i], Cc, Hc, ps.parts[i], ps.parts[i] ? 1 : 0};
+            if ((int)i + 1 == n_before_attn) {
+                if (pp->build_only) return 0;
+                h = full; Nrun = N; film = const_cast<float*>(film_full);
+            } else {
+                h = hc;                                              // the next prefix block continues on the compact batch
+            }
+            hs.push_back(full);
+        } else {
+            if ((rc = run(input_blocks[i], h, nullptr, &h))) return rc;
+            hs.push_back(h);
+        }
         if ((int)i + 1 == n_before_attn && (cfg.use_spatial_encoding || cfg.use_frame_encoding)) {
             // added AFTER the skip push (unet.py:815-818): the skip keeps the un-encoded tensor
             const size_t n = (size_t)N * h.H * h.H * h.C;
@@ -1380,7 +1452,7 @@ static int step_launches(vd_engine* e, int mode, int B, int T, const float* x, c
                          const float* lat, const float* km, const long long* fidx, const long long* t, int obs_mode,
                          int clip, float eta, const float* noise, unsigned long long seed, unsigned long long offset,
                          const unsigned long long* rng, float* sample, float* xstart, float* mean, float* eps_out,
-                         hipStream_t st) {
+                         hipStream_t st, const PrefixPlan* pp = nullptr) {
     int rc;
     const size_t per = (size_t)T * 3 * e->cfg.image_size * e->cfg.image_size;
     // tail of the workspace: t_model [B] + eps scratch (sized by ensure_ws for this B)
@@ -1390,7 +1462,7 @@ static int step_launches(vd_engine* e, int mode, int B, int T, const float* x, c
                        e->rescale, B, e->num_timesteps, tm, e->d_err);
     Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
     FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
-    if ((rc = e->forward(fi, st, ar))) return rc;
+    if ((rc = e->forward(fi, st, ar, pp))) return rc;
     PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
                      mode, eta, seed, offset, sample, xstart, mean, rng};
     ProfScope ps(PC_POSTERIOR, 0.0, 4.0 * B * per * 5.0, st);
@@ -1511,8 +1583,40 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     e->win_lost = false;
     ++e->win_gen;
     e->win_left = t_start + 1;
+    // window prefix cache (opt-in): the frames whose network input cannot change during the window -- observed (obs = 1,
+    // lat = 0) in 'x_0' mode with the default 'channel' conditioning (assemble_kernel: v = obs_src, indicator channels,
+    // timestep 0) -- run the blocks before the first attention layer ONCE, now; the captured step runs them on the others
+    const int N = B * T;
+    std::vector<unsigned char> inv;
+    int n_inv = 0;
+    if (e->prefix_cache_on && obs_mode == 0 && e->cfg.cond_emb_type == 0 && e->n_before_attn > 0) {
+        std::vector<float> hm(2 * (size_t)N);
+        VD_HIP(hipMemcpyAsync(hm.data(), obs, N * sizeof(float), hipMemcpyDeviceToHost, st));
+        VD_HIP(hipMemcpyAsync(hm.data() + N, lat, N * sizeof(float), hipMemcpyDeviceToHost, st));
+        VD_HIP(hipStreamSynchronize(st));
+        inv.resize(N);
+        for (int n = 0; n < N; ++n) { inv[n] = hm[n] == 1.f && hm[N + n] == 0.f; n_inv += inv[n]; }
+        if (n_inv == 0) inv.clear();
+    }
+    auto build_pass = [&](vd_engine::WinGraph& g) -> int {               // the invariant frames' prefix, eagerly, into the store
+        float* tm = reinterpret_cast<float*>(e->ws + e->ws_tail);
+        float* eps = reinterpret_cast<float*>(e->ws + e->ws_tail + (((size_t)B * sizeof(float) + 255) & ~(size_t)255));
+        hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(e->d_win_t),
+                           e->d_tmap, e->rescale, B, e->num_timesteps, tm, e->d_err);
+        Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
+        FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
+        PrefixPlan bp; bp.n = g.n_inv; bp.list = g.d_lists + (N - g.n_inv); bp.build_only = true; bp.store = g.store;
+        const bool prof = g_prof.on;
+        g_prof.on = false;
+        const int brc = e->forward(fi, st, ar, &bp);
+        g_prof.on = prof;
+        return brc;
+    };
     for (size_t i = 0; i < e->win_graphs.size(); ++i)
-        if (e->win_graphs[i].key == key) { e->win_cur = (int)i; return 0; }
+        if (e->win_graphs[i].key == key && e->win_graphs[i].inv == inv) {
+            e->win_cur = (int)i;
+            return n_inv ? build_pass(e->win_graphs[i]) : 0;           // same buffers, possibly new contents: the cache is per window
+        }
     // A new signature.  Everything a launch needs lazily (kernel attributes, CU count, the workspace) is set up by one
     // eager forward into the eps scratch before the capture; x is not touched by it.
     {
@@ -1528,9 +1632,26 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     const bool prof = g_prof.on;
     g_prof.on = false;                                          // no event records inside a capture
     const size_t per = (size_t)T * 3 * e->cfg.image_size * e->cfg.image_size;
+    vd_engine::WinGraph wg{};
+    wg.key = key; wg.inv = inv; wg.n_inv = n_inv;
+    PrefixPlan plan;
+    if (n_inv) {
+        std::vector<int> lists;
+        for (int n = 0; n < N; ++n) if (!inv[n]) lists.push_back(n);
+        for (int n = 0; n < N; ++n) if (inv[n]) lists.push_back(n);
+        VD_HIP(hipMalloc(reinterpret_cast<void**>(&wg.d_lists), N * sizeof(int)));
+        wg.store = new PrefixStore();
+        rc = (int)hipMemcpy(wg.d_lists, lists.data(), N * sizeof(int), hipMemcpyHostToDevice);
+        if (rc) set_error("prefix cache: frame lists");
+        if (!rc) rc = build_pass(wg);
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) { set_error("prefix cache: first pass"); rc = -2; }
+        if (rc) { g_prof.on = prof; wg.graph = nullptr; wg.exec = nullptr; if (wg.d_lists) (void)hipFree(wg.d_lists);
+                  for (float* p : wg.store->tens) if (p) (void)hipFree(p); for (double* p : wg.store->parts) if (p) (void)hipFree(p); delete wg.store; return rc; }
+        plan.n = N - n_inv; plan.list = wg.d_lists; plan.store = wg.store;
+    }
     VD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     rc = step_launches(e, sampler, B, T, x, obs_src, obs, lat, km, fidx, e->d_win_t, obs_mode, clip, eta, nullptr, 0, 0,
-                       e->d_win_rng, x, nullptr, nullptr, nullptr, st);
+                       e->d_win_rng, x, nullptr, nullptr, nullptr, st, n_inv ? &plan : nullptr);
     if (!rc) {
         hipLaunchKernelGGL(win_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->d_win_t, e->d_win_rng, B,
                            (unsigned long long)B * per);
@@ -1539,13 +1660,29 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     hipGraph_t graph = nullptr;
     const hipError_t ce = hipStreamEndCapture(st, &graph);
     g_prof.on = prof;
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ce != hipSuccess) { set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); return -2; }
+    auto drop_store = [&]() {
+        if (wg.d_lists) (void)hipFree(wg.d_lists);
+        if (wg.store) { for (float* p : wg.store->tens) if (p) (void)hipFree(p); for (double* p : wg.store->parts) if (p) (void)hipFree(p); delete wg.store; }
+    };
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); drop_store(); return rc; }
+    if (ce != hipSuccess) { set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); drop_store(); return -2; }
     hipGraphExec_t exec = nullptr;
-    VD_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    e->win_graphs.push_back(vd_engine::WinGraph{key, graph, exec});
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { set_error("hipGraphInstantiate"); (void)hipGraphDestroy(graph); drop_store(); return -2; }
+    wg.graph = graph; wg.exec = exec;
+    e->win_graphs.push_back(wg);
     e->win_cur = (int)e->win_graphs.size() - 1;
     return 0;
+}
+
+int vd_set_window_prefix_cache(vd_engine* e, int on) {
+    VD_REQUIRE(e, "null engine");
+    e->prefix_cache_on = on != 0;
+    return 0;
+}
+
+int vd_window_prefix_frames(vd_engine* e) {
+    VD_REQUIRE(e, "null engine");
+    return e->win_cur >= 0 ? e->win_graphs[e->win_cur].n_inv : 0;
 }
 
 unsigned long long vd_window_generation(vd_engine* e) { return e ? e->win_gen : 0; }

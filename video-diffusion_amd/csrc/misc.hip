@@ -12,12 +12,12 @@ namespace vd {
 // [B*T*H*W][Kpad = 64], k = tap*5 + channel (zeros for taps outside the image and for k >= 45), and the stem runs as a
 // plain K = 64 GEMM on gemm_frag_kernel.
 __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
-    const int n = blockIdx.y;
+    const int n = a.frame_list ? a.frame_list[blockIdx.y] : blockIdx.y;      // source frame; the im2col rows go to block blockIdx.y
     const int HW = a.H * a.W;
     const float om = a.obs_mask[n], lm = a.lat_mask[n], km = a.km_mask[n];
     const float any = fminf(om + lm + km, 1.0f);
     const int Cs = a.cond_mode == 0 ? 5 : (a.cond_mode == 1 ? 6 : 3);      // stem input channels (unet.py:932-940)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !a.frame_list) {
         const float t = a.t_model[n / a.T];
         const float tobs = a.obs_t_mode == 0 ? 0.f : (a.obs_t_mode == 1 ? t : t - 1.f);
         // 'channel': observed frames carry the timestep of their source (unet.py:991-1013); 'duplicate' / 'all': every frame
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
     }
     // thread -> (pixel, tap): 16 pixels x 9 taps (+7 idle lanes' worth) per 256 threads would waste lanes; use one thread
     // per (pixel, tap) with 9 taps in consecutive threads: blockIdx.x covers 28 pixels (252 threads active)
+    if (a.scalars_only) return;
     const int tp = threadIdx.x / 9, tap = threadIdx.x - tp * 9;
     const int p = blockIdx.x * 28 + tp;
     if (tp >= 28 || p >= HW) return;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
         }
         if (a.cond_mode == 0) { v[3] = om; v[4] = km; }
     }
-    float* o = a.x_cols + ((size_t)n * HW + p) * a.Kpad + tap * Cs;
+    float* o = a.x_cols + ((size_t)blockIdx.y * HW + p) * a.Kpad + tap * Cs;
     for (int c = 0; c < Cs; ++c) o[c] = v[c];
     if (tap == 8)
         for (int k = 9 * Cs; k < a.Kpad; ++k) o[k - 8 * Cs] = 0.f;   // o + Cs = column 9*Cs
@@ -60,7 +61,54 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
 
 int launch_assemble(const AssembleArgs& a, hipStream_t s) {
     VD_REQUIRE(a.Kpad % 32 == 0 && a.Kpad >= 64, "padded im2col width");
-    hipLaunchKernelGGL(assemble_kernel, dim3((a.H * a.W + 27) / 28, a.B * a.T), dim3(256), 0, s, a);
+    VD_REQUIRE(!(a.frame_list && a.scalars_only), "assemble: a frame list writes im2col rows only");
+    if (a.frame_list && a.n_list == 0) return 0;
+    const dim3 grid(a.scalars_only ? 1 : (a.H * a.W + 27) / 28, a.frame_list ? a.n_list : a.B * a.T);
+    hipLaunchKernelGGL(assemble_kernel, grid, dim3(256), 0, s, a);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ frame-granular gather / scatter (window prefix cache)
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void move_rows_kernel(const float* __restrict__ src, const int* __restrict__ list, size_t row4,
+                                                        float* __restrict__ dst) {
+    const int i = blockIdx.y, f = list[i];
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + (size_t)(SCATTER ? i : f) * row4;
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst) + (size_t)(SCATTER ? f : i) * row4;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < row4; k += (size_t)gridDim.x * 256) d4[k] = s4[k];
+}
+
+static int move_rows(bool scatter, const float* src, const int* list, int n, size_t row_floats, float* dst, hipStream_t s) {
+    VD_REQUIRE(row_floats % 4 == 0, "frame rows in 16-byte units");
+    if (n == 0) return 0;
+    const size_t row4 = row_floats / 4;
+    const int bx = (int)std::min<size_t>((row4 + 1023) / 1024, 64);
+    if (scatter) hipLaunchKernelGGL(move_rows_kernel<true>, dim3(bx, n), dim3(256), 0, s, src, list, row4, dst);
+    else hipLaunchKernelGGL(move_rows_kernel<false>, dim3(bx, n), dim3(256), 0, s, src, list, row4, dst);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+int launch_gather_rows(const float* src, const int* list, int n, size_t row_floats, float* dst, hipStream_t s) {
+    return move_rows(false, src, list, n, row_floats, dst, s);
+}
+int launch_scatter_rows(const float* src, const int* list, int n, size_t row_floats, float* dst, hipStream_t s) {
+    return move_rows(true, src, list, n, row_floats, dst, s);
+}
+
+// src [n][split][C][2] -> dst [frame][C][2] (one entry per frame and channel: the sum over the producer's pixel ranges, fp64)
+__global__ void scatter_stats_kernel(const double* __restrict__ src, int split, int C, const int* __restrict__ list,
+                                     double* __restrict__ dst) {
+    const int i = blockIdx.x, f = list[i];
+    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) {
+        double v = 0;
+        for (int sp = 0; sp < split; ++sp) v += src[((size_t)i * split + sp) * 2 * C + k];
+        dst[(size_t)f * 2 * C + k] = v;
+    }
+}
+int launch_scatter_stats(const double* src, int split, int C, const int* list, int n, double* dst, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scatter_stats_kernel, dim3(n), dim3(256), 0, s, src, split, C, list, dst);
     VD_HIP(hipGetLastError());
     return 0;
 }

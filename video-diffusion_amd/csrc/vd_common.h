@@ -190,8 +190,19 @@ struct AssembleArgs {
     float* x_cols;       // [B*T*H*W][Kpad]: im2col of the stem's input for the 3x3 stem, k = tap*Cs + channel
     float* t_frames;     // [B*T]
     float* amask;        // [B*T] anything mask
+    // window prefix cache (engine.hip): with a frame list the im2col rows of frames list[0..n_list) are written COMPACTLY
+    // (row block i <- frame list[i]) and the per-frame scalars are left alone; scalars_only writes t_frames / amask of every
+    // frame and no im2col
+    const int* frame_list = nullptr;
+    int n_list = 0;
+    int scalars_only = 0;
 };
 int launch_assemble(const AssembleArgs& a, hipStream_t s);
+// frame-granular moves of the window prefix cache: dst[i] = src[list[i]] (rows of row_floats), dst[list[i]] = src[i], and the
+// GroupNorm partial table of a compact tensor folded to ONE entry per (frame, channel) at its frame's place
+int launch_gather_rows(const float* src, const int* list, int n, size_t row_floats, float* dst, hipStream_t s);
+int launch_scatter_rows(const float* src, const int* list, int n, size_t row_floats, float* dst, hipStream_t s);
+int launch_scatter_stats(const double* src, int split, int C, const int* list, int n, double* dst, hipStream_t s);
 // out[n] = [cos(t*f) | sin(t*f)] with the frequency table built on the host (nn.py:89-107)
 int launch_sinus_embed(const float* t, int n, int dim, const float* freqs, float* out, hipStream_t s);
 // RPENet hidden: E[b,t,s,c] = silu(te[b*T+t][c] + Wd[c][:]*feat(d) + bd[c]), d = fi[b,t]-fi[b,s]  (unet.py:283-296)

@@ -22,9 +22,12 @@ _OBS_MODES = {"x_0": 0, "x_t": 1}
 
 
 class WindowExecutor:
-    def __init__(self, model, diffusion):
+    def __init__(self, model, diffusion, prefix_cache=False):
+        """prefix_cache: compute the observed frames' activations before the first attention layer once per window instead
+        of once per step ('x_0' mode, cond_emb_type='channel'; include/vd_amd.h: vd_set_window_prefix_cache)."""
         self.model = diffusion._bind(model)
         self.diffusion = diffusion
+        self.prefix_cache = bool(prefix_cache)
         self.stream = th.cuda.Stream(device=self.model.device)        # a capture needs a non-default stream
         self._bufs = {}
         self.x = None
@@ -67,6 +70,7 @@ class WindowExecutor:
             if t_start is None:
                 t_start = self.diffusion.num_timesteps - 1
             obs_src = bufs["x"] if mode == "x_t" else bufs["obs_src"]
+            _lib.check(_lib.lib().vd_set_window_prefix_cache(self.model._handle, 1 if self.prefix_cache else 0))
             _lib.check(_lib.lib().vd_window_begin(
                 self.model._handle, B, T, _lib.ptr(bufs["x"]), _lib.ptr(obs_src), _lib.ptr(bufs["obs_mask"]),
                 _lib.ptr(bufs["latent_mask"]), _lib.ptr(bufs["kinda_marg_mask"]), _lib.ptr(bufs["frame_indices"]),
@@ -95,6 +99,11 @@ class WindowExecutor:
         """All num_timesteps steps of one window; returns a fresh tensor."""
         self.begin(x_init, model_kwargs, seed=seed, sampler=sampler, eta=eta)
         return self.run(self.diffusion.num_timesteps).clone()
+
+    @property
+    def cached_frames(self):
+        """Frames of the armed window whose prefix activations come from the cache (0: cache off or nothing observed)."""
+        return int(_lib.lib().vd_window_prefix_frames(self.model._handle))
 
     @property
     def graphs(self):
