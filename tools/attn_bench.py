@@ -41,7 +41,7 @@ def main():
         t_no = timeit(lambda: _lib.check(L.vd_op_attn_temporal(_lib.ptr(qkv), None, None, None, _lib.ptr(mask), B, T, HW, C, heads, 0,
                                                                _lib.ptr(out), _lib.current_stream())), args.reps)
         t_sp = timeit(lambda: _lib.check(L.vd_op_attn_spatial(_lib.ptr(qkv), B * T, HW, C, heads, _lib.ptr(out), _lib.current_stream())), args.reps)
-        print(f"HW={HW:4d} C={C}: temporal with RPE {t_rpe:7.1f} us (op entry: includes a hipMalloc/sync)   without RPE {t_no:7.1f} us   "
+        print(f"HW={HW:4d} C={C}: temporal with RPE {t_rpe:7.1f} us   without RPE {t_no:7.1f} us   "
               f"spatial {t_sp:7.1f} us", flush=True)
 
 
