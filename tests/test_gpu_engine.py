@@ -822,6 +822,24 @@ def test_infer_video_graph_executor_statistics_and_reproducibility():
     assert abs(eager[:, 2:].mean() - outs[0][:, 2:].mean()) < 0.05 and abs(eager[:, 2:].std() / outs[0][:, 2:].std() - 1) < 0.1
 
 
+def test_infer_video_prefix_cache_follows_the_uncached_graph_path():
+    """infer_video(..., executor='graph', prefix_cache=True) over a whole autoreg schedule (windows conditioning on frames
+    generated by earlier windows, so the cached rows change from window to window while the buffers and the frame set stay):
+    same seed, same Philox streams -- the video must be the uncached graph path's to within accumulated rounding."""
+    from video_diffusion_amd.video_sample import infer_video
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=4, rp_beta=4, rp_gamma=4, timestep_respacing="ddim5")}
+    model, diff = engine(cfg)
+    batch = torch.rand(2, 10, 3, 32, 32, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    outs = []
+    for pc in (False, True):
+        torch.manual_seed(79)
+        outs.append(infer_video("autoreg", model, diff, batch.cuda(), 4, 2, 2, executor="graph", prefix_cache=pc)[0])
+    assert np.isfinite(outs[1]).all() and np.array_equal(outs[1][:, :2], batch[:, :2].numpy())
+    close(outs[1], outs[0], atol=2e-5, rtol=2e-5)
+    assert model._window_executor.prefix_cache and model._window_executor.cached_frames == 2 * 2
+
+
 def test_full_length_window_250_steps_vs_oracle():
     """A whole ddim250 window (250 chained ancestral steps, the headline schedule) on the tiny config against the CPU
     oracle with the same noise draws: what is bounded is the end-of-window DRIFT of a stochastic trajectory with clamps
