@@ -303,6 +303,16 @@ int vd_op_conv_wino_s64(const float* src0, int Cin, int nfr, int Hs, int Ws, int
 int vd_op_conv_wino_r64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
                         const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
                         void* stream);
+/* Upsample (nearest x2, unet.py:70-77) + conv3x3 in its sub-pixel form on csrc/conv_wino_r64.hip: output pixel (2y + a, 2x + b) sees
+ * only a 2 x 2 neighbourhood of the SOURCE map, i.e. four 3x3 "phase" kernels with one zero row and one zero column each
+ * ((w0, w1 + w2, 0) for a = 0, (0, w0 + w1, w2) for a = 1; sums in fp64), convolved with the low-resolution map; in the Winograd
+ * domain one of the four columns of every such kernel is zero and is skipped (a quarter of the matrix work of F(2x2,3x3) on
+ * the upsampled map).  Weights: OIHW -> 4*O phase kernels -> the vd_pack_conv3_wino_s64 layout = 4 * 48*O*I uint16.  src0
+ * [nfr][Hs][Hs][Cin], out [nfr][2Hs][2Hs][Cout]; gn_part [nfr][vd_conv_ups_stats_split(Hs)][Cout][2] doubles or NULL. */
+int vd_pack_conv3_wino_ups(const float* host_oihw, unsigned short* host_out, int O, int I);
+int vd_conv_ups_stats_split(int Hs);
+int vd_op_conv_wino_ups(const float* src0, int Cin, int nfr, int Hs, const void* w_ups, const float* bias, float* out, int Cout,
+                        double* gn_part, void* stream);
 int vd_op_linear_split(const float* a, int M, int K, const void* w_split, const float* bias, const float* res, int act,
                        float* out, int N, void* stream);
 /* The same layer with the GroupNorm partial sums of its output from the epilogue (the rows are the HW pixels of M / HW

@@ -588,6 +588,47 @@ def test_conv3x3_winograd_split_bf16x6_is_fp32_accurate(N, Cin, Cout, H, ups, ke
     close(tot[..., 1], (o64 * o64).sum((1, 2)).cpu(), atol=1e-3, rtol=1e-5)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H", [(2, 64, 64, 8), (5, 32, 128, 8), (3, 96, 64, 16), (2, 64, 192, 32), (9, 160, 64, 8),
+                                          (1, 32, 64, 64), (128, 64, 64, 16), (3, 512, 128, 16)])
+def test_upsample_conv_sub_pixel_form_is_fp32_accurate(N, Cin, Cout, H):
+    """csrc/conv_wino_r64.hip, sub-pixel form of Upsample + conv3x3 (unet.py:70-77): four phase kernels over the SOURCE map, one
+    Winograd column of each structurally zero and skipped.  Against torch's F.interpolate(nearest) + conv2d at the op
+    tolerance; against an fp64 reference no further away than the same layer on the upsampled map (the kernel it replaces);
+    GroupNorm partial sums (four table entries per tile group) against the stored output.  Source maps 8 (four frames per
+    item, frame counts that are not a multiple of four), 16, 32, 64; 2..32 channel chunks."""
+    L = _lib.lib()
+    x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, scale=(3.0 / (9 * Cin)) ** 0.5), rnd(Cout, scale=0.1)
+    xd, bd = dev(nhwc(x)), dev(b)
+    Ho = 2 * H
+    out_s = torch.full((N, Ho, Ho, Cout), float("nan"), device="cuda")
+    split = L.vd_conv_ups_stats_split(H)
+    part = torch.full((N, split, Cout, 2), float("nan"), dtype=torch.float64, device="cuda")
+    wu = torch.empty(4 * 48 * Cout * Cin, dtype=torch.int16)
+    _lib.check(L.vd_pack_conv3_wino_ups(_lib.ptr(w.contiguous().float()), _lib.ptr(wu), Cout, Cin))
+    wud = dev(wu)
+    _lib.check(L.vd_op_conv_wino_ups(_lib.ptr(xd), Cin, N, H, _lib.ptr(wud), _lib.ptr(bd), _lib.ptr(out_s), Cout, _lib.ptr(part),
+                                     _lib.current_stream()))
+    torch.cuda.synchronize()
+    xin = F.interpolate(x, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w, b, padding=1)
+    got = out_s.permute(0, 3, 1, 2).cpu()
+    close(got, ref, **TOL)
+    ref64 = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    e_new = (got.double() - ref64).abs()
+    out_o = torch.empty(N, Ho, Ho, Cout, device="cuda")               # the same layer as F(2x2,3x3) on the upsampled map
+    ws = dev(pack_wino_split(w))
+    _lib.check(L.vd_op_conv_wino_r64(_lib.ptr(xd), Cin, N, H, H, 1, _lib.ptr(ws), _lib.ptr(bd), None, None, 0, _lib.ptr(out_o), Cout,
+                                     None, _lib.current_stream()))
+    torch.cuda.synchronize()
+    e_old = (out_o.permute(0, 3, 1, 2).cpu().double() - ref64).abs()
+    assert e_new.max() <= 1.5 * e_old.max() + 1e-7, (e_new.max(), e_old.max())
+    assert e_new.mean() <= 1.5 * e_old.mean() + 1e-8, (e_new.mean(), e_old.mean())
+    o64 = out_s.double()
+    tot = part.sum(1).cpu()
+    close(tot[..., 0], o64.sum((1, 2)).cpu(), atol=1e-3, rtol=1e-5)
+    close(tot[..., 1], (o64 * o64).sum((1, 2)).cpu(), atol=1e-3, rtol=1e-5)
+
+
 def pack_conv_split(w):
     O, I = w.shape[:2]
     out = torch.empty(27 * O * I, dtype=torch.int16)

@@ -166,6 +166,9 @@ SIGNATURES = {
     "vd_pack_linear_frag": (_I, [_P, _P, _I, _I]),
     "vd_pack_linear_split": (_I, [_P, _P, _I, _I]),
     "vd_pack_conv3_wino_s64": (_I, [_P, _P, _I, _I]),
+    "vd_pack_conv3_wino_ups": (_I, [_P, _P, _I, _I]),
+    "vd_conv_ups_stats_split": (_I, [_I]),
+    "vd_op_conv_wino_ups": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "vd_op_conv_wino_s64": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "vd_op_conv_wino_r64": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "vd_op_conv_wino_split": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),

@@ -27,7 +27,8 @@ namespace vd {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-struct WinoR64Geom { int tiles_x, tiles_y, nbx, ncb, nitems, xcd_order, ksplit; };   // ksplit > 1: blockIdx.y = the block's slice of the channel chunks
+struct WinoR64Geom { int tiles_x, tiles_y, nbx, ncb, nitems, xcd_order, ksplit; int phase_cb = 0; int cgroup = 0; };   // ksplit > 1: blockIdx.y = the block's slice of the channel chunks
+// phase_cb > 0 (= real Cout / 32): the sub-pixel form of Upsample + conv (see conv3x3_wino_r64_ups_kernel)
 
 // Geometry of an item's patch image.  TF4 = false: one frame, 8 x 8 tiles (maps >= 16 x 16).  TF4 = true: FOUR frames of an
 // 8 x 8 map, 4 x 4 tiles each, a 10 x 10 patch per frame at a frame stride of FSB bytes (every stride a multiple of 256 bytes,
@@ -83,9 +84,43 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #define VD_R64_SKIP 0      // timing-only builds (results wrong): 1 no split, 2 no transform at all, 4 no weight loads, 16 no patch DMA,
 #endif                     // 64 no MFMA, 128 no patch reads
 
-template <bool TF4, bool X3 = false>       // X3: VD_MATH=bf16x3, three of the six piece products (vd_common.h)
-__global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, WinoR64Geom g) {
+// block -> (tile group, first cout tile): blocks are dealt to the 8 XCDs round-robin; inside an XCD the cout blocks of one
+// patch are neighbours
+__device__ __forceinline__ void r64_item(const WinoR64Geom& g, int& bx, int& cob0) {
+    if (g.xcd_order && g.cgroup > 0) {
+        // sub-pixel form: 4 x the cout blocks (16 .. 32 weight slices of 1 - 2 MB against 4 MB of L2 per XCD).  With the cout
+        // block as the fast index every slice had two concurrent readers per XCD (one at 512 couts) and the loop waited on
+        // weights from beyond the L2: 1452 -> 1252 us only for a quarter fewer MFMAs, 338 -> 351 at 512 couts.  Here an XCD
+        // walks ALL its patches with four cout blocks before it takes the next four.
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, px = g.nbx >> 3;
+        const int c_lo = loc % g.cgroup, rest = loc / g.cgroup;
+        cob0 = ((rest / px) * g.cgroup + c_lo) * 2;
+        bx = (rest % px) * 8 + xcd;
+    } else if (g.xcd_order) {
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        cob0 = (loc % g.ncb) * 2;
+        bx = (loc / g.ncb) * 8 + xcd;
+    } else {
+        bx = blockIdx.x % g.nbx;
+        cob0 = (blockIdx.x / g.nbx) * 2;
+    }
+}
+
+// JS >= 0: the sub-pixel form of nearest-x2 Upsample + conv3x3 (unet.py:70-77).  Output pixel (2y + a, 2x + b) only sees a 2 x 2
+// neighbourhood of the SOURCE map: rows (y-1, y) with weights (w0, w1 + w2) for a = 0, (y, y+1) with (w0 + w1, w2) for a = 1,
+// the same along x -- four 3x3 kernels with one zero row and one zero column each, convolved with the low-resolution map
+// (a.Cout = 4 x the real Cout; cout tile 2*blk + a of block blk = b * phase_cb + cb is phase (a, b) of real couts 32*cb ..).
+// In the Winograd domain U = G g G^T of such a kernel has a zero ROW (3 for a = 0, 0 for a = 1) and a zero COLUMN JS (3 for
+// b = 0, 0 for b = 1): the column is the same for both cout tiles of a block and is not computed at all -- three positions
+// per group instead of four, three patch columns transformed instead of four; the zero row costs nothing to keep.  Same
+// products as F(2x2,3x3) on the upsampled map would form, a quarter of them skipped.  X3: VD_MATH=bf16x3 (vd_common.h).
+template <bool TF4, bool X3, int JS>
+__device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& g) {
     using namespace r64;
+    constexpr int NP = JS < 0 ? 4 : 3;                               // positions of a group
+    constexpr int JLa[4] = {JS == 0 ? 1 : 0, JS == 0 ? 2 : 1, JS == 0 ? 3 : 2, 3};     // position li of a group -> column j of the row
+    constexpr int ORDa[4] = {JS == 0 ? 2 : 0, JS == 0 ? 1 : 2, JS == 0 ? 3 : 1, 3};    // the patch column position li recomputes for the next group
+    constexpr bool PH = JS >= 0;
     using G = R64G<TF4>;
     constexpr int P = G::P, SPP = G::SPP, PLB = G::PLB, RSB = G::RSB, NX = G::NX, XBUF = G::XBUF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -102,16 +137,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     const int ks = g.ksplit > 1 ? (int)blockIdx.y : 0;
     const int c_begin = ks * nchunk;
 
-    // ---- item: blocks are dealt to the 8 XCDs round-robin; inside an XCD the cout blocks of one patch are neighbours
     int bx, cob0;
-    if (g.xcd_order) {
-        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-        cob0 = (loc % g.ncb) * 2;
-        bx = (loc / g.ncb) * 8 + xcd;
-    } else {
-        bx = blockIdx.x % g.nbx;
-        cob0 = (blockIdx.x / g.nbx) * 2;
-    }
+    r64_item(g, bx, cob0);
     const int bxx = bx % g.tiles_x; bx /= g.tiles_x;
     const int byy = bx % g.tiles_y; bx /= g.tiles_y;
     const int f0 = TF4 ? bx * 4 : bx;                                 // first frame of the item
@@ -256,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #pragma unroll
     for (int c = 0; c < (VD_R64_BAR2 ? 3 : NB); ++c) x_dma(c);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { b_load(0, j, 0); b_load(0, j, 1); }
+    for (int li = 0; li < NP - 1; ++li) { b_load(0, JLa[li], 0); b_load(0, JLa[li], 1); }
 #if VD_R64_ZERO_EARLY
     // the 256 accumulator writes (1 k cycles of issue) go under the wait for the first patch instead of behind it
     __builtin_amdgcn_sched_barrier(0);
@@ -267,7 +294,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[m][j][n][r]));
+                for (int r = 0; r < 16; ++r)
+                    if (j != JS) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[m][j][n][r]));
     __builtin_amdgcn_sched_barrier(0);
 #else
 #pragma unroll
@@ -279,15 +307,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][j][n][r] = 0.f;
 #endif
-    asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");  // every patch requested so far has landed; the weights may be in flight
+    // every patch requested so far has landed; the (NP - 1) * 6 weight loads may be in flight
+    if constexpr (NP == 4) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { t_read(0, 0, c); t_fma(c, 0); t_fma(c, 1); }
-    t_comb(0, 0); t_comb(0, 1);
+    for (int c = 0; c < 4; ++c)
+        if (JS < 0 || (JS == 3 ? c < 3 : c > 0)) { t_read(0, 0, c); t_fma(c, 0); t_fma(c, 1); }
+    t_comb(JLa[0], 0); t_comb(JLa[0], 1);
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) t_split_a(0, pr);
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) t_split_b(0, pr);
-    t_read(0, 1, 0);
+    t_read(0, 1, ORDa[0]);
 
     R64_STAMP(1);
     // ---- main loop.  Group (chunk, m) = 4 positions x 12 slots; slot k of position j = MFMA (product q = k >> 1, cout tile
@@ -298,7 +329,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     // Patch of chunk c: first read in position 3 of group (c - 1, 0), last read in position 2 of group (c, 0); the block's only
     // barrier sits in front of position 3 of the even groups (c, 0): it hands over patches c + 1, c + 2 and frees two buffers.
     constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
-    constexpr int ORD[4] = {0, 2, 1, 3};
     // two chunks per trip: the chunk's parity (which decides the barrier and the patch requests) is a compile-time constant,
     // so the wait counts hipcc derives for the weight fragments are exact on every path
     for (int chunk0 = 0; chunk0 < nchunk; chunk0 += 2) {
@@ -308,12 +338,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int cur = j & 1, nxt = cur ^ 1;
+            for (int li = 0; li < NP; ++li) {
+                const int j = JLa[li];
+                const int cur = ((cpar * 2 + m) * NP + li) & 1, nxt = cur ^ 1;      // NP = 4: j & 1; the A fragment buffers alternate per position
 #pragma unroll
                 for (int k = 0; k < 12; ++k) {
                     const int q = k >> 1, n = k & 1;
-                    if (m == 0 && j == 3 && k == 0) {
+                    if (m == 0 && li == NP - 1 && k == 0) {
                         // patch chunk + 1 has landed in every wave; nobody reads patch chunk any more (loads return in order:
                         // the 18 youngest are weight loads)
 #if VD_R64_BAR2
@@ -338,15 +369,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #if VD_R64_DMA_SPREAD == 1
                     // one request instruction per slot (an LDS-DMA request blocks the wave's issue for ~63 cycles: twelve in one
                     // slot starve the matrix pipe for the length of eleven MFMAs)
-                    if (m == 0 && cpar == 1 && (j == 0 || j == 1) && k >= 12 - NX) x_dma_one(chunk + 2 + j, k - (12 - NX));   // the last NX slots of positions 0, 1
+                    if (m == 0 && cpar == 1 && (li == 0 || li == 1) && k >= 12 - NX) x_dma_one(chunk + 2 + li, k - (12 - NX));   // the last NX slots of positions 0, 1
 #else
-                    if (m == 0 && j == 0 && k == 4 && cpar == 1) { x_dma(chunk + 2); x_dma(chunk + 3); }
+                    if (m == 0 && li == 0 && k == 4 && cpar == 1) { x_dma(chunk + 2); x_dma(chunk + 3); }
 #endif
 #endif
                     if (!(VD_R64_SKIP & 64) && !(X3 && (q == 0 || q == 1 || q == 3)))      // bf16x3: (A1,B0) (A0,B1) (A0,B0) only
                         acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][PA[q]], bfr[j][n][PB[q]], acc[m][j][n], 0, 0, 0);
                     // the next position's fragment: position j + 1 of this group, or position 0 of the next one
-                    const int jn = (j + 1) & 3;
+                    const int jn = JLa[(li + 1) % NP];
                     if (k == 0) t_comb(jn, 0);
                     else if (k == 3) t_comb(jn, 1);
                     else if (k == 1 || k == 2) t_split_a(nxt, k - 1);
@@ -354,23 +385,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
                     else if (k >= 6 && k < 10) t_split_b(nxt, k - 6);
                     else {
                         // the group after this one: (chunk, 1) or (chunk + 1, 0); the one after that for the last reads
-                        t_fma(ORD[j], k - 10);
+                        t_fma(ORDa[li], k - 10);
                         if (k == 11) {
-                            if (j < 3) t_read(m == 0 ? chunk : chunk + 1, m ^ 1, ORD[j + 1]);
-                            else t_read(chunk + 1, m, ORD[0]);
+                            if (li < NP - 1) t_read(m == 0 ? chunk : chunk + 1, m ^ 1, ORDa[li + 1]);
+                            else t_read(chunk + 1, m, ORDa[0]);
                         }
                     }
                     // weights: (j - 1, n) of the next chunk once its last product has issued; (3, n) in position 0 of the next group
 #if VD_R64_WSPREAD
                     if (k < 6) {                                      // one weight load per slot: (n, piece) = (k / 3, k % 3)
-                        if (m == 1 && j > 0) b_load_one(chunk + 1, j - 1, k / 3, k % 3);
-                        if (m == 0 && j == 0) b_load_one(chunk, 3, k / 3, k % 3);
+                        if (m == 1 && li > 0) b_load_one(chunk + 1, JLa[li - 1], k / 3, k % 3);
+                        if (m == 0 && li == 0) b_load_one(chunk, JLa[NP - 1], k / 3, k % 3);
                     }
 #else
                     if (k == 0 || k == 3) {
                         const int nn = k == 0 ? 0 : 1;
-                        if (m == 1 && j > 0) b_load(chunk + 1, j - 1, nn);
-                        if (m == 0 && j == 0) b_load(chunk, 3, nn);
+                        if (m == 1 && li > 0) b_load(chunk + 1, JLa[li - 1], nn);
+                        if (m == 0 && li == 0) b_load(chunk, JLa[NP - 1], nn);
                     }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
@@ -386,7 +417,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
     // crosses the waves through LDS; wave (p, q) = (wi >> 1, wi & 1) then owns output pixel (p, q) of every tile.
     // Z image: [plane 2*i + q 8][m 2][c4 4][lane 64][4 floats] = 64 KB over the patch buffers.
     const int p = wi >> 1, q = wi & 1;
-    const int obytes = a.nfr * Hl * Wl * a.ldo * 4;
+    // sub-pixel form: block blk = cob0 / 2 = pb * phase_cb + cb; cout tile n is phase (n, pb) of real couts 32*cb .. 32*cb + 31, its
+    // pixel (y, x) of the low-resolution map goes to (2y + n, 2x + pb) of the output
+    const int pcb = PH ? (cob0 >> 1) % g.phase_cb : 0, ppb = PH ? (cob0 >> 1) / g.phase_cb : 0;
+    const int Ho = PH ? 2 * Hl : Hl, Wo = PH ? 2 * Wl : Wl;
+    const int obytes = a.nfr * Ho * Wo * a.ldo * 4;
     const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)ks * (obytes >> 2), 0, obytes, 0x00020000);
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
     const float sgn = p ? -1.f : 1.f;
@@ -398,12 +433,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
         for (int r = 0; r < 16; ++r) {
             const int tt = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int tx = TF4 ? tt & 3 : tt & 7, ty = TF4 ? (tt >> 2) & 3 : tt >> 3, nf = f0 + (TF4 ? tt >> 4 : 0);
-            const unsigned o = (unsigned)(((nf * Hl + oy0 + 2 * ty + p) * Wl + ox0 + 2 * tx + q) * a.ldo + cob0 * 32 + lr) * 4u;
+            const unsigned o = PH ? (unsigned)(((nf * Ho + 2 * (oy0 + 2 * ty + p)) * Wo + 2 * (ox0 + 2 * tx + q) + ppb) * a.ldo + pcb * 32 + lr) * 4u
+                                  : (unsigned)(((nf * Hl + oy0 + 2 * ty + p) * Wl + ox0 + 2 * tx + q) * a.ldo + cob0 * 32 + lr) * 4u;
             oo[m][r] = nf < a.nfr ? o : 0x80000000u;                 // TF4: a frame past the end is neither read nor stored
         }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const int co = (cob0 + n) * 32 + lr;
+        const int co = PH ? pcb * 32 + lr : (cob0 + n) * 32 + lr;
+        const int nso = PH ? n * Wo * a.ldo * 4 : n * 128;             // byte offset of cout tile n: one output row down | 32 channels on
         const float bias = a.bias ? a.bias[co] : 0.f;
         // per-frame bias: TF1 one frame; TF4 registers 0..7 of M-tile m belong to frame 2m, 8..15 to frame 2m + 1
         float bvf[2][2];
@@ -417,9 +454,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], n * 128, 0));
-            const f32x16 z0 = acc[m][0][n] + acc[m][1][n] + acc[m][2][n];
-            const f32x16 z1 = acc[m][1][n] - acc[m][2][n] - acc[m][3][n];
+            for (int r = 0; r < 16; ++r) rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], nso, 0));
+            // Z = M A: columns (1, 1, 1, 0) and (0, 1, -1, -1); the column the sub-pixel form never computed is zero
+            const f32x16 z0 = JS == 0 ? acc[m][1][n] + acc[m][2][n] : acc[m][0][n] + acc[m][1][n] + acc[m][2][n];
+            const f32x16 z1 = JS == 3 ? acc[m][1][n] - acc[m][2][n] : acc[m][1][n] - acc[m][2][n] - acc[m][3][n];
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 *reinterpret_cast<f32x4*>(Zs + ((((wi * 2 + 0) * 2 + m) * 4 + c4) * 64 + lane) * 4) = f32x4{z0[4 * c4], z0[4 * c4 + 1], z0[4 * c4 + 2], z0[4 * c4 + 3]};
@@ -443,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[r] += bvf[m][r >> 3];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)y[r]), osrc, oo[m][r], n * 128, 0);
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)y[r]), osrc, oo[m][r], nso, 0);
             if (a.stats) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -469,13 +507,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, W
                 for (int k = 0; k < 8; ++k) { s += red[((k * NFS + fs) * 32 + c) * 2]; ss += red[((k * NFS + fs) * 32 + c) * 2 + 1]; }
                 const int nf = f0 + fs, sp = TF4 ? 0 : byy * g.tiles_x + bxx;
                 if (nf < a.nfr) {
-                    double* o = a.stats + (((size_t)nf * a.stats_split + sp) * a.Cout + (cob0 + n) * 32 + c) * 2;
+                    // sub-pixel form: four table entries per tile group, one per phase, over the real couts
+                    double* o = PH ? a.stats + (((size_t)nf * a.stats_split + sp * 4 + 2 * n + ppb) * (g.phase_cb * 32) + pcb * 32 + c) * 2
+                                   : a.stats + (((size_t)nf * a.stats_split + sp) * a.Cout + (cob0 + n) * 32 + c) * 2;
                     o[0] = s; o[1] = ss;
                 }
             }
         }
     }
     R64_STAMP(3); R64_STAMP(5);
+}
+
+template <bool TF4, bool X3 = false>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, WinoR64Geom g) { r64_body<TF4, X3, -1>(a, g); }
+
+template <bool TF4, bool X3 = false>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_ups_kernel(IgemmArgs a, WinoR64Geom g) {
+    int bx, cob0;
+    r64_item(g, bx, cob0);
+    if ((cob0 >> 1) < g.phase_cb) r64_body<TF4, X3, 3>(a, g);        // phases (., 0): column 3 of U is zero
+    else r64_body<TF4, X3, 0>(a, g);                                 // phases (., 1): column 0
 }
 
 static bool r64_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -544,7 +595,47 @@ size_t conv_wino_r64_ksplit_floats(int nfr, int Hl, int Cin, int Cout) {
     return S > 1 ? (size_t)S * nfr * Hl * Hl * Cout : 0;
 }
 
+int conv_wino_ups_stats_split(int Hs) { return 4 * conv_wino_stats_split(Hs); }
+
+// Upsample + conv3x3 in its sub-pixel form: a.wwino is the image of pack_conv3_wino_ups (4 x Cout phase kernels), the kernel
+// convolves the LOW-resolution map and writes the interleaved output.
+static int launch_conv_wino_r64_ups(const IgemmArgs& a, hipStream_t s) {
+    VD_REQUIRE(a.ups == 1 && a.res == nullptr && a.fbias == nullptr && a.Cout % 64 == 0, "sub-pixel Upsample conv: no residual, no per-frame bias");
+    VD_REQUIRE(a.stats == nullptr || a.stats_split == conv_wino_ups_stats_split(a.Hs), "GroupNorm partial table: split (sub-pixel form)");
+    VD_REQUIRE((size_t)a.Cin * a.Cout * 4 * 96 < ((size_t)1 << 31), "sub-pixel weight image beyond 2 GiB");
+    WinoR64Geom g;
+    const int Hl = a.Hs;
+    const bool tf4 = Hl == 8;
+    g.tiles_x = tf4 ? 1 : Hl / 16; g.tiles_y = g.tiles_x;
+    g.nbx = g.tiles_x * g.tiles_y * (tf4 ? (a.nfr + 3) / 4 : a.nfr);
+    g.ncb = 4 * a.Cout / 64;
+    g.nitems = g.nbx * g.ncb;
+    g.xcd_order = g.nbx % 8 == 0;
+    g.ksplit = 1;
+    g.phase_cb = a.Cout / 32;
+    g.cgroup = g.ncb % 4 == 0 ? 4 : 2;                                // groups of 1 / 2 / 4 / 8 measured: 1 loses the patch reuse (1347 us at 256 couts), 2 .. 8 within noise
+    IgemmArgs k = a;
+    k.ups = 0; k.Cout = 4 * a.Cout;                                  // the kernel's view: a stride-1 conv of the source map with 4 x Cout outputs
+    static bool attr = false;
+    if (!attr) {
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_ups_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_ups_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_ups_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_ups_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const dim3 grid(g.nitems, 1);
+    if (x3_math()) {
+        if (tf4) hipLaunchKernelGGL((conv3x3_wino_r64_ups_kernel<true, true>), grid, dim3(256), r64::lds_bytes<true>(), s, k, g);
+        else hipLaunchKernelGGL((conv3x3_wino_r64_ups_kernel<false, true>), grid, dim3(256), r64::lds_bytes<false>(), s, k, g);
+    } else if (tf4) hipLaunchKernelGGL(conv3x3_wino_r64_ups_kernel<true>, grid, dim3(256), r64::lds_bytes<true>(), s, k, g);
+    else hipLaunchKernelGGL(conv3x3_wino_r64_ups_kernel<false>, grid, dim3(256), r64::lds_bytes<false>(), s, k, g);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
+    if (a.ups_phase) return launch_conv_wino_r64_ups(a, s);
     const int Hl = a.Hs << a.ups;
     VD_REQUIRE(a.stats == nullptr || a.stats_split == conv_wino_stats_split(Hl), "GroupNorm partial table: split");
     WinoR64Geom g;
@@ -554,6 +645,7 @@ int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
     g.ncb = a.Cout / 64;
     g.nitems = g.nbx * g.ncb;
     g.xcd_order = g.nbx % 8 == 0;
+    // (the grouped cout walk of the sub-pixel form changes nothing here: 2 .. 8 cout blocks per patch, headline 27.55 ms with groups of 0 / 2 / 4)
     // split-K only with scratch from the caller (the engine's arena; the single-operator entry points run one slice)
     g.ksplit = a.ksplit_ws && a.ksplit_ws_floats >= conv_wino_r64_ksplit_floats(a.nfr, Hl, a.Cin, a.Cout)
                    ? conv_wino_r64_ksplit(a.nfr, Hl, a.Cin, a.Cout) : 1;

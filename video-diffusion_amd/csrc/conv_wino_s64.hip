@@ -526,25 +526,57 @@ int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s) {
 // host: U = G g G^T (fp64, rounded once to fp32, row 3 negated), split into three bf16 pieces, packed
 // [Cin/16][xi 16][Cout/32][piece 3][lane 64][8]: lane 32h+r holds U[xi][co = 32*blk + r][ci = 16*chunk + 8*h + e]
 void split3_host(float v, unsigned short out[3]);
-void pack_conv3_wino_s64(const float* oihw, unsigned short* out, int O, int I) {
+// one (cout co of O, cin ci of I) kernel gk[9] (fp64) -> its 16 x 3 pieces in the image
+static void pack_wino_one(const double* gk, unsigned short* out, int O, int I, int co, int ci) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int ncoblk = O / 32;
+    double tmp[4][3], U[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int c = 0; c < 3; ++c) tmp[i][c] = G[i][0] * gk[0 * 3 + c] + G[i][1] * gk[1 * 3 + c] + G[i][2] * gk[2 * 3 + c];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) U[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+    const int ch = ci / 16, k = ci % 16, h = k >> 3, e = k & 7;
+    const int cb = co >> 5, r = co & 31;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            unsigned short pc[3];
+            split3_host((float)(i == 3 ? -U[i][j] : U[i][j]), pc);
+            for (int q3 = 0; q3 < 3; ++q3)
+                out[(((((size_t)ch * 16 + i * 4 + j) * ncoblk + cb) * 3 + q3) * 64 + h * 32 + r) * 8 + e] = pc[q3];
+        }
+}
+
+void pack_conv3_wino_s64(const float* oihw, unsigned short* out, int O, int I) {
     for (int co = 0; co < O; ++co)
         for (int ci = 0; ci < I; ++ci) {
-            const float* gk = oihw + ((size_t)co * I + ci) * 9;
-            double tmp[4][3], U[4][4];
-            for (int i = 0; i < 4; ++i)
-                for (int c = 0; c < 3; ++c) tmp[i][c] = G[i][0] * gk[0 * 3 + c] + G[i][1] * gk[1 * 3 + c] + G[i][2] * gk[2 * 3 + c];
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) U[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
-            const int ch = ci / 16, k = ci % 16, h = k >> 3, e = k & 7;
-            const int cb = co >> 5, r = co & 31;
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) {
-                    unsigned short pc[3];
-                    split3_host((float)(i == 3 ? -U[i][j] : U[i][j]), pc);
-                    for (int q3 = 0; q3 < 3; ++q3)
-                        out[(((((size_t)ch * 16 + i * 4 + j) * ncoblk + cb) * 3 + q3) * 64 + h * 32 + r) * 8 + e] = pc[q3];
+            double gk[9];
+            for (int t = 0; t < 9; ++t) gk[t] = oihw[((size_t)co * I + ci) * 9 + t];
+            pack_wino_one(gk, out, O, I, co, ci);
+        }
+}
+
+// Upsample (nearest x2) + conv3x3 as four 3x3 kernels over the SOURCE map (conv_wino_r64.hip): output pixel (2y + a, 2x + b)
+// reads source rows (y-1, y, y+1) with (w0, w1 + w2, 0) for a = 0 and (0, w0 + w1, w2) for a = 1, columns alike with b; the
+// sums are formed in fp64.  Image of 4*O couts: cout ((b * O/32 + cb) * 2 + a) * 32 + r is phase (a, b) of real cout 32*cb + r.
+void pack_conv3_wino_ups(const float* oihw, unsigned short* out, int O, int I) {
+    const int ncb = O / 32;
+    for (int co = 0; co < O; ++co)
+        for (int ci = 0; ci < I; ++ci) {
+            const float* w = oihw + ((size_t)co * I + ci) * 9;
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    double rows[3][3], gk[9];
+                    for (int c = 0; c < 3; ++c) {                     // vertical combination, per kernel column
+                        const double w0 = w[0 * 3 + c], w1 = w[1 * 3 + c], w2 = w[2 * 3 + c];
+                        rows[0][c] = a == 0 ? w0 : 0.0; rows[1][c] = a == 0 ? w1 + w2 : w0 + w1; rows[2][c] = a == 0 ? 0.0 : w2;
+                    }
+                    for (int r = 0; r < 3; ++r) {
+                        gk[r * 3 + 0] = b == 0 ? rows[r][0] : 0.0;
+                        gk[r * 3 + 1] = b == 0 ? rows[r][1] + rows[r][2] : rows[r][0] + rows[r][1];
+                        gk[r * 3 + 2] = b == 0 ? 0.0 : rows[r][2];
+                    }
+                    const int cb = co >> 5, r32 = co & 31;
+                    pack_wino_one(gk, out, 4 * O, I, ((b * ncb + cb) * 2 + a) * 32 + r32, ci);
                 }
         }
 }

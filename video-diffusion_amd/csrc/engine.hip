@@ -25,7 +25,8 @@ int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hip
 
 // CONV3F / LINF: MFMA-fragment-major images (conv_halo.hip / gemm_frag.hip)
 // CONV3W: Winograd F(2x2,3x3)-transformed weights, 16/9 of the checkpoint size (conv_wino.hip)
-enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_CONV3F, PK_LINF, PK_CONV3W, PK_CONV3S };
+enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_CONV3F, PK_LINF, PK_CONV3W, PK_CONV3S,
+                 PK_CONV3WU };      // PK_CONV3WU: Upsample + conv3x3 in its sub-pixel form (conv_wino_r64.hip): image of 4 x Cout phase kernels
 
 struct Param {
     std::string name;
@@ -113,7 +114,8 @@ struct Arena {
 // ---- per-class kernel timing with HIP events on the launch stream (bench.py's live roofline figure)
 enum ProfClass { PC_IGEMM_128x128 = 0, PC_IGEMM_128x64, PC_IGEMM_64x128, PC_IGEMM_64x64, PC_GN_STATS, PC_GN_TEMPORAL,
                  PC_ATTN_SPATIAL, PC_ATTN_TEMPORAL, PC_OUT_CONV, PC_ELEMENTWISE, PC_POSTERIOR,
-                 PC_CONV_128x128, PC_CONV_128x64, PC_CONV_64x128, PC_CONV_64x64, PC_CONV_WINO, PC_CONV_WINO_R64, PC_IGEMM_128x192, PC_COUNT };
+                 PC_CONV_128x128, PC_CONV_128x64, PC_CONV_64x128, PC_CONV_64x64, PC_CONV_WINO, PC_CONV_WINO_R64, PC_IGEMM_128x192,
+                 PC_CONV_WINO_R64_UPS, PC_COUNT };
 // names of the kernels a class runs on: [0] default arithmetic (bf16x6 split), [1] VD_MATH=fp32 / VD_CONV_SPLIT=0
 static const char* kProfNames[PC_COUNT][2] = {
     {"gemm_split_kernel<128,128>", "gemm_frag_kernel<128,128>"}, {"gemm_split_kernel<128,64>", "gemm_frag_kernel<128,64>"},
@@ -124,7 +126,8 @@ static const char* kProfNames[PC_COUNT][2] = {
     {"conv3x3_frag_kernel<128,128>", "conv3x3_frag_kernel<128,128>"}, {"conv3x3_frag_kernel<128,64>", "conv3x3_frag_kernel<128,64>"},
     {"conv3x3_frag_kernel<64,128>", "conv3x3_frag_kernel<64,128>"}, {"conv3x3_frag_kernel<64,64>", "conv3x3_frag_kernel<64,64>"},
     {"conv3x3_wino_s64_kernel", "conv3x3_wino_kernel"}, {"conv3x3_wino_r64_kernel", "conv3x3_wino_r64_kernel"},
-    {"gemm_split_kernel<128,192>", "gemm_split_kernel<128,192>"}};
+    {"gemm_split_kernel<128,192>", "gemm_split_kernel<128,192>"},
+    {"conv3x3_wino_r64_ups_kernel", "conv3x3_wino_r64_ups_kernel"}};
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; char tag[56]; };
 struct Profiler {
     bool on = false;
@@ -159,7 +162,7 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     one.M = one.nfr * g.Ho * g.Wo;
     const bool wino = conv_wino_supported(one) || conv_wino_s64_supported(one);
     const bool split_gemm = gemm_split_supported(one) || conv_split_supported(one);
-    const int cls = wino ? (int)(conv_wino_r64_supported(one) ? PC_CONV_WINO_R64 : PC_CONV_WINO)
+    const int cls = wino ? (int)(g.ups_phase ? PC_CONV_WINO_R64_UPS : conv_wino_r64_supported(one) ? PC_CONV_WINO_R64 : PC_CONV_WINO)
                     : split_gemm && gemm_split_tile_class(one.M, g.Cout) == 4 ? (int)PC_IGEMM_128x192
                     : igemm_tile_class(one.M, g.Cout) + (conv_halo_supported(one) ? (int)PC_CONV_128x128 : 0);
     char tag[56];
@@ -300,6 +303,7 @@ struct vd_engine {
         const int k = params[p].kind;
         g.w = g.wfrag = g.wwino = nullptr;
         if (k == PK_CONV3W) { g.wwino = W(p); g.wsplit = split_conv() ? 2 : 0; }
+        else if (k == PK_CONV3WU) { g.wwino = W(p); g.wsplit = 2; g.ups_phase = 1; }
         else if (k == PK_CONV3S) { g.wfrag = W(p); g.wsplit = 1; }
         else if (k == PK_CONV3F || k == PK_LINF) { g.wfrag = W(p); g.wsplit = k == PK_LINF && split_math(); }
         else g.w = W(p);
@@ -318,6 +322,7 @@ struct vd_engine {
         if ((kind == PK_STEM || kind == PK_LINF) && split_math()) p.packed = p.packed * 3 / 2;       // three bf16 planes
         if (kind == PK_CONV3S) p.packed = p.numel * 3 / 2;
         if (kind == PK_CONV3W) p.packed = (size_t)16 * p.shape[0] * p.shape[1] * (split_conv() ? 3 : 2) / 2;
+        if (kind == PK_CONV3WU) p.packed = (size_t)4 * 16 * p.shape[0] * p.shape[1] * 3 / 2;
         params.push_back(p);
         pidx[name] = (int)params.size() - 1;
         return (int)params.size() - 1;
@@ -483,7 +488,12 @@ int vd_engine::build() {
             int li = 1;
             if (in_att(ds)) { int ai = add_attn(pre + "." + std::to_string(li++), ch); if (ai < 0) return ai; blk.push_back(Layer{2, ai}); }
             if (lvl && i == nrb) {
-                blk.push_back(Layer{4, add_conv(pre + "." + std::to_string(li++) + ".conv", ch, ch, k3(2 * cfg.image_size / ds, ch), 2 * cfg.image_size / ds)});
+                // Upsample + conv: the sub-pixel form where the split Winograd kernel serves the SOURCE map (VD_UPS_PHASE=0: A/B switch)
+                static const bool no_phase = getenv("VD_UPS_PHASE") && std::string(getenv("VD_UPS_PHASE")) == "0";
+                const int rs_src = cfg.image_size / ds;
+                int kup = k3(2 * rs_src, ch);
+                if (kup == PK_CONV3W && split_conv() && !no_phase && rs_src >= 8 && (rs_src & (rs_src - 1)) == 0 && ch % 64 == 0) kup = PK_CONV3WU;
+                blk.push_back(Layer{4, add_conv(pre + "." + std::to_string(li++) + ".conv", ch, ch, kup, 2 * rs_src)});
                 ds /= 2;
             }
             output_blocks.push_back(blk);
@@ -859,17 +869,19 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
                 IgemmArgs g = conv_args(cur, nullptr, N, 3, stride, ups);
                 float* o = ar.get<float>((size_t)g.M * c.c);
                 nxt = Tens{o, c.c, g.Ho};
+                const bool phase = params[c.w].kind == PK_CONV3WU;                    // sub-pixel Upsample conv: four table entries per tile group
                 if (params[c.w].kind == PK_CONV3W) nxt.part = stats_table(ar, N, g.Ho, c.c, &nxt.split);
+                else if (phase) { nxt.split = conv_wino_ups_stats_split(cur.H); nxt.part = ar.get<double>((size_t)N * nxt.split * c.c * 2); }
                 else if (stride == 2) conv_split_stats_table(ar, g, c.c, &nxt);       // Downsample on the split GEMM
                 const size_t mk = ar.mark();
-                const size_t ksf = stride == 1 ? conv_wino_r64_ksplit_floats(N, g.Ho, cur.C, c.c) : 0;
+                const size_t ksf = stride == 1 && !phase ? conv_wino_r64_ksplit_floats(N, g.Ho, cur.C, c.c) : 0;
                 float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
                 ar.release(mk);                                                       // a transient: the launches are stream-ordered
                 if (!ar.dry) {
                     g.ksplit_ws = ksw; g.ksplit_ws_floats = ksf;
                     set_w(g, c.w); g.bias = W(c.b); g.out = o; g.ldo = c.c; g.Cout = c.c;
                     g.stats = nxt.part; g.stats_split = nxt.split;
-                    if (nxt.part && params[c.w].kind != PK_CONV3W) g.stats_hw = g.Ho * g.Wo;
+                    if (nxt.part && params[c.w].kind != PK_CONV3W && !phase) g.stats_hw = g.Ho * g.Wo;
                     if ((rc = igemm_p(g, st))) return rc;
                 }
                 if (tape) { tape->ops.push_back(TapeOp{0, (int)tape->conv.size()}); tape->conv.push_back(TapeConv{L.type, L.idx, cur, nxt}); }
@@ -1287,6 +1299,10 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
     if (p.kind == PK_CONV3W && split_conv()) {
         tmp.resize(p.packed);
         pack_conv3_wino_s64(host, reinterpret_cast<unsigned short*>(tmp.data()), (int)p.shape[0], (int)p.shape[1]);
+        src = tmp.data();
+    } else if (p.kind == PK_CONV3WU) {
+        tmp.resize(p.packed);
+        pack_conv3_wino_ups(host, reinterpret_cast<unsigned short*>(tmp.data()), (int)p.shape[0], (int)p.shape[1]);
         src = tmp.data();
     } else if (p.kind == PK_CONV3W) {
         tmp.resize(p.packed);
@@ -1920,6 +1936,27 @@ int vd_op_conv_wino_r64(const float* src0, int Cin, int nfr, int Hs, int Ws, int
                         const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
                         void* stream) {
     return op_conv_wino_split(2, src0, Cin, nfr, Hs, Ws, ups, w_split, bias, res, fbias, fbias_ld, out, Cout, gn_part, stream);
+}
+
+int vd_pack_conv3_wino_ups(const float* host_oihw, unsigned short* host_out, int O, int I) {
+    VD_REQUIRE(host_oihw && host_out && O % 64 == 0 && I % 32 == 0, "vd_pack_conv3_wino_ups: O multiple of 64, I of 32");
+    pack_conv3_wino_ups(host_oihw, host_out, O, I);
+    return 0;
+}
+
+int vd_conv_ups_stats_split(int Hs) { return conv_wino_ups_stats_split(Hs); }
+
+int vd_op_conv_wino_ups(const float* src0, int Cin, int nfr, int Hs, const void* w_ups, const float* bias, float* out, int Cout,
+                        double* gn_part, void* stream) {
+    IgemmArgs g{};
+    g.src0 = src0; g.C0 = Cin; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Hs; g.ups = 1; g.ups_phase = 1;
+    g.stride = 1; g.pad = 1; g.ksz = 3;
+    g.Ho = 2 * Hs; g.Wo = 2 * Hs;
+    g.wwino = static_cast<const float*>(w_ups); g.wsplit = 2; g.bias = bias; g.out = out; g.ldo = Cout; g.Cout = Cout;
+    g.M = nfr * g.Ho * g.Wo;
+    g.stats = gn_part; g.stats_split = conv_wino_ups_stats_split(Hs);
+    VD_REQUIRE(conv_wino_r64_supported(g), "vd_op_conv_wino_ups: shape not covered (square power-of-two source map >= 8, Cout % 64, Cin % 32)");
+    return launch_igemm(g, static_cast<hipStream_t>(stream));            // cuts big windows along frames like the engine
 }
 
 int vd_pack_conv3_split(const float* host_oihw, unsigned short* host_out, int O, int I) {

@@ -39,6 +39,7 @@ struct IgemmArgs {
     int C0, Cin;
     int nfr, Hs, Ws;     // stored source dims
     int ups;             // 1: source is read through a nearest x2 upsample (unet.py:69)
+    int ups_phase = 0;   // with ups = 1: wwino holds the sub-pixel image (pack_conv3_wino_ups); conv_wino_r64.hip
     int stride, pad, ksz;
     int Ho, Wo;
     const float* w;      // [ksz*ksz][Cout][Cin]           (generic kernel)
@@ -145,6 +146,11 @@ int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino_s64(const float* oihw, unsigned short* out, int O, int I);
 bool conv_wino_r64_supported(const IgemmArgs& a);        // same weight image, transform + split in registers (conv_wino_r64.hip)
 int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s);
+// Upsample (nearest x2) + conv3x3 in its sub-pixel form (conv_wino_r64.hip): four phase kernels per real cout over the
+// LOW-resolution map, one of the four Winograd columns structurally zero and skipped.  IgemmArgs::ups_phase selects it;
+// the GroupNorm table then has conv_wino_ups_stats_split(Hs) entries per frame.
+void pack_conv3_wino_ups(const float* oihw, unsigned short* out, int O, int I);     // image of 4*O phase kernels
+int conv_wino_ups_stats_split(int Hs);
 int conv_wino_r64_ksplit(int nfr, int Hl, int Cin, int Cout);            // slices of the channel loop a small grid is cut into (1: none)
 size_t conv_wino_r64_ksplit_floats(int nfr, int Hl, int Cin, int Cout);  // floats of scratch the caller then provides in ksplit_ws
 bool gemm_split_supported(const IgemmArgs& a);            // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
