@@ -489,7 +489,8 @@ int vd_engine::build() {
             if (in_att(ds)) { int ai = add_attn(pre + "." + std::to_string(li++), ch); if (ai < 0) return ai; blk.push_back(Layer{2, ai}); }
             if (lvl && i == nrb) {
                 // Upsample + conv: the sub-pixel form where the split Winograd kernel serves the SOURCE map (VD_UPS_PHASE=0: A/B switch)
-                static const bool no_phase = getenv("VD_UPS_PHASE") && std::string(getenv("VD_UPS_PHASE")) == "0";
+                static const bool no_phase = (getenv("VD_UPS_PHASE") && std::string(getenv("VD_UPS_PHASE")) == "0") ||
+                                             (getenv("VD_CONV_R64") && getenv("VD_CONV_R64")[0] == '0');   // the form lives in conv_wino_r64.hip only
                 const int rs_src = cfg.image_size / ds;
                 int kup = k3(2 * rs_src, ch);
                 if (kup == PK_CONV3W && split_conv() && !no_phase && rs_src >= 8 && (rs_src & (rs_src - 1)) == 0 && ch % 64 == 0) kup = PK_CONV3WU;

@@ -207,6 +207,10 @@ bool x3_math() {
 
 // One launch: every operand of `a` is small enough for the 32-bit byte offsets the kernels address with.
 static int launch_igemm_one(const IgemmArgs& a, hipStream_t s) {
+    if (a.ups_phase) {                                                  // sub-pixel weight image: only conv_wino_r64.hip reads it
+        VD_REQUIRE(conv_wino_r64_supported(a), "sub-pixel Upsample conv needs conv_wino_r64.hip (VD_CONV_R64=0 with VD_UPS_PHASE on?)");
+        return launch_conv_wino_r64(a, s);
+    }
     if (gemm_split_supported(a) || conv_split_supported(a)) return launch_gemm_split(a, igemm_tile_class(a.M, a.Cout), s);
     if (conv_wino_r64_supported(a)) return launch_conv_wino_r64(a, s);      // maps >= 16x16; VD_CONV_R64=0 switches it off
     if (conv_wino_s64_supported(a)) return launch_conv_wino_s64(a, s);
