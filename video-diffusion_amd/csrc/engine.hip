@@ -658,13 +658,31 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     Tens ot{nullptr, r.cout, H};
     if (params[r.c2w].kind == PK_CONV3W) ot.part = stats_table(ar, N, H, r.cout, &ot.split);
     const float* film = film_all + r.film_off;
+    // The skip convolution (1x1 over the block input, unet.py:159-166) reads the tensor the first GroupNorm+SiLU reads: where
+    // it runs on the 128x128 tile of gemm_split.hip its column blocks 0 write that activation image from the rows they stage
+    // (IgemmArgs::side) -- the block input, the largest tensor of a decoder block, is read once instead of twice.  Decided by
+    // shape alone (the dry run lays the arena out the same way); VD_NO_SKIP_SIDE: A/B switch.
+    static const bool no_side = getenv("VD_NO_SKIP_SIDE") != nullptr;
+    IgemmArgs gsk{};
+    bool fuse_skip = false;
+    if (r.skw >= 0 && !no_side) {
+        gsk = conv_args(x0, x1, N, 1, 1, 0);
+        set_w(gsk, r.skw); gsk.Cout = r.cout; gsk.ldo = r.cout; gsk.side_hw = HW;
+        IgemmArgs one = gsk; one.nfr = std::max(1, std::min(N, igemm_frames_per_launch(gsk))); one.M = one.nfr * HW;
+        one.wfrag = one.wfrag ? one.wfrag : reinterpret_cast<const float*>(0x1000);      // dry run: no weight image yet, the shape decides
+        fuse_skip = params[r.skw].kind == PK_LINF && split_math() && gemm_split_side_supported(one);
+    }
+    float* sk_early = fuse_skip ? ar.get<float>((size_t)N * HW * r.cout) : nullptr;
     {   // SiLU(GroupNorm(concat(x0, x1))) once, into a transient; the conv then reads plain activations (norm.hip)
         const size_t mk = ar.mark();
         float* a1 = ar.get<float>((size_t)N * HW * cin);
         const size_t ksf = conv_wino_r64_ksplit_floats(N, H, cin, r.cout);      // small grids: split-K scratch (conv_wino_r64.hip)
         float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
         if (!ar.dry) {
-            if ((rc = affine_act(x0.p, s1, x0.C, cin, A1, B1, N, HW, a1, st))) return rc;
+            if (fuse_skip) {
+                gsk.bias = W(r.skb); gsk.out = sk_early; gsk.side = a1; gsk.sideA = A1; gsk.sideB = B1;
+                if ((rc = igemm_p(gsk, st))) return rc;
+            } else if ((rc = affine_act(x0.p, s1, x0.C, cin, A1, B1, N, HW, a1, st))) return rc;
             Tens at{a1, cin, H};
             IgemmArgs g = conv_args(at, nullptr, N, 3, 1, 0);
             set_w(g, r.c1w); g.bias = W(r.c1b);
@@ -678,7 +696,8 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     rc = gn_fold(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, st, ar, &A2, &B2, &mr2);
     if (rc) return rc;
     const float* skip = x0.p;
-    if (r.skw >= 0) {
+    if (fuse_skip) skip = sk_early;
+    else if (r.skw >= 0) {
         float* sk = ar.get<float>((size_t)N * HW * r.cout);
         if (!ar.dry) {
             IgemmArgs g = conv_args(x0, x1, N, 1, 1, 0);

@@ -45,7 +45,10 @@ __device__ __forceinline__ void split3(f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& 
 // CONV: the A operand is the implicit im2col matrix of a 3x3 convolution (any stride, zero padding 1) over one NHWC
 // source: K runs tap-major (k = tap*Cin + c, the order pack_conv3_split stores), the row of an output pixel moves with
 // the tap, and a tap that falls outside the image reads zeros through the descriptor's range check.
-template <int BM, int BN, bool ACT, bool CONV, bool X3 = false>      // X3: VD_MATH=bf16x3, three of the six piece products (vd_common.h)
+// SIDE: the ResBlock skip convolution (unet.py:159-166, 1x1 over the block input) reads the same tensor the block's first
+// GroupNorm+SiLU reads; the column blocks 0 write that activation image from the rows they stage (IgemmArgs::side): one pass
+// over the (largest) tensor of the block instead of two.
+template <int BM, int BN, bool ACT, bool CONV, bool X3 = false, bool SIDE = false>      // X3: VD_MATH=bf16x3, three of the six piece products (vd_common.h)
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
     // weight ring slots (k-steps ahead = RING - 1): 2 for the 128x192 tile (256 registers per wave), 3 for the others -- and 6
@@ -105,6 +108,27 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
 
     f32x4 ra[PF][AR];
     bf16x8 bfr[RING][NI][3], afr[2][MI][3];      // [ring slot][tile][piece]
+    // SIDE: this block's frame, the affine pair of the chunk in flight, and the image rows of this thread
+    static_assert(!SIDE || (BM == 128 && !CONV && !ACT), "side output: 128-row tiles of a plain 1x1");
+    const bool side_on = SIDE && blockIdx.y == 0;
+    const float* sAp = SIDE ? a.sideA + (size_t)(m0 / (SIDE ? a.side_hw : 1)) * a.Cin + lq * 4 : nullptr;
+    const float* sBp = SIDE ? a.sideB + (size_t)(m0 / (SIDE ? a.side_hw : 1)) * a.Cin + lq * 4 : nullptr;
+    f32x4 sA = {0.f, 0.f, 0.f, 0.f}, sB = sA;
+    auto side_affine = [&](int chunk) {
+        if constexpr (SIDE) {
+            if (side_on) { sA = *reinterpret_cast<const f32x4*>(sAp + chunk * 32); sB = *reinterpret_cast<const f32x4*>(sBp + chunk * 32); }
+        }
+    };
+    auto side_store = [&](f32x4 v, int chunk, int j) {
+        if constexpr (SIDE) {
+            const int row = m0 + lrow + 32 * j;
+            if (side_on && row < a.M) {
+                f32x4 r = v * sA + sB;
+                r.x = silu_f(r.x); r.y = silu_f(r.y); r.z = silu_f(r.z); r.w = silu_f(r.w);
+                *reinterpret_cast<f32x4*>(a.side + (size_t)row * a.Cin + chunk * 32 + lq * 4) = r;
+            }
+        }
+    };
     auto a_prefetch = [&](int chunk, int rs) {
         if constexpr (CONV) {
             const int tap = chunk / cpt, c = (chunk - tap * cpt) * 32;
@@ -132,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             f32x4 v = ra[rs][j];
+            side_store(v, 0, j);                 // (the prologue's chunk)
             if constexpr (ACT) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
             bf16x4 p1, p2, p3;
             split3(v, p1, p2, p3);
@@ -192,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
 
     const int nks = 2 * nchunk;
     a_prefetch(0, 0);
+    side_affine(0);
     if constexpr (PF == 3) { a_prefetch(min(1, nchunk - 1), 1); a_prefetch(min(2, nchunk - 1), 2); }
 #pragma unroll
     for (int r = 0; r < RING - 1; ++r) b_load(r, min(r, nks - 1));
@@ -230,8 +256,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         if (X3 && p2 == 2) return;
         afr[slot][i][p2] = *reinterpret_cast<const bf16x8*>(Ab + p2 * PLANE + aoff + i * 32 * SROW + ks * 32);
     };
-    auto a_store_one = [&](char* Ad, int rs, int j) {
+    auto a_store_one = [&](char* Ad, int rs, int j, int data_chunk) {
         f32x4 v = ra[rs][j];
+        if (data_chunk >= 0) side_store(v, data_chunk, j);
         if constexpr (ACT) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
         bf16x4 p1, p2, p3;
         split3(v, p1, p2, p3);
@@ -267,11 +294,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
                 if (ks == 0) {
 #pragma unroll
                     for (int q = t; q < AR; q += NT) if (!(VD_GS_SKIP & 2)) a_prefetch_one(pf_chunk, pf_slot, q);
+                    if (SIDE && t == NT - 1 && chunk + 1 < nchunk) side_affine(chunk + 1);   // PF = 1: the chunk stored in the second k-step
 #pragma unroll
                     for (int q = t; q < MI * 3; q += NT) a_frag_one(aslot ^ 1, Acur, 1, q);
                 } else {
 #pragma unroll
-                    for (int q = t; q < AR; q += NT) if (!(VD_GS_SKIP & 6)) a_store_one(Anext, st_slot, q);
+                    for (int q = t; q < AR; q += NT) if (!(VD_GS_SKIP & 6)) a_store_one(Anext, st_slot, q, SIDE && chunk + 1 < nchunk ? chunk + 1 : -1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -345,10 +373,26 @@ bool gemm_split_supported(const IgemmArgs& a) {
            (size_t)a.M * std::max(std::max(a.C0, a.Cin - a.C0), a.ldo) < (1u << 28) && (size_t)a.Cin * a.Cout * 6 < (1u << 31);
 }
 
+bool gemm_split_side_supported(const IgemmArgs& a) {
+    return gemm_split_supported(a) && a.act == 0 && a.zcount <= 1 && gemm_split_tile_class(a.M, a.Cout) == 0 &&
+           a.side_hw > 0 && a.side_hw % 128 == 0 && a.M % a.side_hw == 0;
+}
+
 template <int BM, int BN>
 static int launch_gs(const IgemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * 3 * BM * SROW;
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.zcount > 1 ? a.zcount : 1);
+    if (a.side) {
+        if constexpr (BM == 128 && BN == 128) {
+            VD_REQUIRE(gemm_split_side_supported(a) && a.sideA && a.sideB, "side output: plain 1x1 on the 128x128 tile, whole frames of a multiple of 128 rows");
+            if (x3_math()) hipLaunchKernelGGL((gemm_split_kernel<128, 128, false, false, true, true>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((gemm_split_kernel<128, 128, false, false, false, true>), grid, dim3(256), lds, s, a);
+            VD_HIP(hipGetLastError());
+            return 0;
+        } else {
+            VD_REQUIRE(false, "side output: 128x128 tile only");
+        }
+    }
     if (x3_math()) {                         // the declared three-product mode (vd_common.h)
         if (a.ksz == 3) {
             if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, true, true>), grid, dim3(256), lds, s, a);

@@ -274,6 +274,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
         if (a.affA) { b.affA = a.affA + (size_t)f0 * a.Cin; b.affB = a.affB + (size_t)f0 * a.Cin; }
         if (a.fbias) b.fbias = a.fbias + (size_t)f0 * a.fbias_ld;
         if (a.stats) b.stats = a.stats + (size_t)f0 * a.stats_split * a.Cout * 2;
+        if (a.side) { b.side = a.side + (size_t)f0 * HWo * a.Cin; b.sideA = a.sideA + (size_t)f0 * a.Cin; b.sideB = a.sideB + (size_t)f0 * a.Cin; }
         const int rc = launch_igemm_one(b, s);
         if (rc) return rc;
     }

@@ -40,6 +40,10 @@ struct IgemmArgs {
     int nfr, Hs, Ws;     // stored source dims
     int ups;             // 1: source is read through a nearest x2 upsample (unet.py:69)
     int ups_phase = 0;   // with ups = 1: wwino holds the sub-pixel image (pack_conv3_wino_ups); conv_wino_r64.hip
+    // gemm_split.hip, 1x1 over a (virtually concatenated) input, 128x128 tile: the column blocks 0 also write
+    // side[m][k] = SiLU(A[m][k] * sideA[frame][k] + sideB[frame][k]) -- the GroupNorm(+FiLM)+SiLU image the ResBlock's first
+    // conv reads (norm.hip: affine_act_kernel) -- from the A tile they stage anyway; side_hw = rows per frame (% 128 == 0)
+    float* side = nullptr; const float* sideA = nullptr; const float* sideB = nullptr; int side_hw = 0;
     int stride, pad, ksz;
     int Ho, Wo;
     const float* w;      // [ksz*ksz][Cout][Cin]           (generic kernel)
@@ -153,7 +157,8 @@ void pack_conv3_wino_ups(const float* oihw, unsigned short* out, int O, int I); 
 int conv_wino_ups_stats_split(int Hs);
 int conv_wino_r64_ksplit(int nfr, int Hl, int Cin, int Cout);            // slices of the channel loop a small grid is cut into (1: none)
 size_t conv_wino_r64_ksplit_floats(int nfr, int Hl, int Cin, int Cout);  // floats of scratch the caller then provides in ksplit_ws
-bool gemm_split_supported(const IgemmArgs& a);            // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
+bool gemm_split_supported(const IgemmArgs& a);
+bool gemm_split_side_supported(const IgemmArgs& a);   // IgemmArgs::side (the ResBlock's activation image from the skip conv's A tiles)            // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
 bool conv_split_supported(const IgemmArgs& a);          // 3x3, stride 1|2: the same kernel over an implicit im2col A
 void pack_conv3_split(const float* w_oihw, unsigned short* out, int Cout, int Cin);
 int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s);
