@@ -21,7 +21,7 @@ for nfr, Cin, Cout, H in SHAPES:
     out = torch.empty(nfr, H, H, Cout, device="cuda")
 
     def run():
-        op(_lib.ptr(x0), Cin, nfr, H, H, 0, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(res), None, 0, _lib.ptr(out), Cout, None, _lib.current_stream())
+        op(_lib.ptr(x0), Cin, nfr, H, H, 0, _lib.ptr(ws), _lib.ptr(b), (None if os.environ.get("VD_WT_NORES") else _lib.ptr(res)), None, 0, _lib.ptr(out), Cout, None, _lib.current_stream())
     for _ in range(100):
         run()
     torch.cuda.synchronize()
