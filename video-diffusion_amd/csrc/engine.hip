@@ -337,6 +337,8 @@ struct vd_engine {
                    hipStream_t st, Arena& ar, Tens* out);
     int gn_fold(const Tens& x0, const Tens* x1, int N, int gw, int gb, const float* film,
                 int film_ld, hipStream_t st, Arena& ar, float** A, float** B, float** mr = nullptr);
+    int gn_act(const Tens& x0, const Tens* x1, int N, int gw, int gb, const float* film, int film_ld, int act, float* y,
+               hipStream_t st, Arena& ar);
     int backward(const FwdIn& in, const float* deps, float* dx, hipStream_t st, Arena& ar);
     int bwd_linear(const float* dy, int M, int pw, const float* res, float* out, hipStream_t st);
     int bwd_conv3(Tens dy, int N, int pw, int cout_bwd, const float* res, float* out, hipStream_t st, Arena& ar);
@@ -625,6 +627,36 @@ int vd_engine::gn_fold(const Tens& x0, const Tens* x1, int N, int gw, int gb,
                             C, *A, *Bp, st, mrp);
 }
 
+// GroupNorm(+FiLM) + SiLU of a (virtually concatenated) tensor into y in ONE launch: the activation pass folds the statistics
+// itself (norm.hip: affine_act_fold_kernel).  For consumers that need nothing but y; not with a tape (the backward pass reads
+// A, B and mean / rstd).  VD_NO_GN_FOLD_FUSE: A/B switch (decided per process: the arena layout follows it).
+static bool gn_fold_fused() {
+    static const bool off = getenv("VD_NO_GN_FOLD_FUSE") != nullptr;
+    return !off;
+}
+int vd_engine::gn_act(const Tens& x0, const Tens* x1, int N, int gw, int gb, const float* film, int film_ld, int act, float* y,
+                      hipStream_t st, Arena& ar) {
+    const int HW = x0.H * x0.H, C = x0.C + (x1 ? x1->C : 0);
+    const Tens* src[2] = {&x0, x1};
+    const double* part[2] = {nullptr, nullptr};
+    int split[2] = {0, 0};
+    for (int i = 0; i < 2; ++i) {
+        if (!src[i]) continue;
+        if (src[i]->part) { part[i] = src[i]->part; split[i] = src[i]->split; continue; }
+        split[i] = gn_stats_split(N, HW, src[i]->C);
+        double* pt = ar.get<double>((size_t)N * split[i] * src[i]->C * 2);
+        part[i] = pt;
+        if (ar.dry) continue;
+        ProfScope ps(PC_GN_STATS, 0.0, 4.0 * N * HW * src[i]->C, st);
+        int rc = launch_gn_stats(src[i]->p, nullptr, src[i]->C, src[i]->C, N, HW, pt, split[i], st);
+        if (rc) return rc;
+    }
+    if (ar.dry) return 0;
+    GnFold f{part[0], split[0], part[1], split[1], (double)HW * (C / 32), W(gw), W(gb), film, film_ld};
+    ProfScope ps(PC_ELEMENTWISE, 0.0, 8.0 * N * HW * C, st);
+    return launch_affine_act_fold(x0.p, x1 ? x1->p : nullptr, x0.C, C, f, N, HW, act, y, st);
+}
+
 // the epilogue of the Winograd conv (the kernel every PK_CONV3W weight runs on) writes the GroupNorm partial sums of
 // its output: allocate the table and hand it to the launch
 static double* stats_table(Arena& ar, int N, int Hout, int Cout, int* split) {
@@ -649,14 +681,8 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     const int cin = x0.C + (x1 ? x1->C : 0);
     VD_REQUIRE(cin == r.cin, "ResBlock input channels");
     const float* s1 = x1 ? x1->p : nullptr;
-    float *A1, *B1, *A2, *B2, *mr1 = nullptr, *mr2 = nullptr;
-    int rc = gn_fold(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, st, ar, &A1, &B1, &mr1);
-    if (rc) return rc;
-    float* h = ar.get<float>((size_t)N * HW * r.cout);
-    Tens ht{h, r.cout, H};
-    if (params[r.c1w].kind == PK_CONV3W) ht.part = stats_table(ar, N, H, r.cout, &ht.split);
-    Tens ot{nullptr, r.cout, H};
-    if (params[r.c2w].kind == PK_CONV3W) ot.part = stats_table(ar, N, H, r.cout, &ot.split);
+    float *A1 = nullptr, *B1 = nullptr, *A2 = nullptr, *B2 = nullptr, *mr1 = nullptr, *mr2 = nullptr;
+    int rc;
     const float* film = film_all + r.film_off;
     // The skip convolution (1x1 over the block input, unet.py:159-166) reads the tensor the first GroupNorm+SiLU reads: where
     // it runs on the 128x128 tile of gemm_split.hip its column blocks 0 write that activation image from the rows they stage
@@ -672,17 +698,28 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         one.wfrag = one.wfrag ? one.wfrag : reinterpret_cast<const float*>(0x1000);      // dry run: no weight image yet, the shape decides
         fuse_skip = params[r.skw].kind == PK_LINF && split_math() && gemm_split_side_supported(one);
     }
+    // the statistics folded by the activation pass itself (gn_act) wherever nothing else reads (A, B): not for the skip
+    // convolution that writes the image (it takes the pair as arrays), not with a tape
+    const bool fold = !tape && gn_fold_fused();
+    const bool fold1 = fold && !fuse_skip;
+    if (!fold1 && (rc = gn_fold(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, st, ar, &A1, &B1, &mr1))) return rc;
+    float* h = ar.get<float>((size_t)N * HW * r.cout);
+    Tens ht{h, r.cout, H};
+    if (params[r.c1w].kind == PK_CONV3W) ht.part = stats_table(ar, N, H, r.cout, &ht.split);
+    Tens ot{nullptr, r.cout, H};
+    if (params[r.c2w].kind == PK_CONV3W) ot.part = stats_table(ar, N, H, r.cout, &ot.split);
     float* sk_early = fuse_skip ? ar.get<float>((size_t)N * HW * r.cout) : nullptr;
     {   // SiLU(GroupNorm(concat(x0, x1))) once, into a transient; the conv then reads plain activations (norm.hip)
         const size_t mk = ar.mark();
         float* a1 = ar.get<float>((size_t)N * HW * cin);
         const size_t ksf = conv_wino_r64_ksplit_floats(N, H, cin, r.cout);      // small grids: split-K scratch (conv_wino_r64.hip)
         float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
+        if (fold1 && (rc = gn_act(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, 1, a1, st, ar))) return rc;
         if (!ar.dry) {
             if (fuse_skip) {
                 gsk.bias = W(r.skb); gsk.out = sk_early; gsk.side = a1; gsk.sideA = A1; gsk.sideB = B1;
                 if ((rc = igemm_p(gsk, st))) return rc;
-            } else if ((rc = affine_act(x0.p, s1, x0.C, cin, A1, B1, N, HW, a1, st))) return rc;
+            } else if (!fold1 && (rc = affine_act(x0.p, s1, x0.C, cin, A1, B1, N, HW, a1, st))) return rc;
             Tens at{a1, cin, H};
             IgemmArgs g = conv_args(at, nullptr, N, 3, 1, 0);
             set_w(g, r.c1w); g.bias = W(r.c1b);
@@ -693,8 +730,8 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         }
         ar.release(mk);
     }
-    rc = gn_fold(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, st, ar, &A2, &B2, &mr2);
-    if (rc) return rc;
+    if (!fold && (rc = gn_fold(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, st, ar, &A2, &B2, &mr2)))
+        return rc;
     const float* skip = x0.p;
     if (fuse_skip) skip = sk_early;
     else if (r.skw >= 0) {
@@ -714,8 +751,9 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         float* a2 = ar.get<float>((size_t)N * HW * r.cout);
         const size_t ksf = conv_wino_r64_ksplit_floats(N, H, r.cout, r.cout);
         float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
+        if (fold && (rc = gn_act(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, 1, a2, st, ar))) return rc;
         if (!ar.dry) {
-            if ((rc = affine_act(h, nullptr, r.cout, r.cout, A2, B2, N, HW, a2, st))) return rc;
+            if (!fold && (rc = affine_act(h, nullptr, r.cout, r.cout, A2, B2, N, HW, a2, st))) return rc;
             Tens at{a2, r.cout, H};
             IgemmArgs g = conv_args(at, nullptr, N, 3, 1, 0);
             set_w(g, r.c2w); g.bias = W(r.c2b);
@@ -790,16 +828,18 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
         if ((rc = linear(o, (int)tok, C, 0, 0, C, W(a.tp.projw), W(a.tp.projb), 0, xn, xt, st, &xt_t))) return rc;
     }
     // ---- spatial attention over the HW pixels of each frame               (unet.py:258-267)
-    float *A, *Bf, *mrs = nullptr;
-    if ((rc = gn_fold(xt_t, nullptr, N, a.sp.normw, a.sp.normb, nullptr, 0, st, ar, &A, &Bf, &mrs))) return rc;
+    float *A = nullptr, *Bf = nullptr, *mrs = nullptr;
+    const bool fold = !tape && gn_fold_fused();
+    if (!fold && (rc = gn_fold(xt_t, nullptr, N, a.sp.normw, a.sp.normb, nullptr, 0, st, ar, &A, &Bf, &mrs))) return rc;
     float* xn2 = ar.get<float>(tok * C);
     float* qkv2 = ar.get<float>(tok * 3 * C);
     float* o2 = ar.get<float>(tok * C);
     float* xs = ar.get<float>(tok * C);
     Tens xs_t{xs, C, H};                               // the block's output: the next ResBlock's GroupNorm (or a skip) reads it
     gemm_stats_table(ar, (int)tok, C, C, &xs_t);
+    if (fold && (rc = gn_act(xt_t, nullptr, N, a.sp.normw, a.sp.normb, nullptr, 0, 0, xn2, st, ar))) return rc;
     if (!ar.dry) {
-        { ProfScope ps(PC_ELEMENTWISE, 0.0, 8.0 * tok * C, st); rc = launch_affine_apply(xt, A, Bf, N, HW, C, xn2, st); }
+        if (!fold) { ProfScope ps(PC_ELEMENTWISE, 0.0, 8.0 * tok * C, st); rc = launch_affine_apply(xt, A, Bf, N, HW, C, xn2, st); }
         if (rc) return rc;
         if ((rc = linear(xn2, (int)tok, C, 0, 0, 3 * C, W(a.sp.qkvw), W(a.sp.qkvb), 0, nullptr, qkv2, st))) return rc;
         AttnSpatialArgs sa{qkv2, o2, N, HW, C, cfg.num_heads, scale};

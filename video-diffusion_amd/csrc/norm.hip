@@ -193,6 +193,100 @@ int launch_affine_act(const float* src0, const float* src1, int C0, int C, const
     return 0;
 }
 
+// ------------------------------------------------------------------ the fold inside the pass
+// gn_final_affine_kernel is 7.5 us of dependent round trips per launch whatever the size (56 launches per step, 0.42 ms: the
+// largest item of the step that is not work).  Here every block of the activation pass folds the statistics of ITS frame
+// itself -- the per-channel sums of the producer's pixel ranges (thread (pixel lane, quad) walks the ranges pl, pl + ppi, ..),
+// summed over the pixel lanes in a fixed order, then the group's cg channels -- and forms (A, B) of its channel quad with the
+// formulas of gn_final_affine_kernel.  The table of a frame is 2 * split * C doubles from L2; the blocks of a CU overlap
+// each other's fold.  The backward pass (tape) and the consumers that read (A, B) as arrays keep the two-launch form.
+__global__ __launch_bounds__(256) void affine_act_fold_kernel(const float* __restrict__ src0, const float* __restrict__ src1,
+                                                              int C0, int C, GnFold f, int HW, int per, int act,
+                                                              float* __restrict__ y) {
+    __shared__ double red[256 * 8];              // [pixel lane][quad][4 sums | 4 sums of squares]
+    __shared__ double gs[1024 * 2];              // [channel][sum, sum of squares] of the frame
+    const int n = blockIdx.y;
+    const int tpp = C >> 2, ppi = blockDim.x / tpp;
+    const int tid = threadIdx.x;
+    const int pl = tid / tpp, c = (tid - pl * tpp) * 4;
+    const int C1 = C - C0, cg = C / 32;
+    {
+        const bool second = c >= C0;
+        const int split = second ? f.split1 : f.split0, ld = second ? C1 : C0, cc = second ? c - C0 : c;
+        const double* p = (second ? f.part1 : f.part0) + ((size_t)n * split * ld + cc) * 2;
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int sp = pl; sp < split; sp += ppi) {
+            const double* q = p + (size_t)sp * ld * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += q[2 * e]; a[4 + e] += q[2 * e + 1]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = a[e];
+    }
+    __syncthreads();
+    if (tid < tpp) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < ppi; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += red[(k * tpp + tid) * 8 + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gs[(tid * 4 + e) * 2] = a[e]; gs[(tid * 4 + e) * 2 + 1] = a[4 + e]; }
+    }
+    __syncthreads();
+    f32x4 A, B;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int g = (c + e) / cg;
+        double s = 0, ss = 0;
+        for (int k = 0; k < cg; ++k) { s += gs[(g * cg + k) * 2]; ss += gs[(g * cg + k) * 2 + 1]; }
+        const double mean = s / f.count;
+        double var = ss / f.count - mean * mean;
+        if (var < 0) var = 0;
+        const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + 1e-5));
+        float Ae = rf * f.gamma[c + e];
+        float Be = f.beta[c + e] - mf * Ae;
+        if (f.film) {
+            const float sc = 1.0f + f.film[(size_t)n * f.film_ld + c + e];
+            const float sh = f.film[(size_t)n * f.film_ld + C + c + e];
+            Ae *= sc;
+            Be = Be * sc + sh;
+        }
+        A[e] = Ae; B[e] = Be;
+    }
+    const int p_begin = blockIdx.x * per, p_end = min(HW, p_begin + per);
+    const float* src; int ld;
+    if (c < C0) { src = src0 + (size_t)n * HW * C0 + c; ld = C0; } else { src = src1 + (size_t)n * HW * C1 + (c - C0); ld = C1; }
+    float* dst = y + (size_t)n * HW * C + c;
+    auto one = [&](f32x4 v) {
+        f32x4 r = v * A + B;
+        if (act) { r.x = silu_f(r.x); r.y = silu_f(r.y); r.z = silu_f(r.z); r.w = silu_f(r.w); }
+        return r;
+    };
+    auto ld4 = [&](const float* q) { return (VD_AA_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : *reinterpret_cast<const f32x4*>(q); };
+    int p = p_begin + pl;
+    for (; p + 3 * ppi < p_end; p += 4 * ppi) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld4(src + (size_t)(p + u * ppi) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(dst + (size_t)(p + u * ppi) * C) = one(v[u]);
+    }
+    for (; p < p_end; p += ppi) *reinterpret_cast<f32x4*>(dst + (size_t)p * C) = one(*reinterpret_cast<const f32x4*>(src + (size_t)p * ld));
+}
+
+int launch_affine_act_fold(const float* src0, const float* src1, int C0, int C, const GnFold& f, int nfr, int HW, int act, float* y,
+                           hipStream_t s) {
+    VD_REQUIRE(C % 32 == 0 && C0 % 4 == 0 && C <= 1024 && (src1 != nullptr || C0 == C), "affine_act_fold: channel counts");
+    VD_REQUIRE(f.part0 && (C0 == C || f.part1), "affine_act_fold: GroupNorm partial tables");
+    const int tpp = C / 4, ppi = 256 / tpp, threads = ppi * tpp;
+    int split = 1;
+    while (nfr * split < 2048 && HW / (split * 2) >= ppi * 16) split *= 2;
+    const int per = (HW + split - 1) / split;
+    hipLaunchKernelGGL(affine_act_fold_kernel, dim3(split, nfr), dim3(threads), 0, s, src0, src1, C0, C, f, HW, per, act, y);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ y = x*A[n][c] + B[n][c]
 // the same pass without the activation (attention blocks: the normalised tensor is also the residual, unet.py:474,538)
 int launch_affine_apply(const float* x, const float* affA, const float* affB, int nfr, int HW, int C, float* y,

@@ -180,6 +180,11 @@ int gn_stats_split(int nfr, int HW, int C);
 int launch_gn_affine(const double* part0, int split0, int C0, const double* part1, int split1, double count,
                      const float* gamma, const float* beta, const float* film, int film_ld, int nfr, int C, float* affA,
                      float* affB, hipStream_t s, float* mr_out = nullptr);      // mr_out: [nfr][32][2] mean, rstd (backward pass)
+// launch_gn_affine + launch_affine_act in one launch: every block folds its frame's statistics itself (norm.hip).
+struct GnFold { const double* part0; int split0; const double* part1; int split1; double count; const float* gamma; const float* beta;
+                const float* film; int film_ld; };
+int launch_affine_act_fold(const float* src0, const float* src1, int C0, int C, const GnFold& f, int nfr, int HW, int act, float* y,
+                           hipStream_t s);
 // y = x*A[n][c] + B[n][c]  (materialised normalisation for the attention residual, unet.py:474,538)
 // y[n][p][0..C) = silu?(concat(src0, src1)[n][p][c] * A[n][c] + B[n][c])
 int launch_affine_act(const float* src0, const float* src1, int C0, int C, const float* affA, const float* affB, int nfr,
