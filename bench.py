@@ -285,15 +285,17 @@ def main():
     import video_diffusion_amd as vda
     from video_diffusion_amd import dist as vdist
 
-    # The matrix products run as six bf16 piece products of exactly split fp32 operands (as accurate as the fp32 MFMA,
-    # DESIGN.md 3).  For a reader who wants the number with EVERY matrix product on the fp32 MFMA, the same benchmark is
-    # run first in a child process with VD_MATH=fp32 -- started before this process touches the GPU.
-    fp32_ref = x3_ref = pc_ref = None
+    # The matrix products run in the library's default arithmetic (VD_MATH=f16x3: fp32 operands carried as two fp16 pieces,
+    # three piece products, fp32 accumulation -- as accurate against fp64 as the fp32 MFMA).  For a reader who wants
+    # the number in the EXACT-split arithmetic (bf16x6, the default of earlier rounds) or with every matrix product on the fp32
+    # MFMA, the same benchmark is run first in child processes with VD_MATH set -- started before this process touches the GPU.
+    math = os.environ.get("VD_MATH") or "f16x3"
+    fp32_ref = x6_ref = pc_ref = None
     # (never under a profiler: its preloaded library has already initialised the GPU in this process, and starting
     # another program from such a process is not allowed on the GPU boxes)
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(
         k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ)
-    if args.gpus == 1 and not args.no_fp32_ref and not profiled and os.environ.get("VD_MATH") not in ("fp32", "bf16x3"):
+    if args.gpus == 1 and not args.no_fp32_ref and not profiled and math == "f16x3":
         child = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--no-cpu-baseline",
                                 "--no-roofline", "--no-fp32-ref", "--no-dropin"], env={**os.environ, "VD_MATH": "fp32"},
                                capture_output=True, text=True)
@@ -302,19 +304,16 @@ def main():
             fp32_ref = {"value": ref["value"], "ms_per_step": ref["ms_per_step"], "note": "VD_MATH=fp32: every matrix product on v_mfma_f32_32x32x2_f32"}
         except Exception:                                            # noqa: BLE001 - the headline run must not depend on it
             fp32_ref = {"error": (child.stderr or child.stdout)[-300:]}
-        # the DECLARED reduced mode (three of the six piece products; tools/x3_check.py + tests/test_gpu_ops.py pin its error):
-        # an extra object only -- `value`, `dtype` and `roofline` of this line stay the exact-split arithmetic
         child = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--no-cpu-baseline",
-                                "--no-roofline", "--no-fp32-ref", "--no-dropin"], env={**os.environ, "VD_MATH": "bf16x3"},
+                                "--no-roofline", "--no-fp32-ref", "--no-dropin"], env={**os.environ, "VD_MATH": "bf16x6"},
                                capture_output=True, text=True)
         try:
             ref = json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1])
-            x3_ref = {"value": ref["value"], "ms_per_step": ref["ms_per_step"],
-                      "note": "VD_MATH=bf16x3, a declared REDUCED mode (operands ~16 significant bits: a1b1 + a1b2 + a2b1; the reference "
-                              "itself samples with TF32 allowed, scripts/video_sample.py:21-22); eps within 5e-4 of the reference on the "
-                              "default model (tools/x3_check.py); NOT the headline, not the default"}
+            x6_ref = {"value": ref["value"], "ms_per_step": ref["ms_per_step"],
+                      "note": "VD_MATH=bf16x6: fp32 operands split EXACTLY into three bf16 pieces, six piece products (the default "
+                              "arithmetic of rounds 1-3; same kernels, twice the MFMAs)"}
         except Exception:                                            # noqa: BLE001
-            x3_ref = {"error": (child.stderr or child.stdout)[-300:]}
+            x6_ref = {"error": (child.stderr or child.stdout)[-300:]}
         # the window executor with the prefix cache (opt-in): work that a window really does only once is outside its timed
         # steps, so it is an extra object too -- `value` stays the step that recomputes every frame
         if args.executor == "eager":
@@ -401,9 +400,10 @@ def main():
                     traffic_source = "profiles/pmc_dominant.json (rocprofv3 --pmc passes of this workload on this kernel source, not this run)"
                 elif rec.get("kernel") == name:
                     traffic_source = "profiles/pmc_dominant.json is stale (kernel source changed since the PMC passes): traffic withheld"
-            split_conv = name in ("conv3x3_wino_s64_kernel", "conv3x3_wino_r64_kernel")
-            # the dominant kernel runs on the bf16 matrix pipe (fp32 operands split exactly into three bf16 pieces) unless
-            # VD_CONV_SPLIT=0 / VD_MATH=fp32 keep it on the fp32 MFMA: `peak` is the dense peak of the pipe it uses
+            split_conv = name == "conv3x3_wino_r64_kernel"
+            pieces = 3 if math == "f16x3" else 6                              # piece products per element product
+            # the dominant kernel runs on the 16-bit matrix pipe (fp32 operands carried as fp16 / bf16 pieces) unless
+            # VD_MATH=fp32 keeps it on the fp32 MFMA: `peak` is the dense peak of the pipe it uses (f16 = bf16 rate)
             peak = PEAK_BF16_MFMA_TFLOPS if split_conv or name.startswith("gemm_split") else PEAK_FP32_MFMA_TFLOPS
             roofline = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=peak,
                             unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
@@ -414,9 +414,10 @@ def main():
                                       "kept busy is mfma_executed_frac")
             if name.startswith("conv3x3_wino"):
                 # `achieved` counts the ALGORITHMIC flops of a direct fp32 3x3 convolution (2*M*Cout*Cin*9).  Winograd
-                # F(2x2,3x3) executes 16/36 of the multiplications; the split kernel spends six bf16 piece products
-                # on each, so the matrix pipe executes achieved * 6 / 2.25 bf16 flops (fp32 kernel: achieved / 2.25)
-                ex = achieved * (6 / 2.25 if split_conv else 1 / 2.25)
+                # F(2x2,3x3) executes 16/36 of the multiplications; the split kernel spends `pieces` piece products
+                # on each, so the matrix pipe executes achieved * pieces / 2.25 flops (fp32 kernel: achieved / 2.25)
+                ex = achieved * (pieces / 2.25 if split_conv else 1 / 2.25)
+                roofline["piece_products"] = pieces if split_conv else 1
                 roofline["mfma_executed_tflops"] = round(ex, 2)
                 roofline["mfma_executed_frac"] = round(ex / peak, 4)
                 if split_conv:
@@ -443,14 +444,14 @@ def main():
         "metric": "denoise-steps/sec", "value": round(value, 4), "unit": "denoise-steps/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": "every matrix product on the fp32 MFMA" if os.environ.get("VD_MATH") == "fp32" else
-                      "DECLARED REDUCED MODE VD_MATH=bf16x3: three of the six bf16 piece products (operands ~16 significant bits); not "
-                      "the arithmetic the headline is quoted in" if os.environ.get("VD_MATH") == "bf16x3" else
-                      "fp32 operands and fp32 accumulation throughout; matrix products (3x3 convs as Winograd F(2x2,3x3), "
-                      "linear layers, 1x1 and stride-2 convs): fp32 operands split EXACTLY into three bf16 pieces, six piece "
-                      "products on the bf16 MFMA with fp32 accumulation (error vs fp64 <= that of the fp32 MFMA; "
-                      "tests/test_gpu_ops.py)" + ("; VD_CONV_SPLIT=0: 3x3 convs on the fp32 MFMA"
-                                                  if os.environ.get("VD_CONV_SPLIT") == "0" else ""),
+        "arithmetic": "VD_MATH=fp32: every matrix product on the fp32 MFMA" if math == "fp32" else
+                      "VD_MATH=bf16x6: fp32 operands and fp32 accumulation; matrix products as six bf16 piece products of EXACTLY split "
+                      "fp32 operands" if math == "bf16x6" else
+                      "VD_MATH=f16x3 (default): fp32 tensors and fp32 accumulation throughout; in the matrix products (3x3 convs as "
+                      "Winograd F(2x2,3x3), linear layers, 1x1 and stride-2 convs) every fp32 operand is carried as two fp16 pieces "
+                      "(22 significand bits, exact power-of-two scaling) and a product is three piece products on the f16 MFMA; error "
+                      "against fp64 held to the fp32-MFMA kernel's (mean <= 1.5x, max <= 2.5x: tests/test_gpu_ops.py, "
+                      "profiles/r04_split_accuracy.json); the exact-split and fp32-MFMA numbers of the same run: bf16x6_exact_split, fp32_mfma_only",
         "sec_per_clip_batch": round(nts * elapsed / args.steps, 2),
         "config": {"workload": workload, "batch_per_gpu": B, "frames": T, "image_size": S, "respaced_steps": nts,
                    "parallelism": f"batch-shard x{world} (no collective in the step)", "rccl_ranks": world,
@@ -466,8 +467,8 @@ def main():
                                   "(scripts/video_sample.py:151), torch.randn_like noise, fresh tensors per step"}
     if fp32_ref is not None:
         line["fp32_mfma_only"] = fp32_ref
-    if x3_ref is not None:
-        line["bf16x3_declared_reduced_mode"] = x3_ref
+    if x6_ref is not None:
+        line["bf16x6_exact_split"] = x6_ref
     if pc_ref is not None:
         line["window_prefix_cache_opt_in"] = pc_ref
     if classes is not None:

@@ -48,6 +48,9 @@ typedef struct vd_engine vd_engine;
 
 const char* vd_last_error(void);
 const char* vd_version(void);
+/* 16 hex digits: SHA-1 over the compiler flags and every source the library was built from (_lib.source_sha() recomputes it from
+ * the sources on disk: a loaded library that does not match them is stale, whatever the file times say). */
+const char* vd_source_sha(void);
 
 /* CondMargVideoModel(...) constructor via create_video_model (script_util.py:229-300; unet.py:929-947).
  * Host-only: builds the topology and the parameter table; touches no GPU. */
@@ -59,11 +62,11 @@ int vd_param_count(vd_engine* e);
 int vd_param_info(vd_engine* e, int index, char* name, int name_cap, int* ndim, long long shape[4]);
 
 /* model.load_state_dict(sd) (scripts/video_sample.py:565).  Weights live in ONE packed device buffer in kernel-ready
- * layouts chosen at load time (default arithmetic: 3x3 stride-1 convs as the Winograd image U = G g G^T split into three
- * bf16 planes [I/16][16][O/32][3][64][8]; linear / 1x1 / stem / stride-2 convs as split MFMA fragments
- * [K/16][N/32][3][64][8]; spatial_encoding -> [HW][C]) so that a single RCCL broadcast replaces
- * dist_util.sync_params' per-tensor broadcasts (dist_util.py:139-143).  The layout depends on VD_MATH / VD_CONV_SPLIT /
- * VD_CONV: vd_weights_layout_id() identifies it, and ranks compare it before accepting a broadcast buffer.
+ * layouts chosen at load time (split arithmetic: 3x3 stride-1 convs as the Winograd image U = G g G^T in three 16-bit
+ * planes [I/16][16][O/32][3][64][8]; linear / 1x1 / stem / stride-2 convs as split MFMA fragments
+ * [K/16][N/32][3][64][8], each image followed by its per-output scales; spatial_encoding -> [HW][C]) so that a
+ * single RCCL broadcast replaces dist_util.sync_params' per-tensor broadcasts (dist_util.py:139-143).  The layout depends on
+ * VD_MATH: vd_weights_layout_id() identifies it, and ranks compare it before accepting a broadcast buffer.
  * The buffer is caller-owned (e.g. a torch tensor) and must outlive the engine. */
 long long vd_weights_bytes(vd_engine* e);
 int vd_set_weight_storage(vd_engine* e, void* dev_buffer, long long bytes);
@@ -94,6 +97,9 @@ enum { VD_TAB_SQRT_RECIP = 0, VD_TAB_SQRT_RECIPM1, VD_TAB_COEF1, VD_TAB_COEF2, V
        VD_TAB_ALPHA /* alphas = 1 - betas (the guidance weight, gaussian_diffusion.py:363) */, VD_NTAB };
 int vd_set_schedule(vd_engine* e, int num_timesteps, const float* host_tab, const int* host_timestep_map,
                     float rescale);
+/* What the network's output is (ModelMeanType, gaussian_diffusion.py:29-36,326-341): 0 EPSILON (default); 1 START_X
+ * (predict_xstart=True, script_util.py:429-431): pred_xstart = clamp(model_output), DDIM derives eps from it. */
+int vd_set_model_mean_type(vd_engine* e, int type);
 
 
 /* Timestep indices outside [0, num_timesteps) make the reference raise IndexError (_extract_into_tensor,
@@ -241,11 +247,24 @@ int vd_profile_end(double* out, int cap);
 int vd_profile_classes(void);
 const char* vd_profile_class_name(int i);
 
+/* ---- arithmetic of the matrix products (environment VD_MATH, read once per process) -------------
+ *   0  f16x3  (default) an fp32 operand x is carried as two fp16 pieces, x ~ a0 + 2^-12 a1, a0 = f16(x), a1 = f16((x - a0) 2^12):
+ *             22 significand bits (relative error <= 2^-22 for 2^-14 <= |x| <= 65504, absolute <= 2^-37 below; larger |x| -> NaN,
+ *             never a silently wrong number); a product is three piece products a0 b0 + a0 b1 + a1 (2^-12 b0) on
+ *             v_mfma_f32_32x32x16_f16 with fp32 accumulation; weights carry a per-output power-of-two scale (image trailer).
+ *   1  bf16x6 the exact split: three bf16 pieces per operand, six piece products (the default of earlier releases).
+ *   2  fp32   every product on v_mfma_f32_32x32x2_f32.
+ * The packed weight image depends on it (vd_weights_layout_id). */
+int vd_math_mode(void);
+/* uint16 count of a split weight image with n_out outputs and k_total inputs per output, trailer included
+ * (= 3 n_out k_total + 4 n_out): [k/16][n_out/32][piece 3][lane 64][8 x 16 bit], then n_out float scales, n_out reciprocals. */
+long long vd_split_image_u16(long long n_out, long long k_total);
+
 /* ---- single-operator entry points (parity tests call the kernels through these) -------------- */
 /* NHWC conv / linear on fp32 MFMA.  src1/C0: virtual channel concat; affA/affB: folded GroupNorm(+FiLM);
  * act: SiLU on the operand; res: residual in the epilogue; fbias: per-frame bias [nfr][fbias_ld]. */
-/* w_packed: [tap][Cout][Cin] (generic kernel; may be NULL when w_frag covers the shape);
- * w_frag: MFMA-fragment-major weights from vd_pack_conv3_frag / vd_pack_linear_frag, or NULL;
+/* w_packed: [tap][Cout][Cin] (generic kernel; may be NULL when w_frag / w_wino covers the shape);
+ * w_frag: MFMA-fragment-major weights of a linear layer / 1x1 conv from vd_pack_linear_frag, or NULL;
  * w_wino: Winograd-transformed 3x3 weights from vd_pack_conv3_wino, or NULL (preferred when given and supported:
  *         one plain source tensor -- no concat, no affine/act prologue -- stride 1, square power-of-two >= 8x8,
  *         Cout % 64 == 0, Cin % 32 == 0). */
@@ -265,49 +284,37 @@ int vd_op_conv_stats(const float* src0, int Cin, int nfr, int Hs, int Ws, int up
 int vd_op_gn_affine(const double* part0, int split0, int C0, const double* part1, int split1, int C, int nfr, int HW,
                     const float* gamma, const float* beta, const float* film, int film_ld, float* affA, float* affB,
                     void* stream);
-/* Host repack OIHW (O, I multiples of 32) -> [tap][I/32][O/32][kgroup 4][lane 64][4]: lane 32h+r of k-group kg holds
- * w[co = 32*blk + r][ci = 32*chunk + 8*kg + 4*h + e]; one coalesced 1 KiB load per wave per MFMA k-group. */
-int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I);
-/* Winograd F(2x2,3x3) image of a 3x3 weight: U = G g G^T per (cout, cin) with row 2 negated (the kernel negates row 2
- * of B^T as well), 16*O*I floats in [I/16][16][O/32][2][64][4]; pass as w_wino. */
+/* Winograd F(2x2,3x3) image of a 3x3 weight for the fp32-MFMA kernel: U = G g G^T per (cout, cin) with row 2 negated (the
+ * kernel negates row 2 of B^T as well), 16*O*I floats in [I/16][16][O/32][2][64][4]; pass as w_wino. */
 int vd_pack_conv3_wino(const float* host_oihw, float* host_out, int O, int I);
-/* Same for an nn.Linear / 1x1-conv weight [N][K] (N, K multiples of 32) -> [K/32][N/32][4][64][4]; pass the result as
- * w_frag with ksz = 1. */
+/* nn.Linear / 1x1-conv weight [N][K] (N, K multiples of 32) -> [K/32][N/32][4][64][4] for the fp32-MFMA kernel; pass the
+ * result as w_frag with ksz = 1. */
 int vd_pack_linear_frag(const float* host_w, float* host_out, int N, int K);
-/* fp32-accurate linear layer on the bf16 matrix cores (csrc/gemm_split.hip): every fp32 operand is split exactly into
- * three bf16 pieces (3 x 8 significand bits), six of the nine piece products are accumulated in fp32; the weight is
- * split on the host: [N][K] (N, K multiples of 32) -> [K/16][N/32][3][64][8] bf16 = 3*N*K uint16.
- * out[m][n] = bias[n] + res[m][n] + sum_k f(a[m][k]) w[n][k], f = SiLU if act.  The engine's default for every
- * nn.Linear / 1x1 conv / the stem (environment VD_MATH=fp32 selects the plain fp32-MFMA kernels instead). */
+/* Linear layer on the 16-bit matrix cores at fp32 accuracy (csrc/gemm_split.hip) in the process' arithmetic (f16x3 | bf16x6;
+ * with VD_MATH=fp32 these entry points run bf16x6).  The weight is split on the host: [N][K] (N, K multiples of 32) ->
+ * vd_split_image_u16(N, K) uint16.  out[m][n] = bias[n] + res[m][n] + sum_k f(a[m][k]) w[n][k], f = SiLU if act.  The engine's
+ * kernel for every nn.Linear / 1x1 conv / the stem. */
 int vd_pack_linear_split(const float* host_w, unsigned short* host_out, int N, int K);
-/* 3x3 convolutions that Winograd does not cover (the stride-2 Downsample convs, unet.py:98) on the same six-product
- * arithmetic: the split GEMM kernel walks an implicit im2col operand (k = tap*I + c; taps outside the image read 0).
- * Weights: OIHW -> split fragment image of the [O][9*I] matrix = 27*O*I uint16.  stride 1 or 2, padding 1. */
+/* 3x3 convolutions that Winograd does not cover (the stride-2 Downsample convs, unet.py:98) on the same arithmetic: the
+ * split GEMM kernel walks an implicit im2col operand (k = tap*I + c; taps outside the image read 0).
+ * Weights: OIHW -> the split image of the [O][9*I] matrix = vd_split_image_u16(O, 9*I) uint16.  stride 1 or 2, padding 1. */
 int vd_pack_conv3_split(const float* host_oihw, unsigned short* host_out, int O, int I);
 int vd_op_conv_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int stride, const void* w_split, const float* bias,
                      const float* res, float* out, int Cout, void* stream);
-/* The same arithmetic for the 3x3 stride-1 convs: Winograd F(2x2,3x3) whose element products run as six bf16 piece
- * products of the exactly split fp32 operands, 64 couts per block.  Two kernels share the weight image: csrc/conv_wino_r64.hip
- * (input transform and split in the MFMA fragment layout, in registers: the engine's choice) and csrc/conv_wino_s64.hip
- * (block-wide transform through LDS); maps >= 8x8.  Weights: OIHW -> U = G g G^T (fp64, row 3 negated) split into
- * [I/16][16][O/32][3][64][8] bf16 = 48*O*I uint16.  One plain source tensor, stride 1, square power-of-two maps,
- * O % 64 == 0, I % 32 == 0; gn_part as vd_op_conv_stats (or NULL).  vd_op_conv_wino_split takes the kernel the engine
- * would (and cuts big windows along frames); the other two run the named kernel in one launch. */
-int vd_pack_conv3_wino_s64(const float* host_oihw, unsigned short* host_out, int O, int I);
+/* The same arithmetic for the 3x3 stride-1 convs: Winograd F(2x2,3x3) whose element products run as piece products of the
+ * split fp32 operands, 64 couts per block, input transform and split in the MFMA fragment layout, in registers
+ * (csrc/conv_wino_r64.hip); maps >= 8x8.  Weights: OIHW -> U = G g G^T (fp64, row 3 negated) split into
+ * [I/16][16][O/32][3][64][8] + trailer = vd_split_image_u16(O, 16*I) uint16.  One plain source tensor, stride 1, square
+ * power-of-two maps, O % 64 == 0, I % 32 == 0; gn_part as vd_op_conv_stats (or NULL).  Big windows are cut along frames. */
+int vd_pack_conv3_wino_split(const float* host_oihw, unsigned short* host_out, int O, int I);
 int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
                           const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
                           void* stream);
-int vd_op_conv_wino_s64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
-                        const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
-                        void* stream);
-int vd_op_conv_wino_r64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
-                        const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
-                        void* stream);
 /* Upsample (nearest x2, unet.py:70-77) + conv3x3 in its sub-pixel form on csrc/conv_wino_r64.hip: output pixel (2y + a, 2x + b) sees
  * only a 2 x 2 neighbourhood of the SOURCE map, i.e. four 3x3 "phase" kernels with one zero row and one zero column each
  * ((w0, w1 + w2, 0) for a = 0, (0, w0 + w1, w2) for a = 1; sums in fp64), convolved with the low-resolution map; in the Winograd
  * domain one of the four columns of every such kernel is zero and is skipped (a quarter of the matrix work of F(2x2,3x3) on
- * the upsampled map).  Weights: OIHW -> 4*O phase kernels -> the vd_pack_conv3_wino_s64 layout = 4 * 48*O*I uint16.  src0
+ * the upsampled map).  Weights: OIHW -> 4*O phase kernels -> the vd_pack_conv3_wino_split layout = vd_split_image_u16(4*O, 16*I) uint16.  src0
  * [nfr][Hs][Hs][Cin], out [nfr][2Hs][2Hs][Cout]; gn_part [nfr][vd_conv_ups_stats_split(Hs)][Cout][2] doubles or NULL. */
 int vd_pack_conv3_wino_ups(const float* host_oihw, unsigned short* host_out, int O, int I);
 int vd_conv_ups_stats_split(int Hs);

@@ -97,6 +97,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_lib.SIGNATURES) == declared
     assert b"gfx950" in L.vd_version()
+    assert L.vd_source_sha().decode() == _lib.source_sha()      # the loaded binary IS the sources beside it (content hash, not mtimes)
 
 
 def _cfg(tag):
@@ -127,8 +128,15 @@ def test_factory_error_behaviour():
         vda.create_video_model_and_diffusion(**{**d, "rp_alpha": None, "rp_beta": None, "rp_gamma": None})
     with pytest.raises(ValueError, match="cannot create exactly"):
         vda.create_video_model_and_diffusion(**{**d, "timestep_respacing": "ddim300"})
+    # do_cond_marg=False: the reference hands cond_emb_type to UNetVideoModel -> UNetModel.__init__, which does not take it
+    # (script_util.py:275-300; probed on the imported reference by tools/gen_golden_r4.py): same exception, same text
+    with pytest.raises(TypeError, match=r"UNetModel.__init__\(\) got an unexpected keyword argument 'cond_emb_type'"):
+        vda.create_video_model_and_diffusion(**{**d, "do_cond_marg": False})
+    from video_diffusion_amd import gaussian_diffusion as gd
+    _, dx = vda.create_video_model_and_diffusion(**{**d, "predict_xstart": True})       # script_util.py:429-431
+    assert dx.model_mean_type == gd.ModelMeanType.START_X
     model, diff = vda.create_video_model_and_diffusion(**{**d, "timestep_respacing": "ddim250"})
-    assert diff.num_timesteps == 250
+    assert diff.num_timesteps == 250 and diff.model_mean_type == gd.ModelMeanType.EPSILON
     with pytest.raises(RuntimeError, match="Missing key"):
         model.load_state_dict({})
     sd = {k: vda.weights_init.synth_param(k, s) for k, s in model.param_specs()}

@@ -10,20 +10,39 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libvdamd.so")
-SOURCES = ["igemm.hip", "conv_halo.hip", "conv_wino.hip", "conv_wino_s64.hip", "conv_wino_r64.hip", "gemm_frag.hip", "gemm_split.hip", "norm.hip", "backward.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "conv_wino.hip", "conv_wino_r64.hip", "gemm_frag.hip", "gemm_split.hip", "split_pack.hip", "norm.hip", "backward.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vd_amd.h")
 
 
 def _toolchain():
-    """(hipcc, flags) of this process' build and a short tag of them.  Objects are cached per tag (csrc/.obj/<tag>/) and
-    the tag of the linked library is kept beside it, so objects compiled with other flags (timing-only -DVD_*_SKIP builds
-    among them) can never be linked into, or mistaken for, the product library."""
-    import hashlib
+    """(hipcc, flags) of this process' build."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + \
         os.environ.get("VD_HIPCC_FLAGS", "").split()
-    tag = hashlib.sha1("\0".join([hipcc] + flags).encode()).hexdigest()[:12]
-    return hipcc, flags, tag
+    return hipcc, flags
+
+
+def _sha(*parts):
+    import hashlib
+    h = hashlib.sha1()
+    for p in parts:
+        h.update(p if isinstance(p, bytes) else str(p).encode())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def _read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def source_sha():
+    """Identity of the library the sources beside this file would build: SHA-1 over the compiler flags, every csrc/*.hip in
+    SOURCES, vd_common.h and include/vd_amd.h -- by CONTENT, so a checkout / rsync / snapshot with arbitrary mtimes can
+    neither hide a stale binary nor force a rebuild of a fresh one.  The built library carries it (vd_source_sha())."""
+    hipcc, flags = _toolchain()
+    return _sha("\0".join(flags), *[_read(os.path.join(_CSRC, s)) for s in SOURCES], _read(os.path.join(_CSRC, "vd_common.h")),
+                _read(HEADER))[:16]
 
 
 def _stale():
@@ -31,22 +50,14 @@ def _stale():
         return True
     try:
         with open(SO_PATH + ".flags") as f:
-            if f.read().strip() != _toolchain()[2]:
-                return True
+            return f.read().strip() != source_sha()
     except OSError:
         return True
-    t = os.path.getmtime(SO_PATH)
-    deps = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(_CSRC, "vd_common.h"), HEADER]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
-
-
-def _needs(obj, deps):
-    return not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps if os.path.exists(d))
 
 
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> in-tree libvdamd.so (cross-compiles without a GPU): one object per source
-    (csrc/.obj/, compiled in parallel, rebuilt only when the source or a header is newer), then one link.
+    (csrc/.obj/, compiled in parallel, rebuilt only when the hash of the source + headers + flags changed), then one link.
     One process per GPU may get here at once (torchrun): the build is serialised by a lock file and the library is
     written under a per-process name, so a rank either builds or waits and then finds the library fresh."""
     if not force and not _stale():
@@ -58,25 +69,37 @@ def build(force=False, verbose=False):
         try:
             if not force and not _stale():
                 return SO_PATH
-            hipcc, flags, tag = _toolchain()
-            objdir = os.path.join(_CSRC, ".obj", tag)
+            hipcc, flags = _toolchain()
+            sha = source_sha()
+            objdir = os.path.join(_CSRC, ".obj")
             os.makedirs(objdir, exist_ok=True)
-            hdrs = [os.path.join(_CSRC, "vd_common.h"), HEADER]
+            hdr_bytes = [_read(os.path.join(_CSRC, "vd_common.h")), _read(HEADER)]
+            # the library's identity as a translation unit of its own (generated: not part of the hash it states)
+            idsrc = os.path.join(objdir, "build_id.cpp")
+            with open(idsrc, "w") as f:
+                f.write(f'extern "C" const char* vd_source_sha(void) {{ return "{sha}"; }}\n')
 
             def compile_one(src):
-                obj = os.path.join(objdir, src.replace(".hip", ".o"))
-                path = os.path.join(_CSRC, src)
-                if force or _needs(obj, [path] + hdrs):
-                    cmd = [hipcc, *flags, "-c", path, "-o", obj]
+                path = idsrc if src is None else os.path.join(_CSRC, src)
+                obj = os.path.join(objdir, os.path.basename(path).rsplit(".", 1)[0] + ".o")
+                want = _sha("\0".join(flags), _read(path), *hdr_bytes)
+                try:
+                    have = open(obj + ".sha").read().strip()
+                except OSError:
+                    have = ""
+                if force or have != want or not os.path.exists(obj):
+                    cmd = [hipcc, *flags, "-c", path, "-o", obj] if src is not None else [hipcc, "-O2", "-fPIC", "-c", path, "-o", obj]
                     if verbose:
                         print(" ".join(cmd), flush=True)
                     r = subprocess.run(cmd, capture_output=True, text=True)
                     if r.returncode != 0:
                         raise RuntimeError(f"hipcc failed on {src}:\n" + r.stdout + r.stderr)
+                    with open(obj + ".sha", "w") as f:
+                        f.write(want + "\n")
                 return obj
 
             with ThreadPoolExecutor(max_workers=min(8, len(SOURCES), os.cpu_count() or 1)) as pool:
-                objs = list(pool.map(compile_one, SOURCES))
+                objs = list(pool.map(compile_one, SOURCES + [None]))
             tmp = f"{SO_PATH}.{os.getpid()}.tmp"
             cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", tmp]
             if verbose:
@@ -86,7 +109,7 @@ def build(force=False, verbose=False):
                 raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
             os.replace(tmp, SO_PATH)
             with open(SO_PATH + ".flags", "w") as f:
-                f.write(tag + "\n")
+                f.write(sha + "\n")
             return SO_PATH
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
@@ -113,6 +136,7 @@ _F = ctypes.c_float
 SIGNATURES = {
     "vd_last_error": (ctypes.c_char_p, []),
     "vd_version": (ctypes.c_char_p, []),
+    "vd_source_sha": (ctypes.c_char_p, []),
     "vd_create": (_I, [ctypes.POINTER(VdConfig), ctypes.POINTER(_P)]),
     "vd_destroy": (None, [_P]),
     "vd_param_count": (_I, [_P]),
@@ -162,15 +186,15 @@ SIGNATURES = {
     "vd_op_conv_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "vd_op_gn_affine": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "vd_pack_conv3_wino": (_I, [_P, _P, _I, _I]),
-    "vd_pack_conv3_frag": (_I, [_P, _P, _I, _I]),
     "vd_pack_linear_frag": (_I, [_P, _P, _I, _I]),
     "vd_pack_linear_split": (_I, [_P, _P, _I, _I]),
-    "vd_pack_conv3_wino_s64": (_I, [_P, _P, _I, _I]),
+    "vd_pack_conv3_wino_split": (_I, [_P, _P, _I, _I]),
+    "vd_set_model_mean_type": (_I, [_P, _I]),
+    "vd_math_mode": (_I, []),
+    "vd_split_image_u16": (_L, [_L, _L]),
     "vd_pack_conv3_wino_ups": (_I, [_P, _P, _I, _I]),
     "vd_conv_ups_stats_split": (_I, [_I]),
     "vd_op_conv_wino_ups": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
-    "vd_op_conv_wino_s64": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
-    "vd_op_conv_wino_r64": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "vd_op_conv_wino_split": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "vd_pack_conv3_split": (_I, [_P, _P, _I, _I]),
     "vd_op_conv_split": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
@@ -202,6 +226,9 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if not os.environ.get("VD_LIB") and L.vd_source_sha().decode() != source_sha():
+            raise RuntimeError(f"libvdamd.so was built from other sources ({L.vd_source_sha().decode()}) than the ones beside it "
+                               f"({source_sha()}): rebuild (video_diffusion_amd._lib.build(force=True))")
         _lib = L
     return _lib
 

@@ -1,22 +1,19 @@
-// 3x3 stride-1 convolution by Winograd F(2x2,3x3) at fp32 accuracy on the bf16 matrix cores -- the input transform and the
-// split run IN THE FRAGMENT LAYOUT, in registers (gfx950).
+// 3x3 stride-1 convolution by Winograd F(2x2,3x3) at fp32 accuracy on the 16-bit matrix cores -- the input transform and the
+// operand split run IN THE FRAGMENT LAYOUT, in registers (gfx950).
 //
-// Same arithmetic, work split and weight image as conv_wino_s64.hip: block = 4 waves (one per SIMD) = 64 tiles x 64 couts,
-// wave i owns Winograd row i (4 positions x 2 M-tiles x 2 cout tiles = 16 accumulator tiles), V = B^T d B in fp32 split
-// exactly into three bf16 pieces, six piece products per element.  The difference is where V lives.  conv_wino_s64.hip
-// transforms block-wide (thread = tile x channel quad), stores V to LDS and reads it back as MFMA fragments; that costs
-// 16 ds_write_b128 and 16 fragment reads per thread and chunk and two block barriers per chunk, and the LDS instructions
-// are what the matrix pipe waits for (tools/mfma_lds_coissue.hip: a second LDS store per MFMA slot costs 16-20 cycles).
-// Here lane (tile r, k-half h) of wave i reads the two patch rows its Winograd row combines -- 4 columns x 8 channels,
-// sixteen ds_read_b128 per M-tile and chunk, straight from the raw patch -- and forms t = d[X] + s*d[S], the four column
-// combinations and their split in its own registers: the result IS the A fragment.  Same vector-ALU work per MFMA (5.0 per
-// slot), no V image, no stores, no fragment reads, ONE barrier per TWO chunks (patch hand-over), and the LDS that held V
-// now holds four patches: a patch is requested three or four chunks ahead.
+// Block = 4 waves (one per SIMD, 512 registers each) = 64 tiles x 64 couts; wave i owns Winograd row i (4 positions x 2
+// M-tiles x 2 cout tiles = 16 accumulator tiles).  V = B^T d B is formed in fp32 and split into 16-bit pieces (vd_common.h:
+// two fp16 pieces and three piece products per element by default, F16; three bf16 pieces and six products with
+// VD_MATH=bf16x6); U = G g G^T is formed in fp64 on the host and split there (split_pack.hip).  Lane (tile r, k-half h) of
+// wave i reads the two patch rows its Winograd row combines -- 4 columns x 8 channels, sixteen ds_read_b128 per M-tile and
+// chunk, straight from the raw patch -- and forms t = d[X] + s*d[S], the four column combinations and their split in its own
+// registers: the result IS the A fragment.  No V image in LDS, ONE barrier per TWO chunks (patch hand-over), four patch
+// buffers: a patch is requested three or four chunks ahead.
 //
-// Patch image (LDS-DMA, as conv_wino_s64.hip): [row 18][x parity 2][slot 10][64 B = 16 channels of one pixel]; the four
-// 16-byte quads of a pixel are stored at quad ^ ((row >> 1) & 3), so that the 16 lanes of a ds_read_b128 group (four tile
-// rows x four tile columns) fall on 16 different bank quads.
-#include <cstdlib>
+// Patch image (LDS-DMA: buffer_load_dwordx4 ... lds, lane l of a request writes 16 bytes at M0 + 16 l whatever address it
+// gathers from, zeros where that address fails the descriptor's range check): [row 18][x parity 2][slot 10][64 B = 16
+// channels of one pixel]; the four 16-byte quads of a pixel are stored at quad ^ ((row >> 1) & 3), so that the 16 lanes of
+// a ds_read_b128 group (four tile rows x four tile columns) fall on 16 different bank quads.
 #include <cstdlib>
 #include <cstring>
 
@@ -26,6 +23,12 @@ namespace vd {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool F16>
+__device__ __forceinline__ f32x16 r64_mfma(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 struct WinoR64Geom { int tiles_x, tiles_y, nbx, ncb, nitems, xcd_order, ksplit; int phase_cb = 0; int cgroup = 0; };   // ksplit > 1: blockIdx.y = the block's slice of the channel chunks
 // phase_cb > 0 (= real Cout / 32): the sub-pixel form of Upsample + conv (see conv3x3_wino_r64_ups_kernel)
@@ -65,24 +68,9 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #else
 #define R64_STAMP(i)
 #endif
-#ifndef VD_R64_BAR2
-#define VD_R64_BAR2 1      // one block barrier per two chunks (0: per chunk; same-box A/B of the conv class 18.57 -> 18.41 ms)
-#endif
-#ifndef VD_R64_DMA_LATE
-#define VD_R64_DMA_LATE 1  // patches requested behind the chunk pair's last weight loads (0: at the barrier; conv class 18.02 -> 17.78 ms)
-#endif
-#ifndef VD_R64_ZERO_EARLY
-#define VD_R64_ZERO_EARLY 1 // accumulators zeroed between the prologue's requests and its wait (0: wherever the compiler puts them)
-#endif
-#ifndef VD_R64_DMA_SPREAD
-#define VD_R64_DMA_SPREAD 1 // the patch requests of a chunk pair one per slot (0: all in one slot; same-box A/B of the conv class 18.41 -> 18.07 ms)
-#endif
-#ifndef VD_R64_WSPREAD
-#define VD_R64_WSPREAD 1    // one weight load per slot (k = 0..5) instead of three in slots 0 and 3 (18.07 -> 17.97 ms)
-#endif
-#ifndef VD_R64_SKIP
-#define VD_R64_SKIP 0      // timing-only builds (results wrong): 1 no split, 2 no transform at all, 4 no weight loads, 16 no patch DMA,
-#endif                     // 64 no MFMA, 128 no patch reads
+#ifndef VD_R64_ABL
+#define VD_R64_ABL 0       // timing-only builds of the main loop (results WRONG; tools/build_variant.sh): bit 0 no weight reloads, 1 no
+#endif                     // transform / split, 2 no patch requests, 3 no patch reads, 4 no MFMA -- never set in the product library
 
 // block -> (tile group, first cout tile): blocks are dealt to the 8 XCDs round-robin; inside an XCD the cout blocks of one
 // patch are neighbours
@@ -113,14 +101,15 @@ __device__ __forceinline__ void r64_item(const WinoR64Geom& g, int& bx, int& cob
 // In the Winograd domain U = G g G^T of such a kernel has a zero ROW (3 for a = 0, 0 for a = 1) and a zero COLUMN JS (3 for
 // b = 0, 0 for b = 1): the column is the same for both cout tiles of a block and is not computed at all -- three positions
 // per group instead of four, three patch columns transformed instead of four; the zero row costs nothing to keep.  Same
-// products as F(2x2,3x3) on the upsampled map would form, a quarter of them skipped.  X3: VD_MATH=bf16x3 (vd_common.h).
-template <bool TF4, bool X3, int JS>
+// products as F(2x2,3x3) on the upsampled map would form, a quarter of them skipped.
+template <bool TF4, bool F16, int JS>
 __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& g) {
     using namespace r64;
     constexpr int NP = JS < 0 ? 4 : 3;                               // positions of a group
     constexpr int JLa[4] = {JS == 0 ? 1 : 0, JS == 0 ? 2 : 1, JS == 0 ? 3 : 2, 3};     // position li of a group -> column j of the row
     constexpr int ORDa[4] = {JS == 0 ? 2 : 0, JS == 0 ? 1 : 2, JS == 0 ? 3 : 1, 3};    // the patch column position li recomputes for the next group
     constexpr bool PH = JS >= 0;
+    constexpr int NSLOT = F16 ? 6 : 12;                              // MFMAs of a position: piece products x 2 cout tiles
     using G = R64G<TF4>;
     constexpr int P = G::P, SPP = G::SPP, PLB = G::PLB, RSB = G::RSB, NX = G::NX, XBUF = G::XBUF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -162,27 +151,19 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     typedef __attribute__((address_space(3))) void* lds_ptr;
     // A request past the item's last chunk must not land in the output transform's Z image.  It is NOT skipped by a branch:
     // hipcc's s_waitcnt insertion merges the two paths of a conditional request to the one with FEWER loads in flight, i.e.
-    // every wait for a weight fragment behind it becomes a wait for the patch itself (the loop ran `vmcnt(0)` three
-    // positions behind each request pair: the HBM round trip of the patch, every second chunk).  The request always issues;
-    // when it is late it goes through a descriptor of zero records (no memory access, zeros) into the spare fifth buffer.
+    // every wait for a weight fragment behind it becomes a wait for the patch itself.  The request always issues; when it is
+    // late it goes through a descriptor of zero records (no memory access, zeros) into the spare fifth buffer.
     const auto xnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, 0, 0x00020000);
     auto x_dma_one = [&](int chunk, int e) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (VD_R64_SKIP & 16) return;
+#if defined(__HIP_DEVICE_COMPILE__)      // (hipcc's host pass drops a kernel whose body names this builtin)
         const bool live = chunk < nchunk;
         const int bufi = live ? (chunk & (NB - 1)) : NB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? xsrc : xnull, (lds_ptr)(lds + bufi * XBUF + e * 4096 + wi * 1024), 16, xo[e], chunk * 64, 0, 0);
 #endif
     };
     auto x_dma = [&](int chunk) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (VD_R64_SKIP & 16) return;
-        const bool live = chunk < nchunk;
-        const int bufi = live ? (chunk & (NB - 1)) : NB;
 #pragma unroll
-        for (int e = 0; e < NX; ++e)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? xsrc : xnull, (lds_ptr)(lds + bufi * XBUF + e * 4096 + wi * 1024), 16, xo[e], chunk * 64, 0, 0);
-#endif
+        for (int e = 0; e < NX; ++e) x_dma_one(chunk, e);
     };
 
     // ---- transform in the fragment layout.  Lane (tile lr of the M-tile, k-half lh): tile column lr & 7, tile row 4m + (lr >> 3);
@@ -199,11 +180,10 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     }
     float t[4][8];                                                    // t[column][channel] of the group being transformed
     f32x4 stx[2], sts[2];                                             // one column of the patch rows X and S, in flight
-    float tv[8], rr[8];
-    bf16x8 af[2][3];
+    float tv[2][8], rr[8];                                            // V of a position (F16: per fragment buffer, its remainder is formed one position later)
+    u32x4 af[2][3];                                                   // A fragments [buffer][piece]
     // column c of group (chunk, m): four reads
     auto t_read = [&](int chunk, int m, int c) {
-        if (VD_R64_SKIP & (2 | 128)) return;
         const char* rb = lds + (chunk & (NB - 1)) * XBUF + m * G::MOFF + (c & 1) * PLB + (c >> 1) * 64;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -211,80 +191,78 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
             sts[h] = *reinterpret_cast<const f32x4*>(rb + adr[1][h]);
         }
     };
+    auto t_fma1 = [&](int c, int e) {          // plain v_fma_f32: hipcc pairs these into v_pk_fma_f32, which does not co-issue with the MFMA
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t[c][e]) : "v"(tsg), "v"(sts[e >> 2][e & 3]), "v"(stx[e >> 2][e & 3]));
+    };
     auto t_fma = [&](int c, int h) {
-        if (VD_R64_SKIP & 2) return;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)      // plain v_fma_f32: hipcc pairs these into v_pk_fma_f32, which does not co-issue with the bf16 MFMA
-            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t[c][4 * h + e]) : "v"(tsg), "v"(sts[h][e]), "v"(stx[h][e]));
+        for (int e = 4 * h; e < 4 * h + 4; ++e) t_fma1(c, e);
     };
-    auto t_comb = [&](int j, int h) {                                // column combination of position j, channels 4h .. 4h+3
-        if (VD_R64_SKIP & 2) return;
+    auto t_comb1 = [&](int buf, int j, int e) {                      // column combination of position j, channel e
+        // (asm: hipcc otherwise pairs neighbouring channels into v_pk_add_f32)
+        if (j == 0) asm("v_sub_f32 %0, %1, %2" : "=v"(tv[buf][e]) : "v"(t[0][e]), "v"(t[2][e]));
+        else if (j == 1) asm("v_add_f32 %0, %1, %2" : "=v"(tv[buf][e]) : "v"(t[1][e]), "v"(t[2][e]));
+        else if (j == 2) asm("v_sub_f32 %0, %1, %2" : "=v"(tv[buf][e]) : "v"(t[2][e]), "v"(t[1][e]));
+        else asm("v_sub_f32 %0, %1, %2" : "=v"(tv[buf][e]) : "v"(t[1][e]), "v"(t[3][e]));
+    };
+    auto t_comb = [&](int buf, int j, int h) {
 #pragma unroll
-        for (int e = 4 * h; e < 4 * h + 4; ++e)
-            tv[e] = j == 0 ? t[0][e] - t[2][e] : j == 1 ? t[1][e] + t[2][e] : j == 2 ? t[2][e] - t[1][e] : t[1][e] - t[3][e];
+        for (int e = 4 * h; e < 4 * h + 4; ++e) t_comb1(buf, j, e);
     };
-    auto piece = [&](bf16x8& f, int k, unsigned v) { u32x4 w = __builtin_bit_cast(u32x4, f); w[k] = v; f = __builtin_bit_cast(bf16x8, w); };
-    auto t_split_a = [&](int buf, int pr) {                           // channels 2pr, 2pr+1
-        if (VD_R64_SKIP & 2) return;
-        if (VD_R64_SKIP & 1) { piece(af[buf][0], pr, __builtin_bit_cast(unsigned, tv[2 * pr] + tv[2 * pr + 1])); return; }
+    // bf16x6: exact three-way split of channels 2pr, 2pr+1 (vd_common.h: split_a / split_b)
+    auto t_split_a = [&](int buf, int pr) {
         unsigned p1;
-        split_a(tv[2 * pr], tv[2 * pr + 1], p1, rr[2 * pr], rr[2 * pr + 1], 0x07060302u);
-        piece(af[buf][0], pr, p1);
+        split_a(tv[buf][2 * pr], tv[buf][2 * pr + 1], p1, rr[2 * pr], rr[2 * pr + 1], 0x07060302u);
+        af[buf][0][pr] = p1;
     };
     auto t_split_b = [&](int buf, int pr) {
-        if (VD_R64_SKIP & 2) return;
-        if constexpr (X3) {                                           // second piece only: the top halves of the remainders
-            unsigned p2;
-            asm("v_perm_b32 %0, %2, %1, %3" : "=v"(p2) : "v"(rr[2 * pr]), "v"(rr[2 * pr + 1]), "s"(0x07060302u));
-            piece(af[buf][1], pr, p2);
-            return;
-        }
-        if (VD_R64_SKIP & 1) { piece(af[buf][1], pr, __builtin_bit_cast(unsigned, tv[2 * pr])); piece(af[buf][2], pr, __builtin_bit_cast(unsigned, tv[2 * pr + 1])); return; }
         unsigned p2, p3;
         split_b(rr[2 * pr], rr[2 * pr + 1], p2, p3, 0x07060302u);
-        piece(af[buf][1], pr, p2);
-        piece(af[buf][2], pr, p3);
+        af[buf][1][pr] = p2;
+        af[buf][2][pr] = p3;
+    };
+    // f16x3: a0 of channels 2pr, 2pr+1 | a1 = f16((x - a0) * 4096) of the same pair (vd_common.h)
+    auto t_f16_a0 = [&](int buf, int pr) { af[buf][0][pr] = f16_pack(tv[buf][2 * pr], tv[buf][2 * pr + 1]); };
+    // (pad: the LAST pair is written one slot ahead of the MFMA that reads the piece; a VALU write needs two wait states before an
+    // MFMA reads it as A / B, and hipcc pads nothing behind inline asm)
+    auto t_f16_a1 = [&](int buf, int pr, bool pad) {
+        const float r0 = f16_rem_lo(af[buf][0][pr], tv[buf][2 * pr]), r1 = f16_rem_hi(af[buf][0][pr], tv[buf][2 * pr + 1]);
+        af[buf][1][pr] = pad ? f16_pack_scaled_pad(r0, r1, 4096.f) : f16_pack_scaled(r0, r1, 4096.f);
     };
 
-    // ---- B fragments: U[chunk][xi = 4*wi + j][cob][piece][lane][8 bf16] = 1 KiB per (chunk, xi, cob, piece)
+    // ---- B fragments: U[chunk][xi = 4*wi + j][cob][piece][lane][8 x 16 bit] = 1 KiB per (chunk, xi, cob, piece)
     const auto usrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wwino), 0, 16 * a.Cout * a.Cin * 6, 0x00020000);
     const int ustride = 16 * ncoblk * 3072, bstep = ncoblk * 3072;
     const int bsb = (wi * 4 * ncoblk + cob0) * 3072 + c_begin * ustride;
     const unsigned blane = lane * 16u;
-    bf16x8 bfr[4][2][3];
-    auto b_load = [&](int chunk, int j, int n) {
-        if (VD_R64_SKIP & 4) return;
-        const int so = chunk * ustride + bsb + j * bstep + n * 3072;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            bfr[j][n][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, so + p * 1024, 0));
-    };
-
+    u32x4 bfr[4][2][3];
     auto b_load_one = [&](int chunk, int j, int n, int p) {
-        if ((VD_R64_SKIP & 4) || (X3 && p == 2)) return;             // bf16x3 never reads the third weight piece
-        bfr[j][n][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, chunk * ustride + bsb + j * bstep + n * 3072 + p * 1024, 0));
+        bfr[j][n][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, chunk * ustride + bsb + j * bstep + n * 3072 + p * 1024, 0));
+    };
+    auto b_load = [&](int chunk, int j, int n) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b_load_one(chunk, j, n, p);
     };
 
     f32x16 acc[2][4][2];                                              // [m][j][n]; zeroed behind the prologue's requests
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[b][p] = bf16x8{};
+        for (int p = 0; p < 3; ++p) af[b][p] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bfr[j][n][p] = bf16x8{};
+            for (int p = 0; p < 3; ++p) bfr[j][n][p] = u32x4{0u, 0u, 0u, 0u};
 
     R64_STAMP(0); R64_STAMP(4);
-    // ---- prologue: four patches and the weights of chunk 0 requested; group (0, 0) transformed whole, position 0 split,
+    // ---- prologue: three patches and the weights of chunk 0 requested; group (0, 0) transformed whole, position 0 split,
     // column 0 of group (0, 1) in flight -- the state the loop expects at the top of a group
 #pragma unroll
-    for (int c = 0; c < (VD_R64_BAR2 ? 3 : NB); ++c) x_dma(c);
+    for (int c = 0; c < 3; ++c) x_dma(c);
 #pragma unroll
     for (int li = 0; li < NP - 1; ++li) { b_load(0, JLa[li], 0); b_load(0, JLa[li], 1); }
-#if VD_R64_ZERO_EARLY
     // the 256 accumulator writes (1 k cycles of issue) go under the wait for the first patch instead of behind it
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -297,38 +275,46 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                 for (int r = 0; r < 16; ++r)
                     if (j != JS) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[m][j][n][r]));
     __builtin_amdgcn_sched_barrier(0);
-#else
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][j][n][r] = 0.f;
-#endif
     // every patch requested so far has landed; the (NP - 1) * 6 weight loads may be in flight
     if constexpr (NP == 4) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (JS < 0 || (JS == 3 ? c < 3 : c > 0)) { t_read(0, 0, c); t_fma(c, 0); t_fma(c, 1); }
-    t_comb(JLa[0], 0); t_comb(JLa[0], 1);
+    t_comb(0, JLa[0], 0); t_comb(0, JLa[0], 1);
+    if constexpr (F16) {
 #pragma unroll
-    for (int pr = 0; pr < 4; ++pr) t_split_a(0, pr);
+        for (int pr = 0; pr < 4; ++pr) t_f16_a0(0, pr);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1");                 // the first MFMA reads af[0][0]
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
-    for (int pr = 0; pr < 4; ++pr) t_split_b(0, pr);
+        for (int pr = 0; pr < 4; ++pr) t_split_a(0, pr);
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) t_split_b(0, pr);
+    }
     t_read(0, 1, ORDa[0]);
 
     R64_STAMP(1);
-    // ---- main loop.  Group (chunk, m) = 4 positions x 12 slots; slot k of position j = MFMA (product q = k >> 1, cout tile
-    // n = k & 1) + at most 6 vector instructions of the NEXT position's fragment (k 0, 3: column combination; 1, 2, 4, 5:
-    // first split step of a channel pair; 6..9: second) or, k 10 and 11, of the next group's t (column ord[j], in place: its
-    // last reader ran earlier in this group) + the reads of the column after it.  Products in the order (A2,B0) (A1,B1)
-    // (A1,B0) (A0,B2) (A0,B1) (A0,B0).  Weights: one register set, fragment (j, n) reloaded in the position after its last use.
+    // ---- main loop.  Group (chunk, m) = NP positions x NSLOT slots; a slot = one MFMA + a share of the vector work + at most
+    // one memory request (requests in bursts block the wave's issue and starve the matrix pipe: one per slot, never more).
+    //   bf16x6 (12 slots): slot k = product k >> 1 of (A2,B0) (A1,B1) (A1,B0) (A0,B2) (A0,B1) (A0,B0), cout tile k & 1, + <= 6
+    //     vector instructions of the NEXT position's fragment (k 0, 3: column combination; 1, 2, 4, 5: first split step of a
+    //     channel pair; 6..9: second), k 10, 11: the next group's t (column ord[j], in place: its last reader ran earlier in
+    //     this group) + the reads of the column after it.
+    //   f16x3 (6 slots): slot k = product k >> 1 of (A0,B0) (A0,B1) (A1,B2), cout tile k & 1; the fragment's a0 piece is
+    //     complete when its position starts, its a1 piece is formed in slots 0..3 (one channel pair each: 4 instructions) and
+    //     first read in slot 4; beside it slots 0..3 form the NEXT position's V (2 channels each), slot 4 packs its a0 and
+    //     starts the next group's t column, slot 5 finishes it and issues the reads of the column after it: 6 per slot.
+    // Weights: one register set, fragment (j, n, piece) reloaded in the position after its last use, one load per slot.
     // Patch of chunk c: first read in position 3 of group (c - 1, 0), last read in position 2 of group (c, 0); the block's only
-    // barrier sits in front of position 3 of the even groups (c, 0): it hands over patches c + 1, c + 2 and frees two buffers.
-    constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
+    // barrier sits in front of position NP - 1 of the EVEN groups (c, 0): patches c + 1, c + 2 (requested two chunks ago) have
+    // landed in every wave, and the buffers of c - 1, c are free for c + 3, c + 4.  Those are requested in the odd chunk,
+    // BEHIND its last weight loads (position 0 of group (c, 0)): loads return in order, and a weight fragment requested
+    // behind a patch would wait for the patch's HBM round trip.
+    constexpr int PA6[6] = {2, 1, 1, 0, 0, 0}, PB6[6] = {0, 1, 0, 2, 1, 0};
+    constexpr int PA3[3] = {0, 0, 1}, PB3[3] = {0, 1, 2};
     // two chunks per trip: the chunk's parity (which decides the barrier and the patch requests) is a compile-time constant,
     // so the wait counts hipcc derives for the weight fragments are exact on every path
     for (int chunk0 = 0; chunk0 < nchunk; chunk0 += 2) {
@@ -340,70 +326,57 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
 #pragma unroll
             for (int li = 0; li < NP; ++li) {
                 const int j = JLa[li];
-                const int cur = ((cpar * 2 + m) * NP + li) & 1, nxt = cur ^ 1;      // NP = 4: j & 1; the A fragment buffers alternate per position
+                const int cur = ((cpar * 2 + m) * NP + li) & 1, nxt = cur ^ 1;      // the A fragment buffers alternate per position
+                const int jn = JLa[(li + 1) % NP];                                  // the next position: li + 1 of this group, or 0 of the next one
 #pragma unroll
-                for (int k = 0; k < 12; ++k) {
+                for (int k = 0; k < NSLOT; ++k) {
                     const int q = k >> 1, n = k & 1;
-                    if (m == 0 && li == NP - 1 && k == 0) {
-                        // patch chunk + 1 has landed in every wave; nobody reads patch chunk any more (loads return in order:
-                        // the 18 youngest are weight loads)
-#if VD_R64_BAR2
-                        // one barrier per TWO chunks (the channel chunks come in pairs: Cin % 32 == 0): at an even chunk the
-                        // patches chunk + 1 and chunk + 2 (requested two chunks ago) have landed in every wave, and the buffers
-                        // of chunk - 1 and chunk are free for chunk + 3 and chunk + 4 (requested five positions on, see below)
-                        if (cpar == 0) {
-                            asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#if !VD_R64_DMA_LATE
-                            x_dma(chunk + 3);
-                            x_dma(chunk + 4);
-#endif
+                    if (m == 0 && li == NP - 1 && k == 0 && cpar == 0)
+                        asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the 18 youngest requests are weight loads
+                    // the patch requests of the chunk pair, one per slot
+                    if (cpar == 1 && !(VD_R64_ABL & 4)) {
+                        if constexpr (F16) {
+                            const int ord = m == 0 ? (li - 1) * 6 + k : (li == 0 ? (NP - 1) * 6 + k : 99);      // slots behind position 0 of group (c, 0)
+                            if ((m == 1 || li > 0) && ord < 2 * NX) x_dma_one(chunk + 2 + ord / NX, ord % NX);
+                        } else {
+                            if (m == 0 && (li == 0 || li == 1) && k >= 12 - NX) x_dma_one(chunk + 2 + li, k - (12 - NX));   // the last NX slots of positions 0, 1
                         }
-#else
-                        asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                        x_dma(chunk + NB);                                    // past the last chunk: zeros / stale, never used
-#endif
                     }
-#if VD_R64_DMA_LATE
-                    // the two patches are requested BEHIND this chunk pair's last weight loads: loads return in order, and a
-                    // weight fragment requested behind a patch waits for it
-#if VD_R64_DMA_SPREAD == 1
-                    // one request instruction per slot (an LDS-DMA request blocks the wave's issue for ~63 cycles: twelve in one
-                    // slot starve the matrix pipe for the length of eleven MFMAs)
-                    if (m == 0 && cpar == 1 && (li == 0 || li == 1) && k >= 12 - NX) x_dma_one(chunk + 2 + li, k - (12 - NX));   // the last NX slots of positions 0, 1
-#else
-                    if (m == 0 && li == 0 && k == 4 && cpar == 1) { x_dma(chunk + 2); x_dma(chunk + 3); }
-#endif
-#endif
-                    if (!(VD_R64_SKIP & 64) && !(X3 && (q == 0 || q == 1 || q == 3)))      // bf16x3: (A1,B0) (A0,B1) (A0,B0) only
-                        acc[m][j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][PA[q]], bfr[j][n][PB[q]], acc[m][j][n], 0, 0, 0);
-                    // the next position's fragment: position j + 1 of this group, or position 0 of the next one
-                    const int jn = JLa[(li + 1) % NP];
-                    if (k == 0) t_comb(jn, 0);
-                    else if (k == 3) t_comb(jn, 1);
-                    else if (k == 1 || k == 2) t_split_a(nxt, k - 1);
-                    else if (k == 4 || k == 5) t_split_a(nxt, k - 2);
-                    else if (k >= 6 && k < 10) t_split_b(nxt, k - 6);
-                    else {
-                        // the group after this one: (chunk, 1) or (chunk + 1, 0); the one after that for the last reads
-                        t_fma(ORDa[li], k - 10);
-                        if (k == 11) {
-                            if (li < NP - 1) t_read(m == 0 ? chunk : chunk + 1, m ^ 1, ORDa[li + 1]);
-                            else t_read(chunk + 1, m, ORDa[0]);
+                    if (VD_R64_ABL & 16) {}
+                    else if constexpr (F16) acc[m][j][n] = r64_mfma<true>(af[cur][PA3[q]], bfr[j][n][PB3[q]], acc[m][j][n]);
+                    else acc[m][j][n] = r64_mfma<false>(af[cur][PA6[q]], bfr[j][n][PB6[q]], acc[m][j][n]);
+                    if (VD_R64_ABL & 2) {}
+                    else if constexpr (F16) {
+                        if (k < 4) {
+                            t_f16_a1(cur, k, k == 3);
+                            t_comb1(nxt, jn, 2 * k); t_comb1(nxt, jn, 2 * k + 1);
+                        } else if (k == 4) {
+#pragma unroll
+                            for (int pr = 0; pr < 4; ++pr) t_f16_a0(nxt, pr);
+                            t_fma1(ORDa[li], 0); t_fma1(ORDa[li], 1);
+                        } else {
+#pragma unroll
+                            for (int e = 2; e < 8; ++e) t_fma1(ORDa[li], e);
                         }
+                    } else {
+                        if (k == 0) t_comb(nxt, jn, 0);
+                        else if (k == 3) t_comb(nxt, jn, 1);
+                        else if (k == 1 || k == 2) t_split_a(nxt, k - 1);
+                        else if (k == 4 || k == 5) t_split_a(nxt, k - 2);
+                        else if (k >= 6 && k < 10) t_split_b(nxt, k - 6);
+                        else t_fma(ORDa[li], k - 10);
+                    }
+                    if (k == NSLOT - 1 && !(VD_R64_ABL & 8)) {
+                        // the reads of the column after the one just transformed: of the group after this one -- (chunk, 1) or
+                        // (chunk + 1, 0) -- or, from the last position, of the one after that
+                        if (li < NP - 1) t_read(m == 0 ? chunk : chunk + 1, m ^ 1, ORDa[li + 1]);
+                        else t_read(chunk + 1, m, ORDa[0]);
                     }
                     // weights: (j - 1, n) of the next chunk once its last product has issued; (3, n) in position 0 of the next group
-#if VD_R64_WSPREAD
-                    if (k < 6) {                                      // one weight load per slot: (n, piece) = (k / 3, k % 3)
+                    if (k < 6 && !(VD_R64_ABL & 1)) {                 // one weight load per slot: (n, piece) = (k / 3, k % 3)
                         if (m == 1 && li > 0) b_load_one(chunk + 1, JLa[li - 1], k / 3, k % 3);
                         if (m == 0 && li == 0) b_load_one(chunk, JLa[NP - 1], k / 3, k % 3);
                     }
-#else
-                    if (k == 0 || k == 3) {
-                        const int nn = k == 0 ? 0 : 1;
-                        if (m == 1 && li > 0) b_load(chunk + 1, JLa[li - 1], nn);
-                        if (m == 0 && li == 0) b_load(chunk, JLa[NP - 1], nn);
-                    }
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -442,6 +415,8 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
         const int co = PH ? pcb * 32 + lr : (cob0 + n) * 32 + lr;
         const int nso = PH ? n * Wo * a.ldo * 4 : n * 128;             // byte offset of cout tile n: one output row down | 32 channels on
         const float bias = a.bias ? a.bias[co] : 0.f;
+        // F16: the weight row's power-of-two scale leaves here (image trailer: [Cout] s, [Cout] 1 / s; Cout = the image's 4 x real in the sub-pixel form)
+        const float winv = F16 ? (a.wwino + (size_t)24 * a.Cout * a.Cin)[a.Cout + (cob0 + n) * 32 + lr] : 1.f;
         // per-frame bias: TF1 one frame; TF4 registers 0..7 of M-tile m belong to frame 2m, 8..15 to frame 2m + 1
         float bvf[2][2];
 #pragma unroll
@@ -477,7 +452,8 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                                 (*reinterpret_cast<const f32x4*>(zp + 2 * 2048) + *reinterpret_cast<const f32x4*>(zp + 4 * 2048)) * sgn;
                 y[4 * c4] = v.x; y[4 * c4 + 1] = v.y; y[4 * c4 + 2] = v.z; y[4 * c4 + 3] = v.w;
             }
-            y += rv[m];
+            if constexpr (F16) y = y * winv + rv[m];
+            else y += rv[m];
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[r] += bvf[m][r >> 3];
 #pragma unroll
@@ -518,23 +494,34 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     R64_STAMP(3); R64_STAMP(5);
 }
 
-template <bool TF4, bool X3 = false>
-__global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, WinoR64Geom g) { r64_body<TF4, X3, -1>(a, g); }
+template <bool TF4, bool F16>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_kernel(IgemmArgs a, WinoR64Geom g) { r64_body<TF4, F16, -1>(a, g); }
 
-template <bool TF4, bool X3 = false>
+template <bool TF4, bool F16>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_ups_kernel(IgemmArgs a, WinoR64Geom g) {
     int bx, cob0;
     r64_item(g, bx, cob0);
-    if ((cob0 >> 1) < g.phase_cb) r64_body<TF4, X3, 3>(a, g);        // phases (., 0): column 3 of U is zero
-    else r64_body<TF4, X3, 0>(a, g);                                 // phases (., 1): column 0
+    if ((cob0 >> 1) < g.phase_cb) r64_body<TF4, F16, 3>(a, g);       // phases (., 0): column 3 of U is zero
+    else r64_body<TF4, F16, 0>(a, g);                                // phases (., 1): column 0
+}
+
+template <auto KERN>
+static int r64_launch(dim3 grid, size_t lds, hipStream_t s, const IgemmArgs& k, const WinoR64Geom& g) {
+    static bool attr = false;                    // per kernel: each one that runs raises its own LDS limit once
+    if (!attr) {
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(KERN, grid, dim3(256), lds, s, k, g);
+    VD_HIP(hipGetLastError());
+    return 0;
 }
 
 static bool r64_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 bool conv_wino_r64_supported(const IgemmArgs& a) {
-    static const bool on = [] { const char* e = getenv("VD_CONV_R64"); return !(e && e[0] == '0'); }();   // A/B switch: 0 = conv_wino_s64.hip everywhere
     const int Hl = a.Hs << a.ups, Wl = a.Ws << a.ups;
-    return on && a.wsplit == 2 && a.wwino != nullptr && a.ksz == 3 && a.stride == 1 && a.pad == 1 && Hl == Wl && r64_pow2(Hl) && Hl >= 8 &&
+    return a.wsplit == 2 && a.wwino != nullptr && a.ksz == 3 && a.stride == 1 && a.pad == 1 && Hl == Wl && r64_pow2(Hl) && Hl >= 8 &&
            a.Cout % 64 == 0 && a.Cin % 32 == 0 && a.src1 == nullptr && a.C0 == a.Cin && a.affA == nullptr && a.act == 0 &&
            (size_t)a.nfr * a.Hs * a.Ws * a.Cin < (1u << 29) && (size_t)a.Cin * a.Cout * 96 < (1u << 31) &&
            (size_t)a.nfr * Hl * Wl * a.ldo < (1u << 29) && (a.res == nullptr || a.res_ld == a.ldo);
@@ -580,8 +567,7 @@ __global__ __launch_bounds__(256) void wino_r64_reduce_kernel(const float* __res
 // or the map is larger than 16 x 16; else the largest count that keeps >= 4 chunks (an even number) per block and the
 // grid within 288 blocks.  The engine sizes the scratch from this (conv_wino_r64_ksplit_floats) in its dry run too.
 int conv_wino_r64_ksplit(int nfr, int Hl, int Cin, int Cout) {
-    static const bool off = getenv("VD_R64_NO_KSPLIT") != nullptr;             // A/B switch
-    if (off || Hl > 16 || Hl < 8 || Cout % 64 || Cin % 32) return 1;
+    if (Hl > 16 || Hl < 8 || Cout % 64 || Cin % 32) return 1;
     const int items = (Hl == 8 ? (nfr + 3) / 4 : (Hl / 16) * (Hl / 16) * nfr) * (Cout / 64), nchunk = Cin / 16;
     if (items >= 160) return 1;
     int best = 1;
@@ -616,22 +602,12 @@ static int launch_conv_wino_r64_ups(const IgemmArgs& a, hipStream_t s) {
     g.cgroup = g.ncb % 4 == 0 ? 4 : 2;                                // groups of 1 / 2 / 4 / 8 measured: 1 loses the patch reuse (1347 us at 256 couts), 2 .. 8 within noise
     IgemmArgs k = a;
     k.ups = 0; k.Cout = 4 * a.Cout;                                  // the kernel's view: a stride-1 conv of the source map with 4 x Cout outputs
-    static bool attr = false;
-    if (!attr) {
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_ups_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_ups_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_ups_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_ups_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
     const dim3 grid(g.nitems, 1);
-    if (x3_math()) {
-        if (tf4) hipLaunchKernelGGL((conv3x3_wino_r64_ups_kernel<true, true>), grid, dim3(256), r64::lds_bytes<true>(), s, k, g);
-        else hipLaunchKernelGGL((conv3x3_wino_r64_ups_kernel<false, true>), grid, dim3(256), r64::lds_bytes<false>(), s, k, g);
-    } else if (tf4) hipLaunchKernelGGL(conv3x3_wino_r64_ups_kernel<true>, grid, dim3(256), r64::lds_bytes<true>(), s, k, g);
-    else hipLaunchKernelGGL(conv3x3_wino_r64_ups_kernel<false>, grid, dim3(256), r64::lds_bytes<false>(), s, k, g);
-    VD_HIP(hipGetLastError());
-    return 0;
+    const bool f16 = f16_math();
+    if (tf4) return f16 ? r64_launch<&conv3x3_wino_r64_ups_kernel<true, true>>(grid, r64::lds_bytes<true>(), s, k, g)
+                        : r64_launch<&conv3x3_wino_r64_ups_kernel<true, false>>(grid, r64::lds_bytes<true>(), s, k, g);
+    return f16 ? r64_launch<&conv3x3_wino_r64_ups_kernel<false, true>>(grid, r64::lds_bytes<false>(), s, k, g)
+               : r64_launch<&conv3x3_wino_r64_ups_kernel<false, false>>(grid, r64::lds_bytes<false>(), s, k, g);
 }
 
 int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
@@ -649,29 +625,18 @@ int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
     // split-K only with scratch from the caller (the engine's arena; the single-operator entry points run one slice)
     g.ksplit = a.ksplit_ws && a.ksplit_ws_floats >= conv_wino_r64_ksplit_floats(a.nfr, Hl, a.Cin, a.Cout)
                    ? conv_wino_r64_ksplit(a.nfr, Hl, a.Cin, a.Cout) : 1;
-    static bool attr = false;
-    if (!attr) {
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
     IgemmArgs k = a;
     if (g.ksplit > 1) {
         k.out = a.ksplit_ws; k.ldo = a.Cout; k.bias = nullptr; k.fbias = nullptr; k.res = nullptr; k.stats = nullptr;
     }
     const dim3 grid(g.nitems, g.ksplit);
-    if (x3_math()) {
-        static bool attr3 = false;
-        if (!attr3) {
-            VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_r64_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr3 = true;
-        }
-        if (tf4) hipLaunchKernelGGL((conv3x3_wino_r64_kernel<true, true>), grid, dim3(256), r64::lds_bytes<true>(), s, k, g);
-        else hipLaunchKernelGGL((conv3x3_wino_r64_kernel<false, true>), grid, dim3(256), r64::lds_bytes<false>(), s, k, g);
-    } else if (tf4) hipLaunchKernelGGL(conv3x3_wino_r64_kernel<true>, grid, dim3(256), r64::lds_bytes<true>(), s, k, g);
-    else hipLaunchKernelGGL(conv3x3_wino_r64_kernel<false>, grid, dim3(256), r64::lds_bytes<false>(), s, k, g);
-    VD_HIP(hipGetLastError());
+    const bool f16 = f16_math();
+    int rc;
+    if (tf4) rc = f16 ? r64_launch<&conv3x3_wino_r64_kernel<true, true>>(grid, r64::lds_bytes<true>(), s, k, g)
+                      : r64_launch<&conv3x3_wino_r64_kernel<true, false>>(grid, r64::lds_bytes<true>(), s, k, g);
+    else rc = f16 ? r64_launch<&conv3x3_wino_r64_kernel<false, true>>(grid, r64::lds_bytes<false>(), s, k, g)
+                  : r64_launch<&conv3x3_wino_r64_kernel<false, false>>(grid, r64::lds_bytes<false>(), s, k, g);
+    if (rc) return rc;
     if (g.ksplit > 1) {
         const int HW = Hl * Hl;
         hipLaunchKernelGGL(wino_r64_reduce_kernel, dim3(a.nfr, a.Cout / 16), dim3(256), 0, s, a.ksplit_ws, g.ksplit,

@@ -23,9 +23,10 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 
 int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hipStream_t s);
 
-// CONV3F / LINF: MFMA-fragment-major images (conv_halo.hip / gemm_frag.hip)
-// CONV3W: Winograd F(2x2,3x3)-transformed weights, 16/9 of the checkpoint size (conv_wino.hip)
-enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_CONV3F, PK_LINF, PK_CONV3W, PK_CONV3S,
+// PK_CONV3: [tap][Cout][Cin] for the generic kernel (igemm.hip).  PK_LINF / PK_STEM: every nn.Linear, 1x1 conv and the stem as a
+// matrix image -- the split image of gemm_split.hip (split_pack.hip; VD_MATH=fp32: the fragment-major fp32 image of gemm_frag.hip).
+// PK_CONV3W: Winograd F(2x2,3x3) image (conv_wino_r64.hip; fp32: conv_wino.hip).  PK_CONV3S: stride-2 conv on the split GEMM.
+enum ParamKind { PK_RAW = 0, PK_CONV3, PK_STEM, PK_POSENC, PK_OUTCONV, PK_LINF, PK_CONV3W, PK_CONV3S,
                  PK_CONV3WU };      // PK_CONV3WU: Upsample + conv3x3 in its sub-pixel form (conv_wino_r64.hip): image of 4 x Cout phase kernels
 
 struct Param {
@@ -78,19 +79,10 @@ static const int CH_MULT_256[] = {1, 1, 2, 2, 4, 4};
 static const int CH_MULT_128[] = {1, 1, 2, 3, 4};
 static const int CH_MULT_64[] = {1, 2, 3, 4};
 static const int CH_MULT_32[] = {1, 2, 2, 2};
-// VD_MATH=fp32 keeps every matrix product on the fp32 MFMA; default: linear layers / 1x1 convs / the stem run as six
-// bf16 piece products of exactly split fp32 operands with fp32 accumulation (gemm_split.hip, same accuracy, 2.67x rate)
-static bool split_math() {
-    static const bool v = [] { const char* e = getenv("VD_MATH"); return !(e && std::string(e) == "fp32"); }();
-    return v;
-}
-
-// The 3x3 Winograd convs run the same arithmetic (conv_wino_s64.hip: 64 couts per block, block-wide input transform);
-// VD_CONV_SPLIT=0 keeps them on the fp32-MFMA kernel (conv_wino.hip) while the linear layers stay split.
-static bool split_conv() {
-    static const bool v = [] { const char* e = getenv("VD_CONV_SPLIT"); return !(e && std::string(e) == "0") && split_math(); }();
-    return v;
-}
+// VD_MATH (vd_common.h): f16x3 (default) and bf16x6 run every matrix product on the split kernels (gemm_split.hip,
+// conv_wino_r64.hip) over 16-bit piece images; fp32 keeps them on the fp32 MFMA (gemm_frag.hip, conv_wino.hip).
+static bool split_math() { return math_mode() != MATH_FP32; }
+static bool split_conv() { return split_math(); }
 
 constexpr int STEM_KPAD = 64;          // im2col width of the 5-channel 3x3 stem (45 real columns)
 
@@ -116,16 +108,16 @@ enum ProfClass { PC_IGEMM_128x128 = 0, PC_IGEMM_128x64, PC_IGEMM_64x128, PC_IGEM
                  PC_ATTN_SPATIAL, PC_ATTN_TEMPORAL, PC_OUT_CONV, PC_ELEMENTWISE, PC_POSTERIOR,
                  PC_CONV_128x128, PC_CONV_128x64, PC_CONV_64x128, PC_CONV_64x64, PC_CONV_WINO, PC_CONV_WINO_R64, PC_IGEMM_128x192,
                  PC_CONV_WINO_R64_UPS, PC_COUNT };
-// names of the kernels a class runs on: [0] default arithmetic (bf16x6 split), [1] VD_MATH=fp32 / VD_CONV_SPLIT=0
+// names of the kernels a class runs on: [0] split arithmetic (f16x3 | bf16x6), [1] VD_MATH=fp32
 static const char* kProfNames[PC_COUNT][2] = {
     {"gemm_split_kernel<128,128>", "gemm_frag_kernel<128,128>"}, {"gemm_split_kernel<128,64>", "gemm_frag_kernel<128,64>"},
     {"gemm_split_kernel<64,128>", "gemm_frag_kernel<64,128>"}, {"gemm_split_kernel<64,64>", "gemm_frag_kernel<64,64>"},
     {"gn_stats_partial", "gn_stats_partial"}, {"gn_temporal_kernel", "gn_temporal_kernel"},
     {"attn_spatial_kernel", "attn_spatial_kernel"}, {"attn_temporal_kernel", "attn_temporal_kernel"},
     {"out_conv_kernel", "out_conv_kernel"}, {"affine_act_kernel", "affine_act_kernel"}, {"posterior_kernel", "posterior_kernel"},
-    {"conv3x3_frag_kernel<128,128>", "conv3x3_frag_kernel<128,128>"}, {"conv3x3_frag_kernel<128,64>", "conv3x3_frag_kernel<128,64>"},
-    {"conv3x3_frag_kernel<64,128>", "conv3x3_frag_kernel<64,128>"}, {"conv3x3_frag_kernel<64,64>", "conv3x3_frag_kernel<64,64>"},
-    {"conv3x3_wino_s64_kernel", "conv3x3_wino_kernel"}, {"conv3x3_wino_r64_kernel", "conv3x3_wino_r64_kernel"},
+    {"igemm_kernel<128,128> 3x3", "igemm_kernel<128,128> 3x3"}, {"igemm_kernel<128,64> 3x3", "igemm_kernel<128,64> 3x3"},
+    {"igemm_kernel<64,128> 3x3", "igemm_kernel<64,128> 3x3"}, {"igemm_kernel<64,64> 3x3", "igemm_kernel<64,64> 3x3"},
+    {"conv3x3_wino_kernel", "conv3x3_wino_kernel"}, {"conv3x3_wino_r64_kernel", "conv3x3_wino_r64_kernel"},
     {"gemm_split_kernel<128,192>", "gemm_split_kernel<128,192>"},
     {"conv3x3_wino_r64_ups_kernel", "conv3x3_wino_r64_ups_kernel"}};
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; char tag[56]; };
@@ -160,11 +152,11 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     IgemmArgs one = g;                         // a big window goes out as several launches over frame ranges (igemm.hip)
     one.nfr = std::max(1, std::min(g.nfr, igemm_frames_per_launch(g)));
     one.M = one.nfr * g.Ho * g.Wo;
-    const bool wino = conv_wino_supported(one) || conv_wino_s64_supported(one);
+    const bool wino = conv_wino_supported(one) || conv_wino_r64_supported(one);
     const bool split_gemm = gemm_split_supported(one) || conv_split_supported(one);
     const int cls = wino ? (int)(g.ups_phase ? PC_CONV_WINO_R64_UPS : conv_wino_r64_supported(one) ? PC_CONV_WINO_R64 : PC_CONV_WINO)
                     : split_gemm && gemm_split_tile_class(one.M, g.Cout) == 4 ? (int)PC_IGEMM_128x192
-                    : igemm_tile_class(one.M, g.Cout) + (conv_halo_supported(one) ? (int)PC_CONV_128x128 : 0);
+                    : igemm_tile_class(one.M, g.Cout) + (g.ksz == 3 && !split_gemm ? (int)PC_CONV_128x128 : 0);   // 3x3 on the generic kernel
     char tag[56];
     snprintf(tag, sizeof(tag), "M=%d N=%d K=%d k%d s%d%s%s%s", g.M, g.Cout, g.Cin, g.ksz, g.stride, g.ups ? " ups" : "",
              g.affA ? " pro" : (g.act ? " act" : ""), g.res ? " res" : "");
@@ -243,6 +235,7 @@ struct vd_engine {
     // return_attn_weights: device buffers for the next forward, one pair per attention block in execution order
     std::vector<float*> attn_cap_t, attn_cap_s;
     int attn_seq = 0;
+    int mean_type = 0;                               // what the network's output IS: 0 eps (ModelMeanType.EPSILON), 1 x_0 (START_X)
     int* d_err = nullptr;                            // sticky device flags: bit 0 = timestep index out of range
     int device = -1;
     double* d_part = nullptr; size_t part_cap = 0;   // NLL partial sums
@@ -305,7 +298,7 @@ struct vd_engine {
         if (k == PK_CONV3W) { g.wwino = W(p); g.wsplit = split_conv() ? 2 : 0; }
         else if (k == PK_CONV3WU) { g.wwino = W(p); g.wsplit = 2; g.ups_phase = 1; }
         else if (k == PK_CONV3S) { g.wfrag = W(p); g.wsplit = 1; }
-        else if (k == PK_CONV3F || k == PK_LINF) { g.wfrag = W(p); g.wsplit = k == PK_LINF && split_math(); }
+        else if (k == PK_LINF) { g.wfrag = W(p); g.wsplit = split_math(); }
         else g.w = W(p);
     }
 
@@ -318,11 +311,13 @@ struct vd_engine {
         for (long long s : shape) { p.shape[i++] = s; p.numel *= (size_t)s; }
         p.kind = kind;
         p.packed = p.numel;
-        if (kind == PK_STEM) p.packed = (size_t)p.shape[0] * STEM_KPAD;
-        if ((kind == PK_STEM || kind == PK_LINF) && split_math()) p.packed = p.packed * 3 / 2;       // three bf16 planes
-        if (kind == PK_CONV3S) p.packed = p.numel * 3 / 2;
-        if (kind == PK_CONV3W) p.packed = (size_t)16 * p.shape[0] * p.shape[1] * (split_conv() ? 3 : 2) / 2;
-        if (kind == PK_CONV3WU) p.packed = (size_t)4 * 16 * p.shape[0] * p.shape[1] * 3 / 2;
+        // split images: three 16-bit pieces per weight + the trailer of per-output scales (2 floats per output; split_pack.hip)
+        const size_t O = (size_t)p.shape[0];
+        if (kind == PK_STEM) p.packed = O * STEM_KPAD;
+        if ((kind == PK_STEM || kind == PK_LINF) && split_math()) p.packed = p.packed * 3 / 2 + 2 * O;
+        if (kind == PK_CONV3S) p.packed = p.numel * 3 / 2 + 2 * O;
+        if (kind == PK_CONV3W) p.packed = split_conv() ? (size_t)16 * O * p.shape[1] * 3 / 2 + 2 * O : (size_t)16 * O * p.shape[1];
+        if (kind == PK_CONV3WU) p.packed = (size_t)4 * 16 * O * p.shape[1] * 3 / 2 + 8 * O;
         params.push_back(p);
         pidx[name] = (int)params.size() - 1;
         return (int)params.size() - 1;
@@ -372,16 +367,11 @@ int vd_engine::build() {
     p_te0w = add("time_embed.0.weight", {E, mc}, PK_LINF); p_te0b = add("time_embed.0.bias", {E});
     p_te2w = add("time_embed.2.weight", {E, E}, PK_LINF); p_te2b = add("time_embed.2.bias", {E});
 
-    // 3x3 stride-1 convs at >= 8x8 run on the halo kernel and store their weights fragment-major
-    //   (Winograd F(2x2,3x3) where Cout is a multiple of 64; VD_CONV=direct keeps the direct kernel for A/B runs)
-    static const bool no_wino = getenv("VD_CONV") && std::string(getenv("VD_CONV")) == "direct";
-    auto k3 = [&](int res_out, int cout) {
-        if (res_out >= 8 && cout % 64 == 0 && !no_wino) return (int)PK_CONV3W;
-        return res_out >= 8 && cout % 32 == 0 ? (int)PK_CONV3F : (int)PK_CONV3;
-    };
+    // 3x3 stride-1 convs at >= 8x8 with a multiple of 64 couts run as Winograd F(2x2,3x3); the rest on the generic kernel
+    auto k3 = [&](int res_out, int cout) { return res_out >= 8 && cout % 64 == 0 ? (int)PK_CONV3W : (int)PK_CONV3; };
     // backward-data image of a 3x3 stride-1 conv with `co` outputs (= the forward's inputs) and `ci` inputs at resolution rs
     auto k3b = [&](int rs, int co, int ci) {
-        return rs >= 8 && (rs & (rs - 1)) == 0 && co % 64 == 0 && ci % 32 == 0 && split_conv() && !no_wino ? (int)PK_CONV3W : (int)PK_CONV3;
+        return rs >= 8 && (rs & (rs - 1)) == 0 && co % 64 == 0 && ci % 32 == 0 && split_conv() ? (int)PK_CONV3W : (int)PK_CONV3;
     };
     auto bwd3 = [&](int p, int rs) { params[p].kind_bwd = k3b(rs, (int)params[p].shape[1], (int)params[p].shape[0]); };
     auto bwdl = [&](int p) { params[p].kind_bwd = PK_LINF; };
@@ -490,12 +480,10 @@ int vd_engine::build() {
             int li = 1;
             if (in_att(ds)) { int ai = add_attn(pre + "." + std::to_string(li++), ch); if (ai < 0) return ai; blk.push_back(Layer{2, ai}); }
             if (lvl && i == nrb) {
-                // Upsample + conv: the sub-pixel form where the split Winograd kernel serves the SOURCE map (VD_UPS_PHASE=0: A/B switch)
-                static const bool no_phase = (getenv("VD_UPS_PHASE") && std::string(getenv("VD_UPS_PHASE")) == "0") ||
-                                             (getenv("VD_CONV_R64") && getenv("VD_CONV_R64")[0] == '0');   // the form lives in conv_wino_r64.hip only
+                // Upsample + conv: the sub-pixel form where the split Winograd kernel serves the SOURCE map
                 const int rs_src = cfg.image_size / ds;
                 int kup = k3(2 * rs_src, ch);
-                if (kup == PK_CONV3W && split_conv() && !no_phase && rs_src >= 8 && (rs_src & (rs_src - 1)) == 0 && ch % 64 == 0) kup = PK_CONV3WU;
+                if (kup == PK_CONV3W && split_conv() && rs_src >= 8 && (rs_src & (rs_src - 1)) == 0 && ch % 64 == 0) kup = PK_CONV3WU;
                 blk.push_back(Layer{4, add_conv(pre + "." + std::to_string(li++) + ".conv", ch, ch, kup, 2 * rs_src)});
                 ds /= 2;
             }
@@ -537,9 +525,9 @@ int vd_engine::build() {
     for (auto& p : params) {
         if (p.kind_bwd < 0) continue;
         const size_t O = (size_t)p.shape[1], I = (size_t)p.shape[0];          // outputs / inputs of the BACKWARD operator
-        if (p.kind == PK_STEM) p.packed_bwd = (size_t)STEM_KPAD * I * 3 / 2;
-        else if (p.kind_bwd == PK_LINF) p.packed_bwd = O * I * 3 / 2;
-        else if (p.kind_bwd == PK_CONV3W) p.packed_bwd = 16 * O * I * 3 / 2;
+        if (p.kind == PK_STEM) p.packed_bwd = (size_t)STEM_KPAD * I * 3 / 2 + 2 * STEM_KPAD;
+        else if (p.kind_bwd == PK_LINF) p.packed_bwd = O * I * 3 / 2 + 2 * O;
+        else if (p.kind_bwd == PK_CONV3W) p.packed_bwd = 16 * O * I * 3 / 2 + 2 * O;
         else p.packed_bwd = 9 * O * I;
         p.off_bwd = offb;
         offb += (p.packed_bwd + 3) & ~(size_t)3;
@@ -1248,10 +1236,9 @@ extern "C" {
 
 const char* vd_last_error(void) { return g_last_error.c_str(); }
 const char* vd_version(void) {
-    return x3_math() ? "vdamd 0.2 (gfx950; DECLARED REDUCED MODE VD_MATH=bf16x3: matrix products as three bf16 piece products, operands ~16 significant bits)"
-           : split_conv() ? "vdamd 0.2 (gfx950; fp32 operands, matrix products as six bf16 piece products with fp32 accumulation)"
-           : split_math() ? "vdamd 0.2 (gfx950; linear layers as six bf16 piece products, 3x3 convs on the fp32 MFMA)"
-                          : "vdamd 0.2 (gfx950, fp32 MFMA)";
+    return math_mode() == MATH_F16X3 ? "vdamd 0.4 (gfx950; VD_MATH=f16x3: fp32 operands as two fp16 pieces (22 significand bits), three piece products, fp32 accumulation)"
+           : math_mode() == MATH_BF16X6 ? "vdamd 0.4 (gfx950; VD_MATH=bf16x6: fp32 operands split exactly into three bf16 pieces, six piece products, fp32 accumulation)"
+                                        : "vdamd 0.4 (gfx950; VD_MATH=fp32: every matrix product on the fp32 MFMA)";
 }
 
 int vd_create(const vd_config* cfg, vd_engine** out) {
@@ -1284,7 +1271,7 @@ unsigned long long vd_weights_layout_id(vd_engine* e) {
     if (!e) return 0;
     unsigned long long h = 1469598103934665603ull;
     auto mix = [&](unsigned long long v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
-    mix(split_math()); mix(split_conv()); mix(e->packed_total); mix(e->params.size());
+    mix(math_mode()); mix(e->packed_total); mix(e->params.size());
     for (const Param& p : e->params) {
         for (char c : p.name) mix((unsigned char)c);
         mix(p.kind); mix(p.off); mix(p.packed); mix(p.frag_rows); mix(p.frag_row0);
@@ -1333,13 +1320,18 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
     if (p.kind == PK_LINF && split_math()) {
         // rows [row0, row0+rows) of a [frag_rows][K] matrix -> K/16 contiguous pieces of its bf16-split fragment image
         const int rows = (int)p.shape[0], K = (int)p.shape[1];
-        std::vector<unsigned short> sp((size_t)p.numel * 3);
+        std::vector<unsigned short> sp(split_image_u16(rows, K));
         pack_linear_split(host, sp.data(), rows, K, rows, 0);
         const size_t piece = (size_t)(rows / 32) * 1536;                   // ushorts per k-step of this member
         for (int ks = 0; ks < K / 16; ++ks) {
             float* dst = e->wbuf + p.off + ((size_t)ks * (p.frag_rows / 32) + p.frag_row0 / 32) * 768;
             if ((rc_put = e->put(dst, sp.data() + ks * piece, piece * sizeof(unsigned short)))) return rc_put;
         }
+        // the rows' scales and reciprocals into the trailer of the whole (batched) image
+        const float* tr = reinterpret_cast<const float*>(sp.data() + (size_t)rows * K * 3);
+        float* trd = e->wbuf + p.off + (size_t)p.frag_rows * K * 3 / 2;
+        if ((rc_put = e->put(trd + p.frag_row0, tr, rows * sizeof(float)))) return rc_put;
+        if ((rc_put = e->put(trd + p.frag_rows + p.frag_row0, tr + rows, rows * sizeof(float)))) return rc_put;
         p.loaded = true;
         return 0;
     }
@@ -1358,7 +1350,7 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
     }
     if (p.kind == PK_CONV3W && split_conv()) {
         tmp.resize(p.packed);
-        pack_conv3_wino_s64(host, reinterpret_cast<unsigned short*>(tmp.data()), (int)p.shape[0], (int)p.shape[1]);
+        pack_conv3_wino_split(host, reinterpret_cast<unsigned short*>(tmp.data()), (int)p.shape[0], (int)p.shape[1]);
         src = tmp.data();
     } else if (p.kind == PK_CONV3WU) {
         tmp.resize(p.packed);
@@ -1372,10 +1364,6 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
         tmp.resize(p.packed);
         pack_conv3_split(host, reinterpret_cast<unsigned short*>(tmp.data()), (int)p.shape[0], (int)p.shape[1]);
         src = tmp.data();
-    } else if (p.kind == PK_CONV3F) {
-        tmp.resize(p.numel);
-        pack_conv3_frag(host, tmp.data(), (int)p.shape[0], (int)p.shape[1]);
-        src = tmp.data();
     } else if (p.kind == PK_STEM) {                    // OIHW -> [O][k = tap*I + i] (zero padded) -> fragment-major linear
         const int O = (int)p.shape[0], I = (int)p.shape[1];
         std::vector<float> lin((size_t)O * STEM_KPAD, 0.f);
@@ -1383,7 +1371,7 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
             for (int i = 0; i < I; ++i)
                 for (int t = 0; t < 9; ++t) lin[(size_t)o * STEM_KPAD + t * I + i] = host[((size_t)o * I + i) * 9 + t];
         if (split_math()) {
-            tmp.resize((size_t)O * STEM_KPAD * 3 / 2);
+            tmp.resize(p.packed);
             pack_linear_split(lin.data(), reinterpret_cast<unsigned short*>(tmp.data()), O, STEM_KPAD, O, 0);
         } else {
             tmp.resize((size_t)O * STEM_KPAD);
@@ -1462,6 +1450,15 @@ int vd_set_schedule(vd_engine* e, int nts, const float* tab, const int* tmap, fl
     return 0;
 }
 
+// ModelMeanType of the bound diffusion (gaussian_diffusion.py:29-36): 0 EPSILON (default), 1 START_X (predict_xstart=True,
+// script_util.py:429-431).  Captured window graphs bake it in: they are dropped on a change.
+int vd_set_model_mean_type(vd_engine* e, int type) {
+    VD_REQUIRE(e && (type == 0 || type == 1), "model mean type: 0 EPSILON, 1 START_X");
+    if (type != e->mean_type) { if (e->win_cur >= 0) e->win_lost = true; e->drop_window_graphs(); }
+    e->mean_type = type;
+    return 0;
+}
+
 int vd_device_errors(vd_engine* e, int* flags) {
     VD_REQUIRE(e && flags, "null argument");
     *flags = 0;
@@ -1530,6 +1527,9 @@ static int step_launches(vd_engine* e, int mode, int B, int T, const float* x, c
                          const unsigned long long* rng, float* sample, float* xstart, float* mean, float* eps_out,
                          hipStream_t st, const PrefixPlan* pp = nullptr) {
     int rc;
+    // every sampler entry point comes through here (vd_p_sample / vd_ddim_sample / vd_p_mean_variance / the window executor): a
+    // 6-channel network output must never reach the 3-channel posterior kernel
+    VD_REQUIRE(!e->cfg.learn_sigma, "learn_sigma: the reference's sampler asserts on video tensors (gaussian_diffusion.py:283: model_output.shape == (B, 2*T, ...)); only the network forward is served");
     const size_t per = (size_t)T * 3 * e->cfg.image_size * e->cfg.image_size;
     // tail of the workspace: t_model [B] + eps scratch (sized by ensure_ws for this B)
     float* tm = reinterpret_cast<float*>(e->ws + e->ws_tail);
@@ -1541,6 +1541,7 @@ static int step_launches(vd_engine* e, int mode, int B, int T, const float* x, c
     if ((rc = e->forward(fi, st, ar, pp))) return rc;
     PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
                      mode, eta, seed, offset, sample, xstart, mean, rng};
+    if (e->mean_type == 1) pa.x0_given = eps;        // START_X: pred_xstart = process_xstart(model_output) (gaussian_diffusion.py:326-341)
     ProfScope ps(PC_POSTERIOR, 0.0, 4.0 * B * per * 5.0, st);
     return launch_posterior(pa, st);
 }
@@ -1842,7 +1843,7 @@ long long vd_bwd_weights_bytes(vd_engine* e) { return e ? (long long)(e->packed_
 
 int vd_set_bwd_weight_storage(vd_engine* e, void* buf, long long bytes, int on_host) {
     VD_REQUIRE(e && buf, "null argument");
-    VD_REQUIRE(split_conv(), "use_gradient_method runs on the default arithmetic only (VD_MATH / VD_CONV_SPLIT unset)");
+    VD_REQUIRE(split_conv(), "use_gradient_method runs on the split arithmetic only (VD_MATH=f16x3 | bf16x6)");
     VD_REQUIRE(bytes >= (long long)(e->packed_bwd_total * sizeof(float)), "backward weight buffer too small");
     e->wbuf_bwd = static_cast<float*>(buf);
     e->wbuf_bwd_on_host = on_host != 0;
@@ -1877,7 +1878,7 @@ int vd_load_weight_bwd(vd_engine* e, const char* name, const float* host, long l
             for (int i = 0; i < I; ++i)
                 for (int t = 0; t < 9; ++t) wr[((size_t)i * O + o) * 9 + t] = host[((size_t)o * I + i) * 9 + (8 - t)];
         if (p.kind_bwd == PK_CONV3W) {
-            pack_conv3_wino_s64(wr.data(), reinterpret_cast<unsigned short*>(tmp.data()), I, O);
+            pack_conv3_wino_split(wr.data(), reinterpret_cast<unsigned short*>(tmp.data()), I, O);
         } else {                                       // generic kernel: [tap][Cout' = I][Cin' = O]
             for (int i = 0; i < I; ++i)
                 for (int o = 0; o < O; ++o)
@@ -1906,6 +1907,7 @@ int vd_guided_step(vd_engine* e, int B, int T, const float* x, const float* obs,
     if (rc) return rc;
     VD_REQUIRE(e->d_tab, "vd_set_schedule not called");
     VD_REQUIRE(!e->cfg.learn_sigma, "learn_sigma: the reference's sampler asserts on video tensors (gaussian_diffusion.py:283)");
+    VD_REQUIRE(e->mean_type == 0, "use_gradient_method: epsilon-prediction models only");
     VD_REQUIRE(e->wbuf_bwd && !e->wbuf_bwd_on_host, "use_gradient_method: the backward-data weight image is not on the device (vd_set_bwd_weight_storage / vd_load_weight_bwd)");
     VD_REQUIRE(x && obs && lat && km && fidx && t && x_t_minus_1 && noise && (sample == nullptr || noise2 != nullptr), "null tensor");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1950,21 +1952,18 @@ int vd_randn(float* out, long long n, unsigned long long seed, unsigned long lon
     return launch_randn(out, (long)n, seed, offset, static_cast<hipStream_t>(stream));
 }
 
-int vd_pack_conv3_frag(const float* host_oihw, float* host_out, int O, int I) {
-    VD_REQUIRE(host_oihw && host_out && O % 32 == 0 && I % 32 == 0, "O and I multiples of 32");
-    pack_conv3_frag(host_oihw, host_out, O, I);
+long long vd_split_image_u16(long long n_out, long long k_total) { return (long long)split_image_u16((size_t)n_out, (size_t)k_total); }
+int vd_math_mode(void) { return math_mode(); }
+
+int vd_pack_conv3_wino_split(const float* host_oihw, unsigned short* host_out, int O, int I) {
+    VD_REQUIRE(host_oihw && host_out && O % 64 == 0 && I % 32 == 0, "vd_pack_conv3_wino_split: O multiple of 64, I of 32");
+    pack_conv3_wino_split(host_oihw, host_out, O, I);
     return 0;
 }
 
-int vd_pack_conv3_wino_s64(const float* host_oihw, unsigned short* host_out, int O, int I) {
-    VD_REQUIRE(host_oihw && host_out && O % 64 == 0 && I % 32 == 0, "vd_pack_conv3_wino_s64: O multiple of 64, I of 32");
-    pack_conv3_wino_s64(host_oihw, host_out, O, I);
-    return 0;
-}
-
-static int op_conv_wino_split(int kernel, const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split,
-                              const float* bias, const float* res, const float* fbias, int fbias_ld, float* out, int Cout,
-                              double* gn_part, void* stream) {
+int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
+                          const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
+                          void* stream) {
     IgemmArgs g{};
     g.src0 = src0; g.C0 = Cin; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws; g.ups = ups;
     g.stride = 1; g.pad = 1; g.ksz = 3;
@@ -1972,30 +1971,8 @@ static int op_conv_wino_split(int kernel, const float* src0, int Cin, int nfr, i
     g.wwino = static_cast<const float*>(w_split); g.wsplit = 2; g.bias = bias; g.res = res; g.res_ld = Cout;
     g.fbias = fbias; g.fbias_ld = fbias_ld; g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
     g.stats = gn_part; g.stats_split = conv_wino_stats_split(g.Ho);
-    VD_REQUIRE(conv_wino_s64_supported(g), "vd_op_conv_wino_*: shape not covered by the kernels");
-    if (kernel == 0) return launch_igemm(g, static_cast<hipStream_t>(stream));       // the engine's choice
-    VD_REQUIRE(igemm_frames_per_launch(g) >= nfr, "vd_op_conv_wino_*: window too large for one launch");
-    if (kernel == 1) return launch_conv_wino_s64(g, static_cast<hipStream_t>(stream));
-    VD_REQUIRE(conv_wino_r64_supported(g), "vd_op_conv_wino_r64: VD_CONV_R64=0 switches the kernel off");
-    return launch_conv_wino_r64(g, static_cast<hipStream_t>(stream));
-}
-
-int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
-                          const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
-                          void* stream) {
-    return op_conv_wino_split(0, src0, Cin, nfr, Hs, Ws, ups, w_split, bias, res, fbias, fbias_ld, out, Cout, gn_part, stream);
-}
-
-int vd_op_conv_wino_s64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
-                        const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
-                        void* stream) {
-    return op_conv_wino_split(1, src0, Cin, nfr, Hs, Ws, ups, w_split, bias, res, fbias, fbias_ld, out, Cout, gn_part, stream);
-}
-
-int vd_op_conv_wino_r64(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const void* w_split, const float* bias,
-                        const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
-                        void* stream) {
-    return op_conv_wino_split(2, src0, Cin, nfr, Hs, Ws, ups, w_split, bias, res, fbias, fbias_ld, out, Cout, gn_part, stream);
+    VD_REQUIRE(conv_wino_r64_supported(g), "vd_op_conv_wino_split: shape not covered by conv_wino_r64.hip");
+    return launch_igemm(g, static_cast<hipStream_t>(stream));            // cuts big windows along frames like the engine
 }
 
 int vd_pack_conv3_wino_ups(const float* host_oihw, unsigned short* host_out, int O, int I) {

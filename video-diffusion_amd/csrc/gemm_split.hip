@@ -13,6 +13,10 @@
 // Same operand plan as gemm_frag.hip: the A tile [BM][32] of a K-chunk is split once by the staging threads into three
 // bf16 planes in LDS (rows padded to 80 bytes: conflict-free ds_read_b128 fragments), the weights are split on the
 // host at load time and stream from L2 in fragment order [K/16][N/32][piece 3][lane 64][8 bf16], three k-steps ahead.
+//
+// F16 (the default arithmetic, VD_MATH=f16x3, vd_common.h): the A tile is split into TWO fp16 planes, a0 = f16(x) and
+// a1 = f16((x - a0) * 2^12); three piece products a1 * (2^-12 b0) + a0 * b1 + a0 * b0 on v_mfma_f32_32x32x16_f16; the weight
+// rows carry a power-of-two scale (image trailer): the accumulators start at (bias + residual) * s and leave through 1 / s.
 #include <cstring>
 #include <vector>
 
@@ -22,6 +26,14 @@ namespace vd {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_piece(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 #ifndef VD_GS_PF3
 #define VD_GS_PF3 1        // 0: the A operand one chunk ahead for every tile (A/B)
@@ -34,12 +46,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 constexpr int SROW = 80;                   // bytes per LDS row of one plane: 32 bf16 + 16 bytes of padding
 
-__device__ __forceinline__ void split3(f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
-    p1 = __builtin_convertvector(v, bf16x4);
-    f32x4 r = v - __builtin_convertvector(p1, f32x4);
-    p2 = __builtin_convertvector(r, bf16x4);
-    r = r - __builtin_convertvector(p2, f32x4);
-    p3 = __builtin_convertvector(r, bf16x4);
+template <bool F16>
+__device__ __forceinline__ void split3(f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
+    if constexpr (F16) {
+        p1.x = f16_pack(v.x, v.y); p1.y = f16_pack(v.z, v.w);
+        p2.x = f16_pack_scaled(f16_rem_lo(p1.x, v.x), f16_rem_hi(p1.x, v.y), 4096.f);
+        p2.y = f16_pack_scaled(f16_rem_lo(p1.y, v.z), f16_rem_hi(p1.y, v.w), 4096.f);
+        p3 = p2;
+    } else {
+        const bf16x4 q1 = __builtin_convertvector(v, bf16x4);
+        f32x4 r = v - __builtin_convertvector(q1, f32x4);
+        const bf16x4 q2 = __builtin_convertvector(r, bf16x4);
+        r = r - __builtin_convertvector(q2, f32x4);
+        const bf16x4 q3 = __builtin_convertvector(r, bf16x4);
+        p1 = __builtin_bit_cast(u32x2, q1); p2 = __builtin_bit_cast(u32x2, q2); p3 = __builtin_bit_cast(u32x2, q3);
+    }
 }
 
 // CONV: the A operand is the implicit im2col matrix of a 3x3 convolution (any stride, zero padding 1) over one NHWC
@@ -48,7 +69,7 @@ __device__ __forceinline__ void split3(f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& 
 // SIDE: the ResBlock skip convolution (unet.py:159-166, 1x1 over the block input) reads the same tensor the block's first
 // GroupNorm+SiLU reads; the column blocks 0 write that activation image from the rows they stage (IgemmArgs::side): one pass
 // over the (largest) tensor of the block instead of two.
-template <int BM, int BN, bool ACT, bool CONV, bool X3 = false, bool SIDE = false>      // X3: VD_MATH=bf16x3, three of the six piece products (vd_common.h)
+template <int BM, int BN, bool ACT, bool CONV, bool F16 = true, bool SIDE = false>      // F16: VD_MATH=f16x3 (default) | bf16x6 (vd_common.h)
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
     // weight ring slots (k-steps ahead = RING - 1): 2 for the 128x192 tile (256 registers per wave), 3 for the others -- and 6
@@ -59,7 +80,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     // split + store of the next chunk waits a full memory round trip every chunk, and a small-M launch (a B = 1 shard: 60 of
     // them per step) costs ~1 us per chunk whatever its size.  The small tiles have the registers for three chunks in flight.
     constexpr int PF = (BM == 64 && VD_GS_PF3) ? 3 : 1;
-    constexpr int PLANE = BM * SROW, ABUF = 3 * PLANE;                    // bytes
+    constexpr int NPL = F16 ? 2 : 3;                                      // planes of the A tile
+    constexpr int PLANE = BM * SROW, ABUF = NPL * PLANE;                  // bytes
     extern __shared__ __attribute__((aligned(16))) char smem_c[];         // [2][3 planes][BM][SROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -107,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     for (int j = 0; j < NI; ++j) bo[j] = (unsigned)min((int)blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1) * 3072u + lane * 16u;
 
     f32x4 ra[PF][AR];
-    bf16x8 bfr[RING][NI][3], afr[2][MI][3];      // [ring slot][tile][piece]
+    u32x4 bfr[RING][NI][3], afr[2][MI][NPL];     // [ring slot][tile][piece]
     // SIDE: this block's frame, the affine pair of the chunk in flight, and the image rows of this thread
     static_assert(!SIDE || (BM == 128 && !CONV && !ACT), "side output: 128-row tiles of a plain 1x1");
     const bool side_on = SIDE && blockIdx.y == 0;
@@ -158,12 +180,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
             f32x4 v = ra[rs][j];
             side_store(v, 0, j);                 // (the prologue's chunk)
             if constexpr (ACT) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-            bf16x4 p1, p2, p3;
-            split3(v, p1, p2, p3);
+            u32x2 p1, p2, p3;
+            split3<F16>(v, p1, p2, p3);
             char* d = Ad + (lrow + 32 * j) * SROW + lq * 8;
-            *reinterpret_cast<bf16x4*>(d) = p1;
-            *reinterpret_cast<bf16x4*>(d + PLANE) = p2;
-            *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = p3;
+            *reinterpret_cast<u32x2*>(d) = p1;
+            *reinterpret_cast<u32x2*>(d + PLANE) = p2;
+            if constexpr (!F16) *reinterpret_cast<u32x2*>(d + 2 * PLANE) = p3;
         }
     };
     auto b_load = [&](int slot, int kstep) {      // kstep = global 16-wide k step
@@ -172,26 +194,29 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                bfr[slot][j][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p * 1024, so, 0));
+                bfr[slot][j][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p * 1024, so, 0));
     };
     const int aoff = (wm * (BM / 2) + lr) * SROW + lh * 16;
     auto a_frags = [&](int slot, const char* Ab, int ks) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                afr[slot][i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * PLANE + aoff + i * 32 * SROW + ks * 32);
+            for (int p = 0; p < NPL; ++p)
+                afr[slot][i][p] = *reinterpret_cast<const u32x4*>(Ab + p * PLANE + aoff + i * 32 * SROW + ks * 32);
     };
 
     const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.ldo * 4, 0x00020000);
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0,
                                                         a.res ? a.M * a.ldo * 4 : 0, 0x00020000);
     unsigned vb[MI][NI];
-    float bv[NI];
+    float bv[NI], wsc[NI], winv[NI];             // F16: the weight rows' power-of-two scale and its reciprocal (image trailer)
+    const float* trailer = a.wfrag + (size_t)(CONV ? 9 : 1) * a.Cin * a.Cout * 3 / 2;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int co = n0 + wn * (BN / 2) + j * 32 + lr;
         bv[j] = a.bias && co < a.Cout ? a.bias[co] : 0.f;
+        wsc[j] = F16 ? trailer[min(co, a.Cout - 1)] : 1.f;
+        winv[j] = F16 ? trailer[a.Cout + min(co, a.Cout - 1)] : 1.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
             vb[i][j] = co < a.Cout ? (unsigned)((m0 + wm * (BM / 2) + i * 32 + 4 * lh) * a.ldo + co) * 4u : 0x80000000u;
@@ -214,6 +239,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
                     acc[i][j][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vb[i][j] + srow, 0, 0));
                 }
     }
+    if constexpr (F16) {                         // (bias + residual) * s: exact (s is a power of two), undone by 1 / s at the end
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= wsc[j];
+    }
 
     const int nks = 2 * nchunk;
     a_prefetch(0, 0);
@@ -235,8 +268,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     // stops spilling: 256 registers + 44 bytes of scratch -> 236, none.)
     auto b_load_one = [&](int slot, int kstep, int idx) {                // idx = j * 3 + p
         const int j = idx / 3, p2 = idx - 3 * j;
-        if (X3 && p2 == 2) return;
-        bfr[slot][j][p2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p2 * 1024, kstep * ncoblk * 3072, 0));
+        bfr[slot][j][p2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p2 * 1024, kstep * ncoblk * 3072, 0));
     };
     auto a_prefetch_one = [&](int chunk, int rs, int j) {
         if constexpr (CONV) {
@@ -253,19 +285,19 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     };
     auto a_frag_one = [&](int slot, const char* Ab, int ks, int idx) {   // idx = i * 3 + p
         const int i = idx / 3, p2 = idx - 3 * i;
-        if (X3 && p2 == 2) return;
-        afr[slot][i][p2] = *reinterpret_cast<const bf16x8*>(Ab + p2 * PLANE + aoff + i * 32 * SROW + ks * 32);
+        if (p2 >= NPL) return;
+        afr[slot][i][p2] = *reinterpret_cast<const u32x4*>(Ab + p2 * PLANE + aoff + i * 32 * SROW + ks * 32);
     };
     auto a_store_one = [&](char* Ad, int rs, int j, int data_chunk) {
         f32x4 v = ra[rs][j];
         if (data_chunk >= 0) side_store(v, data_chunk, j);
         if constexpr (ACT) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-        bf16x4 p1, p2, p3;
-        split3(v, p1, p2, p3);
+        u32x2 p1, p2, p3;
+        split3<F16>(v, p1, p2, p3);
         char* d = Ad + (lrow + 32 * j) * SROW + lq * 8;
-        *reinterpret_cast<bf16x4*>(d) = p1;
-        *reinterpret_cast<bf16x4*>(d + PLANE) = p2;
-        if (!X3) *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = p3;
+        *reinterpret_cast<u32x2*>(d) = p1;
+        *reinterpret_cast<u32x2*>(d + PLANE) = p2;
+        if constexpr (!F16) *reinterpret_cast<u32x2*>(d + 2 * PLANE) = p3;
     };
     constexpr int NT = MI * NI;                                            // tiles = slots per k-step
     auto kstep = [&](int chunk, int ks, int gslot, int aslot, int pf_chunk, int pf_slot, int st_slot) {
@@ -278,14 +310,18 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
             for (int j = 0; j < NI; ++j) {
                 const int t = i * NI + j;
                 f32x16 c = acc[i][j];
-                if constexpr (!X3) {
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][1], bfr[gslot][j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][2], bfr[gslot][j][0], c, 0, 0, 0);
+                if constexpr (F16) {             // a1 * (2^-12 b0) + a0 * b1 + a0 * b0
+                    c = mfma_piece<true>(afr[aslot][i][1], bfr[gslot][j][2], c);
+                    c = mfma_piece<true>(afr[aslot][i][0], bfr[gslot][j][1], c);
+                    c = mfma_piece<true>(afr[aslot][i][0], bfr[gslot][j][0], c);
+                } else {
+                    c = mfma_piece<false>(afr[aslot][i][0], bfr[gslot][j][2], c);
+                    c = mfma_piece<false>(afr[aslot][i][1], bfr[gslot][j][1], c);
+                    c = mfma_piece<false>(afr[aslot][i][2], bfr[gslot][j][0], c);
+                    c = mfma_piece<false>(afr[aslot][i][0], bfr[gslot][j][1], c);
+                    c = mfma_piece<false>(afr[aslot][i][1], bfr[gslot][j][0], c);
+                    c = mfma_piece<false>(afr[aslot][i][0], bfr[gslot][j][0], c);
                 }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][1], bfr[gslot][j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[aslot][i][0], bfr[gslot][j][0], c, 0, 0, 0);
                 acc[i][j] = c;
                 // this tile's share of the step's requests
 #pragma unroll
@@ -318,6 +354,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         }
     }
 
+    if constexpr (F16) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= winv[j];
+    }
     // GroupNorm partial sums of the output (the layout gn_stats_partial / the Winograd epilogue write): a wave tile is BM/2
     // rows of ONE frame (a.stats_hw % (BM/2) == 0), a lane holds 16 rows of its column per M-tile, the other 16 sit in lane ^ 32
     if (a.stats) {
@@ -378,34 +422,31 @@ bool gemm_split_side_supported(const IgemmArgs& a) {
            a.side_hw > 0 && a.side_hw % 128 == 0 && a.M % a.side_hw == 0;
 }
 
-template <int BM, int BN>
-static int launch_gs(const IgemmArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)2 * 3 * BM * SROW;
+template <int BM, int BN, bool F16>
+static int launch_gs_m(const IgemmArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * (F16 ? 2 : 3) * BM * SROW;
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.zcount > 1 ? a.zcount : 1);
     if (a.side) {
         if constexpr (BM == 128 && BN == 128) {
             VD_REQUIRE(gemm_split_side_supported(a) && a.sideA && a.sideB, "side output: plain 1x1 on the 128x128 tile, whole frames of a multiple of 128 rows");
-            if (x3_math()) hipLaunchKernelGGL((gemm_split_kernel<128, 128, false, false, true, true>), grid, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL((gemm_split_kernel<128, 128, false, false, false, true>), grid, dim3(256), lds, s, a);
+            hipLaunchKernelGGL((gemm_split_kernel<128, 128, false, false, F16, true>), grid, dim3(256), lds, s, a);
             VD_HIP(hipGetLastError());
             return 0;
         } else {
             VD_REQUIRE(false, "side output: 128x128 tile only");
         }
     }
-    if (x3_math()) {                         // the declared three-product mode (vd_common.h)
-        if (a.ksz == 3) {
-            if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, true, true>), grid, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, true, true>), grid, dim3(256), lds, s, a);
-        } else if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, false, true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, false, true>), grid, dim3(256), lds, s, a);
-    } else if (a.ksz == 3) {
-        if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, true>), grid, dim3(256), lds, s, a);
-    } else if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, false>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, false>), grid, dim3(256), lds, s, a);
+    if (a.ksz == 3) {
+        if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, true, F16>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, true, F16>), grid, dim3(256), lds, s, a);
+    } else if (a.act) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, true, false, F16>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, false, false, F16>), grid, dim3(256), lds, s, a);
     VD_HIP(hipGetLastError());
     return 0;
+}
+template <int BM, int BN>
+static int launch_gs(const IgemmArgs& a, hipStream_t s) {
+    return f16_math() ? launch_gs_m<BM, BN, true>(a, s) : launch_gs_m<BM, BN, false>(a, s);
 }
 
 // 128x192 tile for the wide projections (qkv: N = 1152, 1536; proj: N = 384): the A tile is staged and split once per 192
@@ -437,49 +478,6 @@ int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s) {
         case 2: return launch_gs<64, 128>(a, s);
         default: return launch_gs<64, 64>(a, s);
     }
-}
-
-// host: fp32 -> three bf16 pieces (round to nearest even on the top 16 bits)
-static inline unsigned short bf16_rne(float f) {
-    unsigned u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);          // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-static inline float bf16_to_f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
-
-void split3_host(float v, unsigned short out[3]) {
-    out[0] = bf16_rne(v);
-    const float r1 = v - bf16_to_f(out[0]);
-    out[1] = bf16_rne(r1);
-    out[2] = bf16_rne(r1 - bf16_to_f(out[1]));
-}
-
-// rows [row0, row0+rows) of a [n_total][K] row-major matrix into the split fragment image of the WHOLE matrix:
-// [K/16][n_total/32][piece 3][lane 64][8]: lane 32h+r of a (k-step, column block) holds W[n = 32*blk + r][k = 16*ks + 8h + j]
-void pack_linear_split(const float* w, unsigned short* out_base, int rows, int K, int n_total, int row0) {
-    const int nks = K / 16, ncoblk = n_total / 32;
-    for (int ks = 0; ks < nks; ++ks)
-        for (int cb = 0; cb < rows / 32; ++cb)
-            for (int h = 0; h < 2; ++h)
-                for (int r = 0; r < 32; ++r)
-                    for (int j = 0; j < 8; ++j) {
-                        unsigned short p[3];
-                        split3_host(w[(size_t)(cb * 32 + r) * K + ks * 16 + 8 * h + j], p);
-                        for (int q = 0; q < 3; ++q)
-                            out_base[((((size_t)ks * ncoblk + row0 / 32 + cb) * 3 + q) * 64 + h * 32 + r) * 8 + j] = p[q];
-                    }
-}
-
-// OIHW 3x3 weights -> the split fragment image of the [Cout][9*Cin] matrix with k = tap*Cin + c (the order the CONV
-// mode of the kernel walks K)
-void pack_conv3_split(const float* w, unsigned short* out, int Cout, int Cin) {
-    std::vector<float> lin((size_t)Cout * 9 * Cin);
-    for (int o = 0; o < Cout; ++o)
-        for (int i = 0; i < Cin; ++i)
-            for (int t = 0; t < 9; ++t) lin[(size_t)o * 9 * Cin + (size_t)t * Cin + i] = w[((size_t)o * Cin + i) * 9 + t];
-    pack_linear_split(lin.data(), out, Cout, 9 * Cin, Cout, 0);
 }
 
 }  // namespace vd

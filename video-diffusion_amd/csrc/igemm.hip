@@ -200,28 +200,17 @@ static int launch_t(const IgemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-bool x3_math() {
-    static const bool v = [] { const char* e = getenv("VD_MATH"); return e && std::string(e) == "bf16x3"; }();
-    return v;
-}
-
 // One launch: every operand of `a` is small enough for the 32-bit byte offsets the kernels address with.
 static int launch_igemm_one(const IgemmArgs& a, hipStream_t s) {
     if (a.ups_phase) {                                                  // sub-pixel weight image: only conv_wino_r64.hip reads it
-        VD_REQUIRE(conv_wino_r64_supported(a), "sub-pixel Upsample conv needs conv_wino_r64.hip (VD_CONV_R64=0 with VD_UPS_PHASE on?)");
+        VD_REQUIRE(conv_wino_r64_supported(a), "sub-pixel Upsample conv: shape not covered by conv_wino_r64.hip");
         return launch_conv_wino_r64(a, s);
     }
     if (gemm_split_supported(a) || conv_split_supported(a)) return launch_gemm_split(a, igemm_tile_class(a.M, a.Cout), s);
-    if (conv_wino_r64_supported(a)) return launch_conv_wino_r64(a, s);      // maps >= 16x16; VD_CONV_R64=0 switches it off
-    if (conv_wino_s64_supported(a)) return launch_conv_wino_s64(a, s);
-    VD_REQUIRE(!a.wsplit, "bf16-split weights given for a shape the split kernels do not cover");
+    if (conv_wino_r64_supported(a)) return launch_conv_wino_r64(a, s);
+    VD_REQUIRE(!a.wsplit, "split weight image given for a shape the split kernels do not cover");
     if (gemm_frag_supported(a)) return launch_gemm_frag(a, igemm_tile_class(a.M, a.Cout), s);
     if (conv_wino_supported(a)) return launch_conv_wino(a, s);
-    static const bool no_halo = getenv("VD_NO_HALO") != nullptr;     // A/B switch for tools/bench_conv.py
-    if (!no_halo && conv_halo_supported(a)) {
-        const int rc = launch_conv_halo(a, igemm_tile_class(a.M, a.Cout), s);
-        if (rc <= 0) return rc;            // 1: shape not covered by the halo tiling -> generic path below
-    }
     VD_REQUIRE(a.w != nullptr, "this shape runs on the generic kernel and needs [tap][Cout][Cin] weights");
     switch (igemm_tile_class(a.M, a.Cout)) {
         case 0: return launch_t<128, 128>(a, s);
@@ -242,7 +231,7 @@ int igemm_frames_per_launch(const IgemmArgs& a) {
     const size_t out_pf = (size_t)a.Ho * a.Wo * std::max(a.ldo, a.res ? a.res_ld : 0);
     const size_t pf = std::max(in_pf, out_pf);
     if (pf == 0 || (size_t)a.nfr * pf <= lim || a.zcount > 1) return a.nfr;
-    const size_t align = (a.Hs == 1 && a.Ws == 1) ? 256 : 4;       // whole 128-row tiles / whole 4-frame groups (conv_wino_s64 TF4)
+    const size_t align = (a.Hs == 1 && a.Ws == 1) ? 256 : 4;       // whole 128-row tiles / whole 4-frame groups (conv_wino_r64 TF4)
     size_t maxfr = lim / pf / align * align;
     if (maxfr == 0) return 0;
     const size_t nl = ((size_t)a.nfr + maxfr - 1) / maxfr;

@@ -72,7 +72,7 @@ struct IgemmArgs {
     // problem z reads src0 + z*zs_a, wfrag + z*zs_w, bias + z*zs_bias and writes out + z*zs_out (element strides).
     // The three RPE-net output layers of an attention block (unet.py:283-298) go out this way.
     int zcount, zs_a, zs_w, zs_bias, zs_out;
-    // wsplit == 2: wwino is the image of pack_conv3_wino_s64 (conv_wino_s64.hip).  Otherwise:
+    // wsplit == 2: wwino is the image of pack_conv3_wino_split (conv_wino_r64.hip).  Otherwise:
     // wfrag is the bf16-split image of the weights (gemm_split.hip: fp32 accuracy from six bf16 piece products);
     // zs_w then counts floats of that image as well
     int wsplit;
@@ -103,18 +103,14 @@ struct AttnTemporalArgs {
 int launch_igemm(const IgemmArgs& a, hipStream_t s);
 int igemm_frames_per_launch(const IgemmArgs& a);   // frames (rows) per launch: big windows are cut along the frame dimension
 int igemm_tile_class(int M, int Cout);   // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
-// 3x3 stride-1 path with an LDS-staged, once-transformed input halo tile (conv_halo.hip)
-bool conv_halo_supported(const IgemmArgs& a);
-int launch_conv_halo(const IgemmArgs& a, int tile_class, hipStream_t s);
 // linear / 1x1 path with fragment-major weights (gemm_frag.hip); wfrag = [K/32][N/32][4][64][4]
 bool gemm_frag_supported(const IgemmArgs& a);
 int launch_gemm_frag(const IgemmArgs& a, int tile_class, hipStream_t s);
 void pack_linear_frag(const float* w, float* out_base, int rows, int K, int n_total, int row0);
-void pack_conv3_frag(const float* oihw, float* out, int O, int I);
 // Winograd F(2x2,3x3) path (conv_wino.hip): 2.25x fewer MFMAs than the direct 3x3 kernels
 bool conv_wino_supported(const IgemmArgs& a);
 int conv_wino_stats_split(int Hout);
-// ---- exact three-way bf16 split of a pair of fp32 values (conv_wino_s64.hip), plain VALU only: v_pk_*_f32
+// ---- exact three-way bf16 split of a pair of fp32 values (conv_wino_r64.hip, VD_MATH=bf16x6), plain VALU only: v_pk_*_f32
 // and v_dot2c_f32_bf16 do not overlap the bf16 MFMA (tools/mfma_bf16_coissue.hip)
 // first half: p1 = top halves (a bf16 pair), r = x - p1 (exact)
 __device__ __forceinline__ void split_a(float x0, float x1, unsigned& p1, float& r0, float& r1, unsigned sel) {
@@ -140,15 +136,63 @@ __device__ __forceinline__ void split_b(float r0, float r1, unsigned& p2, unsign
         : "v"(r0), "v"(r1), "s"(sel));
 }
 
-// VD_MATH=bf16x3: the DECLARED reduced mode (never the default, never the headline): only the three piece products
-// a1*b1 + a1*b2 + a2*b1 of the six -- operands effectively rounded to 16 significant bits (relative error per product
-// <= ~2^-15; the reference itself samples with TF32, 10 bits, allowed: scripts/video_sample.py:21-22).  Read once per process.
-bool x3_math();
-// fp32-accurate Winograd conv on the bf16 matrix cores (conv_wino_s64.hip); weights: [Cin/16][16][Cout/32][3][64][8] bf16
-bool conv_wino_s64_supported(const IgemmArgs& a);        // wsplit == 2
-int launch_conv_wino_s64(const IgemmArgs& a, hipStream_t s);
-void pack_conv3_wino_s64(const float* oihw, unsigned short* out, int O, int I);
-bool conv_wino_r64_supported(const IgemmArgs& a);        // same weight image, transform + split in registers (conv_wino_r64.hip)
+// ---- arithmetic of the matrix products (VD_MATH, read once per process; every rank of a job must agree: the packed weight
+// image depends on it -- vd_weights_layout_id):
+//   f16x3  (default)  an fp32 operand x is carried as TWO fp16 pieces, x ~ a0 + 2^-12 a1 with a0 = f16(x) (round to nearest
+//                     even) and a1 = f16((x - a0) * 2^12) (x - a0 is exact in fp32): 22 significand bits, relative error
+//                     <= 2^-22 for 2^-14 <= |x| <= 65504, absolute error <= 2^-37 below (tools/mfma_f16_coissue.hip measures
+//                     2^-23 worst over 2^20 values per binade); |x| > 65504 becomes inf and the product NaN -- loudly, never
+//                     silently.  A product a*b is THREE piece products on v_mfma_f32_32x32x16_f16 with fp32 accumulation:
+//                     a0*b0 (exact in fp32: 11 x 11 bits) + a0*b1 + a1*(2^-12 b0); the dropped a1*b1 is <= 2^-22 |ab|.
+//                     Weights are scaled per output channel by a power of two on the host (max |w s| in [2^13, 2^14): every
+//                     piece, 2^-12 b0 included, sits in fp16's normal range down to 2^-15 of the row's largest weight) and the
+//                     epilogue multiplies by 1/s -- exact.  Measured against fp64 the result is as close as the fp32 MFMA's
+//                     (tests/test_gpu_ops.py states the bound); the products of K >= 64 terms are dominated by the rounding of
+//                     the fp32 accumulator, which every mode shares.
+//   bf16x6            the EXACT split: x = x1 + x2 + x3, three bf16 pieces, six piece products (the default of rounds 1-3).
+//   fp32              every product on v_mfma_f32_32x32x2_f32 (gemm_frag.hip, conv_wino.hip).
+enum { MATH_F16X3 = 0, MATH_BF16X6 = 1, MATH_FP32 = 2 };
+int math_mode();
+inline bool f16_math() { return math_mode() == MATH_F16X3; }
+// Split weight images (gemm_split.hip, conv_wino_r64.hip) are followed by a trailer of 2 * N floats, N = output channels of
+// the image: [N] the power-of-two scale s the row was multiplied with (1 in bf16x6), [N] its reciprocal.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// device: the two fp16 pieces of a pair of fp32 values.  p0 = {f16(x0), f16(x1)}; p1 = {f16((x0 - p0.lo) * 4096), f16(...)}:
+// v_fma_mix_f32 reads the fp16 half directly (x - a0 in one instruction), v_fma_mixlo/hi_f16 scale and round in one.  Plain
+// VALU issue cost each (tools/mfma_f16_coissue.hip: they co-issue with the f16 MFMA like v_fma_f32).
+__device__ __forceinline__ unsigned f16_pack(float x0, float x1) {
+    unsigned p;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p) : "v"(x0), "v"(x1));
+    return p;
+}
+__device__ __forceinline__ float f16_rem_lo(unsigned p0, float x0) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p0), "v"(x0));
+    return r;
+}
+__device__ __forceinline__ float f16_rem_hi(unsigned p0, float x1) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p0), "v"(x1));
+    return r;
+}
+__device__ __forceinline__ unsigned f16_pack_scaled(float r0, float r1, float k4096) {
+    unsigned p;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(p) : "v"(r0), "s"(k4096));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(p) : "v"(r1), "s"(k4096));
+    return p;
+}
+__device__ __forceinline__ unsigned f16_pack_scaled_pad(float r0, float r1, float k4096) {   // + the two wait states a VALU write needs before an MFMA reads it
+    unsigned p;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(p) : "v"(r0), "s"(k4096));
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(p) : "v"(r1), "s"(k4096));
+    return p;
+}
+// host packers of the split images (split_pack.hip); sizes in uint16 INCLUDING the trailer
+size_t split_image_u16(size_t n_out, size_t k_total);            // n_out * k_total * 3 + 4 * n_out
+// fp32-accurate Winograd conv on the 16-bit matrix cores (conv_wino_r64.hip); weights: [Cin/16][16][Cout/32][3][64][8] + trailer
+void pack_conv3_wino_split(const float* oihw, unsigned short* out, int O, int I);
+bool conv_wino_r64_supported(const IgemmArgs& a);        // wsplit == 2
 int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s);
 // Upsample (nearest x2) + conv3x3 in its sub-pixel form (conv_wino_r64.hip): four phase kernels per real cout over the
 // LOW-resolution map, one of the four Winograd columns structurally zero and skipped.  IgemmArgs::ups_phase selects it;

@@ -66,7 +66,7 @@ def share_weights(model, state_dict_fn, rank):
         model.load_state_dict(state_dict_fn())
     buf = model.packed_weights()
     if dist.is_initialized() and dist.get_world_size() > 1:
-        # the packed layout depends on per-process environment (VD_MATH, VD_CONV_SPLIT, VD_CONV): every rank must hold
+        # the packed layout depends on per-process environment (VD_MATH): every rank must hold
         # rank 0's layout before it accepts rank 0's bytes
         # (checked collectively, so that EVERY rank raises instead of one rank leaving the others in the broadcast)
         mine = torch.tensor([model.weights_layout_id() & 0x7FFFFFFFFFFFFFFF, buf.numel()], dtype=torch.int64, device=buf.device)
@@ -74,8 +74,8 @@ def share_weights(model, state_dict_fn, rank):
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if not torch.equal(lo.cpu(), hi.cpu()):
-            raise RuntimeError(f"rank {rank}: packed-weight layout differs between ranks (VD_MATH / VD_CONV_SPLIT / "
-                               f"VD_CONV must agree on every rank): mine {mine.tolist()}, job min {lo.tolist()} max {hi.tolist()}")
+            raise RuntimeError(f"rank {rank}: packed-weight layout differs between ranks (VD_MATH "
+                               f"must agree on every rank): mine {mine.tolist()}, job min {lo.tolist()} max {hi.tolist()}")
     broadcast_packed(buf, src=0)
     if rank != 0:
         model.mark_weights_received()     # state_dict() stays rank 0's: other ranks hold only the packed device image

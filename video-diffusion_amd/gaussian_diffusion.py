@@ -97,9 +97,9 @@ class GaussianDiffusion:
         self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
         self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
         self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
-        if model_mean_type != ModelMeanType.EPSILON:
-            raise NotImplementedError("the HIP engine implements the epsilon-prediction parameterisation "
-                                      "(create_gaussian_diffusion default, script_util.py:429-431)")
+        if model_mean_type not in (ModelMeanType.EPSILON, ModelMeanType.START_X):
+            # (create_gaussian_diffusion only ever builds EPSILON or START_X, script_util.py:429-431)
+            raise NotImplementedError("ModelMeanType.PREVIOUS_X: not reachable from the reference's factory, not built")
         # LEARNED / LEARNED_RANGE (learn_sigma=True) construct fine, as in the reference, and fail at the first step the way
         # the reference does: see _refuse_learned
 
@@ -139,6 +139,7 @@ class GaussianDiffusion:
             tm = np.ascontiguousarray(np.array(tmap, dtype=np.int32))
             _lib.check(_lib.lib().vd_set_schedule(model._handle, self.num_timesteps, _lib.ptr(tab), _lib.ptr(tm),
                                                   float(np.float32(scale))))
+            _lib.check(_lib.lib().vd_set_model_mean_type(model._handle, 1 if self.model_mean_type == ModelMeanType.START_X else 0))
             model._bound_schedule = self
         return model
 
@@ -203,6 +204,8 @@ class GaussianDiffusion:
         """p_mean_variance(..., use_gradient_method=True) (+ p_sample's noise add) on the engine: one taped forward, the
         loss gradient, one backward-data pass (gaussian_diffusion.py:264-271,350-364).  Draw order as in the reference:
         the noise of the x_{t-1} sample inside p_mean_variance first, p_sample's own noise second."""
+        if self.model_mean_type != ModelMeanType.EPSILON:
+            raise NotImplementedError("use_gradient_method with predict_xstart=True")
         base = self._bind(model)
         base._require_guidance()
         dev = base.device
@@ -325,6 +328,8 @@ class GaussianDiffusion:
     def _vb_terms_bpd(self, model, x_start, x_t, t, clip_denoised=True, model_kwargs=None, latent_mask=None, _noise=None):
         """gaussian_diffusion.py:750-790 -> {'output': [N] bits/dim, 'pred_xstart'} (+ the two MSEs of
         calc_bpd_loop_subsampled when the noise x_t was drawn with is passed)."""
+        if self.model_mean_type != ModelMeanType.EPSILON:
+            raise NotImplementedError("the NLL path with predict_xstart=True")
         model = self._bind(model)
         dev = model.device
         xs, xt = _f32(x_start, dev), _f32(x_t, dev)

@@ -43,7 +43,10 @@ def create_video_model(T, image_size, num_channels, num_res_blocks, learn_sigma,
     if class_cond:
         raise NotImplementedError("class_cond is not supported by the HIP engine")
     if not do_cond_marg:
-        raise NotImplementedError("do_cond_marg=False (plain UNetVideoModel)")
+        # script_util.py:275-300: ModelClass = UNetVideoModel, which is handed cond_emb_type=... and passes it on to
+        # UNetModel.__init__, which does not take it -- the reference cannot construct this model (tools/gen_golden_r4.py
+        # records the probe); same exception, same message
+        raise TypeError("UNetModel.__init__() got an unexpected keyword argument 'cond_emb_type'")
     attention_ds = tuple(image_size // int(res) for res in attention_resolutions.split(","))
     bucket_params = dict(alpha=rp_alpha, beta=rp_beta, gamma=rp_gamma) if any([rp_alpha, rp_beta, rp_gamma]) else None
     return CondMargVideoModel(
