@@ -724,7 +724,9 @@ def test_window_executor_equals_eager_steps_bit_for_bit():
     """vd_window_begin / vd_window_run: device-resident step index and Philox counter, one captured graph per window
     signature.  Its trajectory must be the eager one: step k of the window == vd_p_sample(noise=NULL, seed, offset =
     k*B*per) applied to the previous result, to the bit (same kernels, same addresses for the activations), for
-    p_sample and DDIM; a second window of the same shape reuses the graph, another shape adds one."""
+    p_sample and DDIM; a second window of the same shape reuses the graph, another shape adds one.  'x_t_minus_1' windows
+    (gaussian_diffusion.py:565-568) re-noise the clean observed frames to t - 1 inside the graph before every step: the eager
+    replay draws the same noise (vd_randn at the second half of the step's Philox range) and calls q_sample itself."""
     from video_diffusion_amd import _lib
     from video_diffusion_amd.executor import WindowExecutor
     cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=6, image_size=32, num_channels=64, num_res_blocks=1,
@@ -737,7 +739,8 @@ def test_window_executor_equals_eager_steps_bit_for_bit():
     seen = []
     for wi, (B, T, n_obs, sampler, obsf) in enumerate([(2, 6, 2, "p_sample", "x_0"), (2, 6, 3, "p_sample", "x_0"),
                                                        (1, 4, 1, "ddim", "x_0"), (2, 6, 2, "p_sample", "x_t"),
-                                                       (3, 6, 2, "p_sample", "x_0"), (2, 6, 2, "p_sample", "x_0")]):
+                                                       (3, 6, 2, "p_sample", "x_0"), (2, 6, 2, "p_sample", "x_0"),
+                                                       (2, 6, 2, "p_sample", "x_t_minus_1"), (2, 6, 3, "ddim", "x_t_minus_1")]):
         c = _rand_window(B, T, 32, n_obs, seed=40 + wi)
         kw = kwargs_of(c, observed_frames=obsf)
         x_init = c["x0"].cuda().clone()
@@ -755,6 +758,12 @@ def test_window_executor_equals_eager_steps_bit_for_bit():
             t = torch.full((B,), ti, dtype=torch.int64, device="cuda")
             nxt = torch.empty_like(cur)
             obs_src = cur if obsf == "x_t" else k["obs_src"]
+            if obsf == "x_t_minus_1":
+                nz = torch.empty_like(cur)
+                _lib.check(L.vd_randn(_lib.ptr(nz), nz.numel(), seed, step * B * per + B * per // 2, _lib.current_stream()))
+                obs_src = torch.empty_like(cur)
+                x0d = c["x0"].cuda().float().contiguous()
+                _lib.check(L.vd_q_sample(model._handle, B, per, _lib.ptr(x0d), _lib.ptr(t - 1), _lib.ptr(nz), _lib.ptr(obs_src), _lib.current_stream()))
             args = (model._handle, B, T, _lib.ptr(cur), _lib.ptr(obs_src), _lib.ptr(k["obs_mask"]), _lib.ptr(k["latent_mask"]),
                     _lib.ptr(k["kinda_marg_mask"]), _lib.ptr(k["frame_indices"]), _lib.ptr(t), k["obs_mode"], 1)
             if sampler == "p_sample":
@@ -763,12 +772,12 @@ def test_window_executor_equals_eager_steps_bit_for_bit():
                 _lib.check(L.vd_ddim_sample(*args, 0.5, None, seed, step * B * per, _lib.ptr(nxt), None, None, _lib.current_stream()))
             cur = nxt
             if step == 2:
-                assert torch.equal(cur, got_mid)
-        assert torch.equal(cur, got) and torch.isfinite(got).all()
+                assert torch.equal(cur, got_mid), (wi, obsf, sampler, float((cur - got_mid).abs().max()))
+        assert torch.equal(cur, got) and torch.isfinite(got).all(), (wi, obsf, sampler, float((cur - got).abs().max()))
         seen.append(ex.graphs - g0)
     # windows 0 and 1 share a signature; window 4 is bigger than anything before it: the workspace is reallocated and the
     # captured graphs (which hold addresses inside it) are dropped; window 5 re-captures window 0's signature
-    assert seen == [1, 1, 2, 3, 1, 2], seen
+    assert seen == [1, 1, 2, 3, 1, 2, 3, 4], seen
     model.check_device_errors()
 
 
@@ -1165,6 +1174,17 @@ def test_cond_emb_variants_and_learn_sigma_match_reference_golden(name):
             assert str(rec[f"{name}_t{t_val}_psample_error"]) == "AssertionError"
             with pytest.raises(AssertionError, match="gaussian_diffusion.py:283"):
                 diff.p_sample(model, x, t, model_kwargs=kwargs_of(c))
+            # the window executor and the C entry points below the Python mirror refuse it too (a 6-channel output
+            # must never reach the 3-channel posterior kernel)
+            from video_diffusion_amd import _lib
+            from video_diffusion_amd.executor import WindowExecutor
+            with pytest.raises(AssertionError, match="gaussian_diffusion.py:283"):
+                WindowExecutor(model, diff).begin(x, kwargs_of(c))
+            k = model._pack_kwargs(x, kwargs_of(c))
+            rc = _lib.lib().vd_p_mean_variance(model._handle, 2, x.shape[1], _lib.ptr(x), _lib.ptr(k["obs_src"]), _lib.ptr(k["obs_mask"]),
+                                               _lib.ptr(k["latent_mask"]), _lib.ptr(k["kinda_marg_mask"]), _lib.ptr(k["frame_indices"]),
+                                               _lib.ptr(t), k["obs_mode"], 1, _lib.ptr(torch.empty_like(x)), None, None, _lib.current_stream())
+            assert rc != 0 and b"learn_sigma" in _lib.lib().vd_last_error()
             continue
         sample, xstart = diff._step(0, model, x, t, True, None, kwargs_of(c), 0.0, c["noise"])
         gain = 1.0 + float(diff.sqrt_recipm1_alphas_cumprod[t_val])

@@ -360,14 +360,10 @@ def test_attention_spatial_peaked_scores():
                                                            (2, 7, 16, 128, 2, False, True, 1), (1, 32, 16, 256, 4, True, False, 1),
                                                            (1, 17, 48, 192, 4, True, True, 0), (1, 3, 16, 64, 4, True, True, 1),
                                                            (8, 16, 256, 384, 4, True, False, 1), (2, 20, 64, 512, 4, False, True, 1)])
-@pytest.mark.parametrize("kernel", ["auto", "mfma"])
-def test_attention_temporal(B, T, HW, C, heads, rpe, mask, allow, kernel, monkeypatch):
-    """unet.py:486-536 + RPE einsums :357-378 + mask rule :511-524.  `auto`: the launcher's choice (4-pixel VALU blocks for
-    grids that would not fill the chip, ragged pixel counts or head dims); `mfma`: the 16-pixel matrix-pipe kernel forced."""
-    if kernel == "mfma":
-        if HW % 16 or (C // heads) % 16 or C // heads > 128:
-            pytest.skip("shape not served by the matrix-pipe kernel")
-        monkeypatch.setenv("VD_ATTN_T", "mfma")
+def test_attention_temporal(B, T, HW, C, heads, rpe, mask, allow):
+    """unet.py:486-536 + RPE einsums :357-378 + mask rule :511-524.  The launcher picks the kernel from the per-item shape
+    alone: the 16-pixel matrix-pipe kernel where pixels % 16 == 0 and head dim % 16 == 0, 4-pixel VALU blocks otherwise; the
+    last assert below holds it to that (a clip alone == the same clip inside a batch, bit for bit)."""
     qkv = rnd(B, T, HW, 3 * C) * 1.5
     Rk, Rq, Rv = (rnd(B, T, T, C, seed=s) for s in (1, 2, 3))
     m = None
@@ -404,6 +400,12 @@ def test_attention_temporal(B, T, HW, C, heads, rpe, mask, allow, kernel, monkey
         o = o + torch.einsum("bdhts,btshf->bdhtf", a, rv)
     ref = o.permute(0, 3, 1, 2, 4).reshape(B, T, HW, C)
     close(out.cpu(), ref, **TOL)
+    if B > 1:                                                        # the last batch item on its own: the same bits
+        one = torch.empty(1, T, HW, C, device="cuda")
+        b1 = [bufs[0][B - 1:].contiguous()] + [None if r is None else r[B - 1:].contiguous() for r in bufs[1:]]
+        _lib.check(_lib.lib().vd_op_attn_temporal(*[_lib.ptr(b) for b in b1], 1, T, HW, C, heads, allow, _lib.ptr(one), _lib.current_stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(one[0], out[B - 1])
 
 
 @pytest.mark.parametrize("N,H,C", [(2, 32, 32), (3, 16, 128), (1, 20, 64), (2, 4, 32)])
@@ -496,13 +498,13 @@ def pack_lin_split(w):
     return out
 
 
-# Error against an fp64 product, relative to the fp32-MFMA kernel's on the same inputs (both kernels accumulate in fp32).
-# bf16x6 multiplies exact operands: it must not be further away (1.5x covers the different association).  f16x3 carries
-# operands to 22 bits and drops a1*b1: its mean error stays at the fp32 kernel's (the accumulator's rounding dominates),
-# its worst element may be up to 2.5x further where K is short (few roundings to hide behind); measured ratios:
-# profiles/r04_split_accuracy.json.
+# Error against an fp64 product, relative to the fp32-MFMA kernel's on the same inputs (all kernels accumulate in fp32): the claim
+# the bench line and INTEGRATION.md make for the default arithmetic is exactly this bound.  bf16x6 multiplies exact operands,
+# f16x3 carries them to 22 bits and drops a1*b1; measured on MI355X (profiles/r04_split_accuracy.json, K = 32 .. 4608, operand
+# magnitudes 1e-3 .. 100) BOTH are at least as close to fp64 as the fp32 MFMA: f16x3 max <= 1.06x, mean <= 1.02x; bf16x6 max <=
+# 1.09x, mean <= 0.88x (the rounding of the fp32 accumulator dominates, and a 16-deep MFMA rounds K / 16 times, not K / 2).
 def err_bounds():
-    return (1.5, 1.5) if math_mode() != "f16x3" else (2.5, 1.5)
+    return (1.5, 1.5) if math_mode() != "f16x3" else (1.5, 1.25)
 
 
 def check_vs_fp32_kernel(e_split, e_fp32):
@@ -729,8 +731,14 @@ def test_every_arithmetic_mode_end_to_end(mode):
     assert rep["mode"] == mode and mode in rep["version"]
     for net in ("eps_tiny", "psample_tiny", "eps_full64"):
         assert rep[net]["outside_tol"] == 0, (net, rep[net])
-    fmax, fmean = (2.5, 1.5) if mode == "f16x3" else (1.5, 1.5)
+    fmax, fmean = (1.5, 1.25) if mode == "f16x3" else (1.5, 1.5)
     for op in ("linear", "conv"):
         k = rep[op]["fp32_kernel"]
         assert rep[op]["max_err"] <= fmax * k["max_err"] + 1e-7 and rep[op]["mean_err"] <= fmean * k["mean_err"] + 1e-8, rep[op]
-        assert abs(rep[op]["signed_mean_err"]) <= 0.05 * rep[op]["mean_err"] + 1e-9, ("systematic bias", rep[op])
+        # Signed mean error.  The operand split rounds to nearest in both modes (rounds 1-3 truncated in the conv kernel: a bias of the
+        # sign of a*b).  What is left is a small NEGATIVE offset of the 16-bit MFMA's own fp32 accumulation -- the same in f16x3 and
+        # bf16x6, absent from the fp32 MFMA, growing with K: -2 .. -6 % of the mean |error| at these sizes, -31 % at K = 4608
+        # (profiles/r04_split_accuracy.json) -- i.e. 1e-8 .. 1e-7 of the output's RMS.  Bounded here so that a regression of the
+        # split (a truncating piece would show +-30 % at K = 512) cannot hide behind it.
+        assert abs(rep[op]["signed_mean_err"]) <= 0.2 * rep[op]["mean_err"] + 1e-9, ("systematic bias", rep[op])
+        assert abs(k["signed_mean_err"]) <= 0.05 * k["mean_err"] + 1e-9, ("fp32 kernel bias", k)

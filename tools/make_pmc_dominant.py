@@ -2,7 +2,9 @@
 """profiles/pmc_dominant.json from a tools/profile_bench.sh summary (gpurun_out/prof_<tag>/summary.json): HBM bytes per
 launch of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE / WRITE_SIZE in KiB; gfx950:
 FETCH_SIZE x2 for wide coalesced reads), plus the MFMA-busy and LDS figures of the same passes.
-  python tools/make_pmc_dominant.py gpurun_out/prof_r01m/summary.json conv3x3_wino_s64_kernel r01m"""
+  python tools/make_pmc_dominant.py gpurun_out/prof_r04/summary.json conv3x3_wino_r64_kernel r04
+Also the proof that the timed kernel executes all of the work: SQ_INSTS_MFMA per launch must equal the algorithmic FLOPs of the
+launch x piece products / 2.25 (Winograd) / 32768 (FLOPs of one 32x32x16 MFMA) -- asserted, and stored for bench.py to print."""
 import hashlib
 import json
 import os
@@ -20,8 +22,14 @@ n = tot["dispatches"]
 stats = [v for k, v in d["stats"].items() if kernel in k]
 fetch, write = tot["FETCH_SIZE"] * 1024 / n, tot["WRITE_SIZE"] * 1024 / n
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KSRC = {"conv3x3_wino_r64_kernel": ["video-diffusion_amd/csrc/conv_wino_r64.hip"],
-        "conv3x3_wino_s64_kernel": ["video-diffusion_amd/csrc/conv_wino_s64.hip"]}.get(kernel, [])
+KSRC = {"conv3x3_wino_r64_kernel": ["video-diffusion_amd/csrc/conv_wino_r64.hip", "video-diffusion_amd/csrc/vd_common.h"]}.get(kernel, [])
+# the un-profiled bench line of the same box and command (tools/profile_bench.sh): algorithmic FLOPs per launch, arithmetic mode
+bench = json.load(open(os.path.join(os.path.dirname(summary), "bench.json")))
+assert bench["roofline"]["kernel"] == kernel, (bench["roofline"]["kernel"], kernel)
+pieces = bench["roofline"].get("piece_products", 6)
+mfma_expected = bench["roofline"]["alg_gflop_per_launch"] * 1e9 * pieces / 2.25 / 32768
+mfma_measured = tot["SQ_INSTS_MFMA"] / n
+assert abs(mfma_measured / mfma_expected - 1) < 1e-4, f"SQ_INSTS_MFMA per launch {mfma_measured} != expected {mfma_expected}: work skipped or duplicated"
 out = {
     "kernel": kernel,
     # bench.py withholds `traffic` when these no longer match the tree (a kernel edited after the PMC passes)
@@ -38,6 +46,10 @@ out = {
     "avg_launch_us_rocprof": sum(s["total_ns"] for s in stats) / max(sum(s["calls"] for s in stats), 1) / 1e3,
     "lds_bank_conflict_frac": tot["SQ_LDS_BANK_CONFLICT"] / tot["SQ_LDS_IDX_ACTIVE"] if tot.get("SQ_LDS_IDX_ACTIVE") else None,
     "valu_insts_per_mfma": tot["SQ_INSTS_VALU"] / tot["SQ_INSTS_MFMA"] if tot.get("SQ_INSTS_MFMA") else None,
+    "mfma_insts_per_launch": mfma_measured,
+    "mfma_insts_expected_per_launch": mfma_expected,
+    "mfma_insts_ratio": mfma_measured / mfma_expected,
+    "lib_source_sha": bench.get("lib_source_sha"),
 }
 json.dump(out, open("profiles/pmc_dominant.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -4,7 +4,9 @@
 #   2) PMC passes (separate runs, counters only + kernel trace): FETCH_SIZE, WRITE_SIZE, MFMA busy / cycles
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=$1; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
-CMD="python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --no-fp32-ref --no-dropin"
+CMD="python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --no-fp32-ref --no-dropin --no-full-window"
+# the same command un-profiled, with the live roofline: algorithmic FLOPs per launch for tools/make_pmc_dominant.py's MFMA check
+timeout -k 10 300 python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fp32-ref --no-dropin --no-full-window > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM TCC_HIT_sum TCC_MISS_sum"; do

@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "da92a0ef7df7348d"; }
+extern "C" const char* vd_source_sha(void) { return "5c1af29f18c1c358"; }

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(AttnSpatialArgs a) {
 // The same attention on the bf16 matrix cores at fp32 accuracy (default; VD_MATH=fp32 keeps the kernel above).
 // q*scale, k, v and the softmax weights p are each split EXACTLY into three bf16 pieces (vd_common.h: split_a/split_b)
 // and every product runs as six piece products of v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the arithmetic of
-// gemm_split.hip / conv_wino_s64.hip: 6 x 32 cycles per 16 k instead of 8 x 64.
+// VD_MATH=bf16x6 in gemm_split.hip / conv_wino_r64.hip: 6 x 32 cycles per 16 k instead of 8 x 64 (this kernel keeps the exact
+// split in every mode but fp32: 0.7 ms of a 23 ms step).
 //   S^T = K . Q^T : A = K tile (three bf16 planes in LDS, rows of FK bf16 + 16 bytes: conflict-free ds_read_b128),
 //                   B = Q^T pieces, split once per wave and kept in registers
 //   O^T += V^T . P^T : B = P^T, the S^T accumulator registers split in place (k order of an accumulator tile:
@@ -343,7 +344,7 @@ int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s) {
     VD_REQUIRE(a.C % a.heads == 0, "channels divisible by heads");
     const int F = a.C / a.heads;
     dim3 grid((a.L + 127) / 128, a.heads, a.nfr);
-    static const bool fp32_mfma = [] { const char* e = getenv("VD_MATH"); return e && std::string(e) == "fp32"; }();
+    const bool fp32_mfma = math_mode() == MATH_FP32;
     switch (F) {
 #define VD_CASE(FV) case FV: if (fp32_mfma) hipLaunchKernelGGL((attn_spatial_kernel<FV>), grid, dim3(256), 0, s, a); \
                              else hipLaunchKernelGGL((attn_spatial_split_kernel<FV>), grid, dim3(256), 0, s, a); break;

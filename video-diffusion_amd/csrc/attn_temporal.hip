@@ -502,11 +502,10 @@ int launch_attn_temporal(const AttnTemporalArgs& a, hipStream_t s) {
     VD_REQUIRE(a.C % a.heads == 0 && (a.C / a.heads) % 8 == 0, "head dim multiple of 8");
     VD_REQUIRE((a.Rk == nullptr) == (a.Rq == nullptr) && (a.Rk == nullptr) == (a.Rv == nullptr), "all or no RPE terms");
     const int F = a.C / a.heads;
-    static const bool valu_only = [] { const char* e = getenv("VD_ATTN_T"); return e && std::string(e) == "valu"; }();   // A/B switch
-    // 16-pixel blocks: a B = 1 shard has 64 of them at 16x16 and the VALU kernel's 4-pixel blocks fill the chip better
-    // (same-box A/B, B = 1 x T = 16 step: 5.87 ms against 5.95 with this kernel)
-    const bool fills = (long)(a.HW / 16) * a.heads * a.B >= 128 || (getenv("VD_ATTN_T") && std::string(getenv("VD_ATTN_T")) == "mfma");
-    if (!valu_only && fills && a.HW % 16 == 0 && F % 16 == 0 && F <= 128) {           // the matrix-pipe kernel: 16-pixel blocks, 16-feature k steps, one feature tile per wave
+    // The kernel is chosen by the per-item shape alone (pixels, heads, head dim, T), never by the batch: a clip gives the same
+    // bits whether it is sampled alone (a strong-scaling shard) or inside a batch.  (At B = 1 the 4-pixel blocks of the
+    // VALU kernel fill the chip slightly better -- 5.87 against 5.95 ms per step -- which is not worth a batch-dependent result.)
+    if (a.HW % 16 == 0 && F % 16 == 0 && F <= 128) {           // the matrix-pipe kernel: 16-pixel blocks, 16-feature k steps, one feature tile per wave
         const bool rpe = a.Rk != nullptr;
         if (a.T == 16 && F == 96) return rpe ? launch_tm<1, 6, true, true>(a, s) : launch_tm<1, 6, false, true>(a, s);     // the default models' two shapes
         if (a.T == 16 && F == 128) return rpe ? launch_tm<1, 8, true, true>(a, s) : launch_tm<1, 8, false, true>(a, s);

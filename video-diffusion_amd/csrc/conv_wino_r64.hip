@@ -221,13 +221,48 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
         af[buf][1][pr] = p2;
         af[buf][2][pr] = p3;
     };
-    // f16x3: a0 of channels 2pr, 2pr+1 | a1 = f16((x - a0) * 4096) of the same pair (vd_common.h)
+    // f16x3: a0 of channels 2pr, 2pr+1 (vd_common.h); the prologue's form
     auto t_f16_a0 = [&](int buf, int pr) { af[buf][0][pr] = f16_pack(tv[buf][2 * pr], tv[buf][2 * pr + 1]); };
-    // (pad: the LAST pair is written one slot ahead of the MFMA that reads the piece; a VALU write needs two wait states before an
-    // MFMA reads it as A / B, and hipcc pads nothing behind inline asm)
-    auto t_f16_a1 = [&](int buf, int pr, bool pad) {
-        const float r0 = f16_rem_lo(af[buf][0][pr], tv[buf][2 * pr]), r1 = f16_rem_hi(af[buf][0][pr], tv[buf][2 * pr + 1]);
-        af[buf][1][pr] = pad ? f16_pack_scaled_pad(r0, r1, 4096.f) : f16_pack_scaled(r0, r1, 4096.f);
+    // The slot bodies of the f16x3 loop are ONE asm statement each.  Single-instruction statements would let hipcc interleave them,
+    // but it pads every asm output that the next instruction reads with an s_nop (it cannot know the producer is a plain VALU
+    // instruction), and with one wave per SIMD an s_nop is an issue slot like any other: the first f16x3 loop of round 4 carried
+    // 9 of them per position next to 36 vector instructions, and its six scalar adds for the weight offsets on top.
+    // Slot k < 4: the a1 piece of channel pair k of THIS position's fragment -- r = x - a0 (v_fma_mix_f32 reads the fp16 half),
+    // r * 2^12, round -- and channels 2k, 2k+1 of the NEXT position's V (column combination X -/+ Y).  `early`: the piece is read
+    // by the MFMA of the next slot, and a VALU write needs two wait states before an MFMA reads it as A / B: the combination
+    // goes behind the conversion.
+#define VD_R64_A1 "v_fma_mix_f32 %3, %5, -1.0, %6 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %4, %5, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+                  "v_ldexp_f32 %3, %3, 12\n\tv_ldexp_f32 %4, %4, 12\n\t"
+#define VD_R64_A1_OPS : "=&v"(af[cur][1][k]), "=&v"(tv[nxt][2 * k]), "=&v"(tv[nxt][2 * k + 1]), "=&v"(r0), "=&v"(r1) \
+                      : "v"(af[cur][0][k]), "v"(tv[cur][2 * k]), "v"(tv[cur][2 * k + 1]), "v"(t[cx][2 * k]), "v"(t[cy][2 * k]), "v"(t[cx][2 * k + 1]), "v"(t[cy][2 * k + 1])
+    auto f16_slot_a = [&](int cur, int nxt, int k, int jn, bool early) {
+        const int cx = jn == 0 ? 0 : jn == 2 ? 2 : 1, cy = jn == 0 ? 2 : jn == 1 ? 2 : jn == 2 ? 1 : 3;      // V[jn] = t[cx] - t[cy] (jn = 1: +)
+        float r0, r1;
+        if (jn == 1) {
+            if (early) asm(VD_R64_A1 "v_cvt_pk_f16_f32 %0, %3, %4\n\tv_add_f32 %1, %8, %9\n\tv_add_f32 %2, %10, %11" VD_R64_A1_OPS);
+            else asm(VD_R64_A1 "v_add_f32 %1, %8, %9\n\tv_add_f32 %2, %10, %11\n\tv_cvt_pk_f16_f32 %0, %3, %4" VD_R64_A1_OPS);
+        } else {
+            if (early) asm(VD_R64_A1 "v_cvt_pk_f16_f32 %0, %3, %4\n\tv_sub_f32 %1, %8, %9\n\tv_sub_f32 %2, %10, %11" VD_R64_A1_OPS);
+            else asm(VD_R64_A1 "v_sub_f32 %1, %8, %9\n\tv_sub_f32 %2, %10, %11\n\tv_cvt_pk_f16_f32 %0, %3, %4" VD_R64_A1_OPS);
+        }
+    };
+#undef VD_R64_A1
+#undef VD_R64_A1_OPS
+    // Slot 4: the a0 piece of the next position's fragment (four conversions) + channels 0, 1 of the next group's t column c
+    auto f16_slot_b = [&](int nxt, int c) {
+        asm("v_cvt_pk_f16_f32 %0, %6, %7\n\tv_cvt_pk_f16_f32 %1, %8, %9\n\tv_cvt_pk_f16_f32 %2, %10, %11\n\tv_cvt_pk_f16_f32 %3, %12, %13\n\t"
+            "v_fma_f32 %4, %14, %15, %16\n\tv_fma_f32 %5, %14, %17, %18"
+            : "=&v"(af[nxt][0][0]), "=&v"(af[nxt][0][1]), "=&v"(af[nxt][0][2]), "=&v"(af[nxt][0][3]), "=&v"(t[c][0]), "=&v"(t[c][1])
+            : "v"(tv[nxt][0]), "v"(tv[nxt][1]), "v"(tv[nxt][2]), "v"(tv[nxt][3]), "v"(tv[nxt][4]), "v"(tv[nxt][5]), "v"(tv[nxt][6]), "v"(tv[nxt][7]),
+              "v"(tsg), "v"(sts[0][0]), "v"(stx[0][0]), "v"(sts[0][1]), "v"(stx[0][1]));
+    };
+    // Slot 5: channels 2 .. 7 of that column
+    auto f16_slot_c = [&](int c) {
+        asm("v_fma_f32 %0, %6, %7, %8\n\tv_fma_f32 %1, %6, %9, %10\n\tv_fma_f32 %2, %6, %11, %12\n\tv_fma_f32 %3, %6, %13, %14\n\t"
+            "v_fma_f32 %4, %6, %15, %16\n\tv_fma_f32 %5, %6, %17, %18"
+            : "=&v"(t[c][2]), "=&v"(t[c][3]), "=&v"(t[c][4]), "=&v"(t[c][5]), "=&v"(t[c][6]), "=&v"(t[c][7])
+            : "v"(tsg), "v"(sts[0][2]), "v"(stx[0][2]), "v"(sts[0][3]), "v"(stx[0][3]), "v"(sts[1][0]), "v"(stx[1][0]), "v"(sts[1][1]), "v"(stx[1][1]),
+              "v"(sts[1][2]), "v"(stx[1][2]), "v"(sts[1][3]), "v"(stx[1][3]));
     };
 
     // ---- B fragments: U[chunk][xi = 4*wi + j][cob][piece][lane][8 x 16 bit] = 1 KiB per (chunk, xi, cob, piece)
@@ -236,8 +271,12 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     const int bsb = (wi * 4 * ncoblk + cob0) * 3072 + c_begin * ustride;
     const unsigned blane = lane * 16u;
     u32x4 bfr[4][2][3];
+    // (n, piece) offsets 0 .. 3072 ride in the instruction's 12-bit immediate, the last two behind a second scalar base: two
+    // scalar adds per position instead of six (every instruction of a one-wave-per-SIMD stream is an issue slot)
     auto b_load_one = [&](int chunk, int j, int n, int p) {
-        bfr[j][n][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane, chunk * ustride + bsb + j * bstep + n * 3072 + p * 1024, 0));
+        const int idx = n * 3 + p, so = chunk * ustride + bsb + j * bstep;
+        bfr[j][n][p] = idx < 4 ? __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane + idx * 1024u, so, 0))
+                               : __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane + (idx - 4) * 1024u, so + 4096, 0));
     };
     auto b_load = [&](int chunk, int j, int n) {
 #pragma unroll
@@ -347,17 +386,9 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                     else acc[m][j][n] = r64_mfma<false>(af[cur][PA6[q]], bfr[j][n][PB6[q]], acc[m][j][n]);
                     if (VD_R64_ABL & 2) {}
                     else if constexpr (F16) {
-                        if (k < 4) {
-                            t_f16_a1(cur, k, k == 3);
-                            t_comb1(nxt, jn, 2 * k); t_comb1(nxt, jn, 2 * k + 1);
-                        } else if (k == 4) {
-#pragma unroll
-                            for (int pr = 0; pr < 4; ++pr) t_f16_a0(nxt, pr);
-                            t_fma1(ORDa[li], 0); t_fma1(ORDa[li], 1);
-                        } else {
-#pragma unroll
-                            for (int e = 2; e < 8; ++e) t_fma1(ORDa[li], e);
-                        }
+                        if (k < 4) f16_slot_a(cur, nxt, k, jn, k == 3);
+                        else if (k == 4) f16_slot_b(nxt, ORDa[li]);
+                        else f16_slot_c(ORDa[li]);
                     } else {
                         if (k == 0) t_comb(nxt, jn, 0);
                         else if (k == 3) t_comb(nxt, jn, 1);

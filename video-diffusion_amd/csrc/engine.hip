@@ -88,10 +88,16 @@ constexpr int STEM_KPAD = 64;          // im2col width of the 5-channel 3x3 stem
 
 struct Arena {
     char* base = nullptr;
-    size_t cap = 0, used = 0, peak = 0;
-    bool dry = false;
+    size_t cap = 0, used = 0, peak = 0;     // cap: bytes this arena may hand out (the workspace up to its tail; 0 = unchecked)
+    bool dry = false, overflow = false;
     template <class Tp> Tp* get(size_t n) {
         size_t bytes = (n * sizeof(Tp) + 255) & ~(size_t)255;
+        if (!dry && cap && used + bytes > cap) {
+            // the dry run that sized the workspace did not see this request: never write past the arena (the tail holds t_model
+            // and the eps scratch).  The request is served from the base -- results are garbage -- and the forward fails loudly.
+            overflow = true;
+            return reinterpret_cast<Tp*>(base);
+        }
         char* p = (dry ? reinterpret_cast<char*>(0x1000) : base) + used;     // dry run: distinct, never dereferenced (the backward keys gradients by tensor address)
         used += bytes;
         peak = std::max(peak, used);
@@ -265,6 +271,7 @@ struct vd_engine {
     unsigned long long win_gen = 0;                      // bumped by every vd_window_begin: a run must name the window it continues
     long long win_left = 0;                              // steps the current window still has (t + 1)
     long long* d_win_t = nullptr; int win_t_cap = 0;     // [B] current respaced index of the window
+    float* d_win_xtm1 = nullptr; size_t win_xtm1_cap = 0; // 'x_t_minus_1' windows: the observed frames re-noised to t - 1, redrawn every step
     unsigned long long* d_win_rng = nullptr;             // {seed, Philox offset}
 
     ~vd_engine() {
@@ -277,6 +284,7 @@ struct vd_engine {
         if (d_part) (void)hipFree(d_part);
         if (d_win_t) (void)hipFree(d_win_t);
         if (d_win_rng) (void)hipFree(d_win_rng);
+        if (d_win_xtm1) (void)hipFree(d_win_xtm1);
         for (auto& g : win_graphs) free_graph(g);
     }
 
@@ -652,6 +660,16 @@ static double* stats_table(Arena& ar, int N, int Hout, int Cout, int* split) {
     return ar.get<double>((size_t)N * *split * Cout * 2);
 }
 
+// split-K scratch of a small-grid Winograd conv (conv_wino_r64.hip).  The dry run that sizes the workspace takes the largest
+// request over every batch 1..N: the prefix-cache forward runs the same layer on a compact batch (fewer frames = a smaller
+// grid = possibly MORE slices), and the arena must hold that too
+static size_t ksplit_scratch(const Arena& ar, int N, int H, int cin, int cout) {
+    if (!ar.dry) return conv_wino_r64_ksplit_floats(N, H, cin, cout);
+    size_t m = 0;
+    for (int n = 1; n <= N; ++n) m = std::max(m, conv_wino_r64_ksplit_floats(n, H, cin, cout));
+    return m;
+}
+
 static IgemmArgs conv_args(Tens x0, const Tens* x1, int N, int ksz, int stride, int ups) {
     IgemmArgs g{};
     g.src0 = x0.p; g.C0 = x0.C; g.Cin = x0.C;
@@ -700,7 +718,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     {   // SiLU(GroupNorm(concat(x0, x1))) once, into a transient; the conv then reads plain activations (norm.hip)
         const size_t mk = ar.mark();
         float* a1 = ar.get<float>((size_t)N * HW * cin);
-        const size_t ksf = conv_wino_r64_ksplit_floats(N, H, cin, r.cout);      // small grids: split-K scratch (conv_wino_r64.hip)
+        const size_t ksf = ksplit_scratch(ar, N, H, cin, r.cout);      // small grids: split-K scratch (conv_wino_r64.hip)
         float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
         if (fold1 && (rc = gn_act(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, 1, a1, st, ar))) return rc;
         if (!ar.dry) {
@@ -737,7 +755,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     {
         const size_t mk = ar.mark();
         float* a2 = ar.get<float>((size_t)N * HW * r.cout);
-        const size_t ksf = conv_wino_r64_ksplit_floats(N, H, r.cout, r.cout);
+        const size_t ksf = ksplit_scratch(ar, N, H, r.cout, r.cout);
         float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
         if (fold && (rc = gn_act(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, 1, a2, st, ar))) return rc;
         if (!ar.dry) {
@@ -889,10 +907,12 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
     Tens h{x8, STEM_KPAD, S};
     int Nrun = Npre;                                                 // batch of the block being run: Npre in the prefix, N behind it
     const float* film_full = film;
-    if (pp) {                                                        // FiLM rows of the listed frames, compactly
-        float* fc = ar.get<float>((size_t)std::max(Npre, 1) * film_total);
-        if ((rc = launch_gather_rows(film_full, pp->list, Npre, film_total, fc, st))) return rc;
-        film = fc;
+    if (pp || ar.dry) {                                              // FiLM rows of the listed frames, compactly (the dry run sizes it for any list)
+        float* fc = ar.get<float>((size_t)std::max(pp ? Npre : N, 1) * film_total);
+        if (pp) {
+            if ((rc = launch_gather_rows(film_full, pp->list, Npre, film_total, fc, st))) return rc;
+            film = fc;
+        }
     }
     auto run = [&](const std::vector<Layer>& blk, Tens in0, const Tens* in1, Tens* outp) -> int {
         const int N = Nrun;
@@ -922,7 +942,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
                 else if (phase) { nxt.split = conv_wino_ups_stats_split(cur.H); nxt.part = ar.get<double>((size_t)N * nxt.split * c.c * 2); }
                 else if (stride == 2) conv_split_stats_table(ar, g, c.c, &nxt);       // Downsample on the split GEMM
                 const size_t mk = ar.mark();
-                const size_t ksf = stride == 1 && !phase ? conv_wino_r64_ksplit_floats(N, g.Ho, cur.C, c.c) : 0;
+                const size_t ksf = stride == 1 && !phase ? ksplit_scratch(ar, N, g.Ho, cur.C, c.c) : 0;
                 float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
                 ar.release(mk);                                                       // a transient: the launches are stream-ordered
                 if (!ar.dry) {
@@ -1000,6 +1020,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
           rc = launch_out_conv(h.p, A, Bf, W(p_outw), W(p_outb), N, S, S, h.C, cfg.learn_sigma ? 6 : 3, in.eps, st); }
         if (rc) return rc;
     }
+    VD_REQUIRE(!ar.overflow, "workspace overflow: the forward asked for more than the dry run measured (this step's output is invalid)");
     return 0;
 }
 
@@ -1066,7 +1087,7 @@ int vd_engine::bwd_conv3(Tens dy, int N, int pw, int cout_bwd, const float* resi
     const Param& p = params[pw];
     IgemmArgs g = conv_args(dy, nullptr, N, 3, 1, 0);
     const size_t mk = ar.mark();
-    const size_t ksf = p.kind_bwd == PK_CONV3W ? conv_wino_r64_ksplit_floats(N, dy.H, dy.C, cout_bwd) : 0;
+    const size_t ksf = p.kind_bwd == PK_CONV3W ? ksplit_scratch(ar, N, dy.H, dy.C, cout_bwd) : 0;
     g.ksplit_ws = ksf ? ar.get<float>(ksf) : nullptr; g.ksplit_ws_floats = ksf;
     ar.release(mk);
     if (ar.dry) return 0;
@@ -1498,7 +1519,7 @@ int vd_unet_forward(vd_engine* e, int B, int T, const float* x, const float* obs
     VD_REQUIRE(x && obs_src && obs && lat && km && fidx && t_model && eps, "null tensor");
     VD_REQUIRE(obs_mode >= 0 && obs_mode <= 2, "observed_frames must be x_0 / x_t / x_t_minus_1");
     if ((rc = e->ensure_ws(B, T))) return rc;
-    Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
+    Arena ar; ar.base = e->ws; ar.cap = e->ws_tail;                   // the activations end where t_model and the eps scratch begin
     FwdIn fi{B, T, x, obs_src, obs, lat, km, t_model, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
     return e->forward(fi, static_cast<hipStream_t>(stream), ar);
 }
@@ -1536,7 +1557,7 @@ static int step_launches(vd_engine* e, int mode, int B, int T, const float* x, c
     float* eps = eps_out ? eps_out : reinterpret_cast<float*>(e->ws + e->ws_tail + (((size_t)B * sizeof(float) + 255) & ~(size_t)255));
     hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(t), e->d_tmap,
                        e->rescale, B, e->num_timesteps, tm, e->d_err);
-    Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
+    Arena ar; ar.base = e->ws; ar.cap = e->ws_tail;                   // the activations end where t_model and the eps scratch begin
     FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
     if ((rc = e->forward(fi, st, ar, pp))) return rc;
     PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
@@ -1635,8 +1656,7 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     if (rc) return rc;
     VD_REQUIRE(e->d_tab, "vd_set_schedule not called");
     VD_REQUIRE(x && obs_src && obs && lat && km && fidx, "null tensor");
-    VD_REQUIRE(obs_mode == 0 || obs_mode == 1, "the window executor keeps observed frames fixed (x_0) or reads them from x (x_t); "
-               "x_t_minus_1 is re-drawn by the host every step");
+    VD_REQUIRE(obs_mode >= 0 && obs_mode <= 2, "observed_frames must be x_0 / x_t / x_t_minus_1");
     VD_REQUIRE(sampler == 0 || sampler == 1, "sampler: 0 p_sample, 1 ddim_sample");
     VD_REQUIRE(t_start >= 0 && t_start < e->num_timesteps, "t_start outside the schedule");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1650,6 +1670,19 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
         e->win_t_cap = B;
     }
     if (!e->d_win_rng) VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_win_rng), 2 * sizeof(unsigned long long)));
+    const size_t per_w = (size_t)T * 3 * e->cfg.image_size * e->cfg.image_size;
+    if (obs_mode == 2 && (size_t)B * per_w > e->win_xtm1_cap) {
+        if (e->d_win_xtm1) {                                    // captured graphs hold the old buffer's address
+            e->drop_window_graphs();
+            VD_HIP(hipFree(e->d_win_xtm1));
+        }
+        e->d_win_xtm1 = nullptr; e->win_xtm1_cap = 0;
+        VD_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_win_xtm1), (size_t)B * per_w * sizeof(float)));
+        e->win_xtm1_cap = (size_t)B * per_w;
+    }
+    // 'x_t_minus_1' (gaussian_diffusion.py:565-568): obs_src holds the CLEAN observed frames x0; every step first draws
+    // x_t_minus_1 = q_sample(x0, t - 1) into the engine's buffer (the second half of the step's Philox range), the network reads that
+    const float* net_obs_src = obs_mode == 2 ? e->d_win_xtm1 : obs_src;
     hipLaunchKernelGGL(win_set_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->d_win_t, e->d_win_rng, B, t_start, seed, offset);
     VD_HIP(hipGetLastError());
     vd_engine::WinKey key;
@@ -1680,7 +1713,7 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
         float* eps = reinterpret_cast<float*>(e->ws + e->ws_tail + (((size_t)B * sizeof(float) + 255) & ~(size_t)255));
         hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(e->d_win_t),
                            e->d_tmap, e->rescale, B, e->num_timesteps, tm, e->d_err);
-        Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
+        Arena ar; ar.base = e->ws; ar.cap = e->ws_tail;                   // the activations end where t_model and the eps scratch begin
         FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
         PrefixPlan bp; bp.n = g.n_inv; bp.list = g.d_lists + (N - g.n_inv); bp.build_only = true; bp.store = g.store;
         const bool prof = g_prof.on;
@@ -1701,8 +1734,10 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
         float* eps = reinterpret_cast<float*>(e->ws + e->ws_tail + (((size_t)B * sizeof(float) + 255) & ~(size_t)255));
         hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(e->d_win_t),
                            e->d_tmap, e->rescale, B, e->num_timesteps, tm, e->d_err);
-        Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
-        FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
+        Arena ar; ar.base = e->ws; ar.cap = e->ws_tail;                   // the activations end where t_model and the eps scratch begin
+        if (obs_mode == 2 && (rc = launch_q_sample_prev(obs_src, reinterpret_cast<const int64_t*>(e->d_win_t), e->d_tab, e->num_timesteps, B, (long)per_w,
+                                                        e->d_win_rng, (unsigned long long)B * per_w / 2, e->d_win_xtm1, st))) return rc;
+        FwdIn fi{B, T, x, net_obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
         if ((rc = e->forward(fi, st, ar))) return rc;
         VD_HIP(hipStreamSynchronize(st));
     }
@@ -1727,8 +1762,10 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
         plan.n = N - n_inv; plan.list = wg.d_lists; plan.store = wg.store;
     }
     VD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    rc = step_launches(e, sampler, B, T, x, obs_src, obs, lat, km, fidx, e->d_win_t, obs_mode, clip, eta, nullptr, 0, 0,
-                       e->d_win_rng, x, nullptr, nullptr, nullptr, st, n_inv ? &plan : nullptr);
+    rc = obs_mode == 2 ? launch_q_sample_prev(obs_src, reinterpret_cast<const int64_t*>(e->d_win_t), e->d_tab, e->num_timesteps, B, (long)per,
+                                              e->d_win_rng, (unsigned long long)B * per / 2, e->d_win_xtm1, st) : 0;
+    if (!rc) rc = step_launches(e, sampler, B, T, x, net_obs_src, obs, lat, km, fidx, e->d_win_t, obs_mode, clip, eta, nullptr, 0, 0,
+                                e->d_win_rng, x, nullptr, nullptr, nullptr, st, n_inv ? &plan : nullptr);
     if (!rc) {
         hipLaunchKernelGGL(win_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->d_win_t, e->d_win_rng, B,
                            (unsigned long long)B * per);
@@ -1746,6 +1783,18 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     hipGraphExec_t exec = nullptr;
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { set_error("hipGraphInstantiate"); (void)hipGraphDestroy(graph); drop_store(); return -2; }
     wg.graph = graph; wg.exec = exec;
+    if (wg.store) {
+        // a prefix store holds full-size copies of every tensor before the first attention layer (over 1 GB per block at 128x128,
+        // N = 160): sampling modes whose observed-frame pattern changes from window to window (hierarchy, adaptive, mixed) would
+        // grow device memory without bound.  At most four graphs keep a store; the oldest one goes first.
+        int cnt = 0, oldest = -1;
+        for (size_t i = 0; i < e->win_graphs.size(); ++i) if (e->win_graphs[i].store) { ++cnt; if (oldest < 0) oldest = (int)i; }
+        if (cnt >= 4) {
+            (void)hipDeviceSynchronize();                       // its graph may still be queued on the executor's stream
+            vd_engine::free_graph(e->win_graphs[oldest]);
+            e->win_graphs.erase(e->win_graphs.begin() + oldest);
+        }
+    }
     e->win_graphs.push_back(wg);
     e->win_cur = (int)e->win_graphs.size() - 1;
     return 0;
@@ -1924,7 +1973,7 @@ int vd_guided_step(vd_engine* e, int B, int T, const float* x, const float* obs,
     hipLaunchKernelGGL(map_t_kernel, dim3((B + 63) / 64), dim3(64), 0, st, reinterpret_cast<const int64_t*>(t), e->d_tmap,
                        e->rescale, B, e->num_timesteps, tm, e->d_err);
     hipLaunchKernelGGL(guided_masks_kernel, dim3((N + 63) / 64), dim3(64), 0, st, obs, lat, N, obs_net, lat_net);
-    Arena ar; ar.base = e->ws; ar.cap = e->ws_cap;
+    Arena ar; ar.base = e->ws; ar.cap = (size_t)(tail - e->ws);       // forward + backward live below the step's own buffers
     Tape tp; e->tape = &tp;
     FwdIn fi{B, T, x, x, obs_net, lat_net, km, tm, reinterpret_cast<const int64_t*>(fidx), 0, eps};
     rc = e->forward(fi, st, ar);

@@ -50,8 +50,8 @@ template <bool F16>
 __device__ __forceinline__ void split3(f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
     if constexpr (F16) {
         p1.x = f16_pack(v.x, v.y); p1.y = f16_pack(v.z, v.w);
-        p2.x = f16_pack_scaled(f16_rem_lo(p1.x, v.x), f16_rem_hi(p1.x, v.y), 4096.f);
-        p2.y = f16_pack_scaled(f16_rem_lo(p1.y, v.z), f16_rem_hi(p1.y, v.w), 4096.f);
+        p2.x = f16_pack_scaled(f16_rem_lo(p1.x, v.x), f16_rem_hi(p1.x, v.y));
+        p2.y = f16_pack_scaled(f16_rem_lo(p1.y, v.z), f16_rem_hi(p1.y, v.w));
         p3 = p2;
     } else {
         const bf16x4 q1 = __builtin_convertvector(v, bf16x4);

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* x0, const fl
         long long tt = t[i / per];
         if (tt < 0) tt += NT;                   // t-1 at t=0 wraps like numpy/torch indexing (gaussian_diffusion.py:565-568)
         if (tt < 0 || tt >= NT) { out[i] = __builtin_nanf(""); continue; }       // IndexError in the reference
-        out[i] = tab[TAB_SQRT_ACP * NT + tt] * x0[i] + tab[TAB_SQRT_1M_ACP * NT + tt] * noise[i];
+        out[i] = fmaf(tab[TAB_SQRT_1M_ACP * NT + tt], noise[i], tab[TAB_SQRT_ACP * NT + tt] * x0[i]);   // (one rounding order for this kernel and q_sample_prev_kernel)
     }
 }
 
@@ -396,6 +396,30 @@ int launch_q_sample(const float* x0, const float* noise, const int64_t* t, const
     const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(q_sample_kernel, dim3(grid), dim3(256), 0, s, x0, noise, t, tab, num_timesteps, (size_t)per,
                        total, out);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// The window executor's `observed_frames = 'x_t_minus_1'` (gaussian_diffusion.py:565-568: x_t_minus_1 = q_sample(x0, t - 1, fresh
+// noise) before every step of p_sample_loop): t and the Philox {seed, offset} are read from device memory, the noise is
+// element i of the stream at offset + draw_offset, index t - 1 = -1 wraps to the last entry like the reference's negative index.
+__global__ __launch_bounds__(256) void q_sample_prev_kernel(const float* x0, const long long* t, const float* tab, int NT, size_t per, size_t total,
+                                                            const unsigned long long* dstate, unsigned long long draw_offset, float* out) {
+    const unsigned long long seed = dstate[0], offset = dstate[1] + draw_offset;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        long long tt = t[i / per] - 1;
+        if (tt < 0) tt += NT;
+        if (tt < 0 || tt >= NT) { out[i] = __builtin_nanf(""); continue; }
+        out[i] = fmaf(tab[TAB_SQRT_1M_ACP * NT + tt], normal_at(seed, offset, i), tab[TAB_SQRT_ACP * NT + tt] * x0[i]);
+    }
+}
+
+int launch_q_sample_prev(const float* x0, const int64_t* t, const float* tab, int num_timesteps, int B, long per, const unsigned long long* dstate,
+                         unsigned long long draw_offset, float* out, hipStream_t s) {
+    const size_t total = (size_t)B * per;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(q_sample_prev_kernel, dim3(grid), dim3(256), 0, s, x0, reinterpret_cast<const long long*>(t), tab, num_timesteps, (size_t)per,
+                       total, dstate, draw_offset, out);
     VD_HIP(hipGetLastError());
     return 0;
 }

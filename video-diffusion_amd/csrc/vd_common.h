@@ -111,29 +111,31 @@ void pack_linear_frag(const float* w, float* out_base, int rows, int K, int n_to
 bool conv_wino_supported(const IgemmArgs& a);
 int conv_wino_stats_split(int Hout);
 // ---- exact three-way bf16 split of a pair of fp32 values (conv_wino_r64.hip, VD_MATH=bf16x6), plain VALU only: v_pk_*_f32
-// and v_dot2c_f32_bf16 do not overlap the bf16 MFMA (tools/mfma_bf16_coissue.hip)
-// first half: p1 = top halves (a bf16 pair), r = x - p1 (exact)
-__device__ __forceinline__ void split_a(float x0, float x1, unsigned& p1, float& r0, float& r1, unsigned sel) {
+// and v_dot2c_f32_bf16 do not overlap the bf16 MFMA (tools/mfma_bf16_coissue.hip).  Every piece is rounded to NEAREST
+// (v_cvt_pk_bf16_f32): rounds 1-3 truncated (v_and_b32 0xffff0000), which gave the three dropped piece products the sign of
+// a*b -- a systematic bias of ~10 % of the mean error (tools/mode_check.py signed_mean_err) -- at the same instruction count.
+// first half: p1 = bf16 pair of (x0, x1), r = x - p1 (exact in fp32)
+__device__ __forceinline__ void split_a(float x0, float x1, unsigned& p1, float& r0, float& r1, unsigned) {
     float h0, h1;
-    asm("v_and_b32 %3, 0xffff0000, %5\n\t"
-        "v_and_b32 %4, 0xffff0000, %6\n\t"
-        "v_perm_b32 %0, %6, %5, %7\n\t"
+    asm("v_cvt_pk_bf16_f32 %0, %5, %6\n\t"
+        "v_lshlrev_b32 %3, 16, %0\n\t"
+        "v_and_b32 %4, 0xffff0000, %0\n\t"
         "v_sub_f32 %1, %5, %3\n\t"
         "v_sub_f32 %2, %6, %4"
         : "=&v"(p1), "=&v"(r0), "=&v"(r1), "=&v"(h0), "=&v"(h1)
-        : "v"(x0), "v"(x1), "s"(sel));
+        : "v"(x0), "v"(x1));
 }
-// second half: p2 = top halves of r, p3 = r - p2 (exactly a bf16 value)
-__device__ __forceinline__ void split_b(float r0, float r1, unsigned& p2, unsigned& p3, unsigned sel) {
+// second half: p2 = bf16 pair of r, p3 = r - p2 (at most 8 significant bits are left: exactly a bf16 value)
+__device__ __forceinline__ void split_b(float r0, float r1, unsigned& p2, unsigned& p3, unsigned) {
     float h0, h1;
-    asm("v_and_b32 %2, 0xffff0000, %4\n\t"
-        "v_and_b32 %3, 0xffff0000, %5\n\t"
-        "v_perm_b32 %0, %5, %4, %6\n\t"
+    asm("v_cvt_pk_bf16_f32 %0, %4, %5\n\t"
+        "v_lshlrev_b32 %2, 16, %0\n\t"
+        "v_and_b32 %3, 0xffff0000, %0\n\t"
         "v_sub_f32 %2, %4, %2\n\t"
         "v_sub_f32 %3, %5, %3\n\t"
-        "v_perm_b32 %1, %3, %2, %6"
+        "v_cvt_pk_bf16_f32 %1, %2, %3"
         : "=&v"(p2), "=&v"(p3), "=&v"(h0), "=&v"(h1)
-        : "v"(r0), "v"(r1), "s"(sel));
+        : "v"(r0), "v"(r1));
 }
 
 // ---- arithmetic of the matrix products (VD_MATH, read once per process; every rank of a job must agree: the packed weight
@@ -146,9 +148,9 @@ __device__ __forceinline__ void split_b(float r0, float r1, unsigned& p2, unsign
 //                     a0*b0 (exact in fp32: 11 x 11 bits) + a0*b1 + a1*(2^-12 b0); the dropped a1*b1 is <= 2^-22 |ab|.
 //                     Weights are scaled per output channel by a power of two on the host (max |w s| in [2^13, 2^14): every
 //                     piece, 2^-12 b0 included, sits in fp16's normal range down to 2^-15 of the row's largest weight) and the
-//                     epilogue multiplies by 1/s -- exact.  Measured against fp64 the result is as close as the fp32 MFMA's
-//                     (tests/test_gpu_ops.py states the bound); the products of K >= 64 terms are dominated by the rounding of
-//                     the fp32 accumulator, which every mode shares.
+//                     epilogue multiplies by 1/s -- exact.  Measured against fp64 the result is at least as close as the fp32
+//                     MFMA's (max <= 1.06x, mean <= 1.02x: profiles/r04_split_accuracy.json; tests/test_gpu_ops.py asserts
+//                     <= 1.5x / 1.25x): the rounding of the fp32 accumulator dominates, and every mode shares it.
 //   bf16x6            the EXACT split: x = x1 + x2 + x3, three bf16 pieces, six piece products (the default of rounds 1-3).
 //   fp32              every product on v_mfma_f32_32x32x2_f32 (gemm_frag.hip, conv_wino.hip).
 enum { MATH_F16X3 = 0, MATH_BF16X6 = 1, MATH_FP32 = 2 };
@@ -159,8 +161,8 @@ inline bool f16_math() { return math_mode() == MATH_F16X3; }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // device: the two fp16 pieces of a pair of fp32 values.  p0 = {f16(x0), f16(x1)}; p1 = {f16((x0 - p0.lo) * 4096), f16(...)}:
-// v_fma_mix_f32 reads the fp16 half directly (x - a0 in one instruction), v_fma_mixlo/hi_f16 scale and round in one.  Plain
-// VALU issue cost each (tools/mfma_f16_coissue.hip: they co-issue with the f16 MFMA like v_fma_f32).
+// v_fma_mix_f32 reads the fp16 half directly (x - a0 in one instruction).  Plain VALU issue cost each
+// (tools/mfma_f16_coissue.hip: they co-issue with the f16 MFMA like v_fma_f32): 2.5 instructions per value in all.
 __device__ __forceinline__ unsigned f16_pack(float x0, float x1) {
     unsigned p;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p) : "v"(x0), "v"(x1));
@@ -176,16 +178,16 @@ __device__ __forceinline__ float f16_rem_hi(unsigned p0, float x1) {
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p0), "v"(x1));
     return r;
 }
-__device__ __forceinline__ unsigned f16_pack_scaled(float r0, float r1, float k4096) {
+// p1 = {f16(r0 * 2^12), f16(r1 * 2^12)}: v_ldexp_f32 + v_cvt_pk_f16_f32.  (v_fma_mixlo/hi_f16 would scale and round in one
+// instruction each, but they write HALF a register: gfx950 needs a wait state behind such a write before the register is read
+// again, hipcc pads every one with an s_nop, and with one wave per SIMD an s_nop is an issue slot like any other: the ISA of
+// round 4's first f16x3 loop carried nine of them per Winograd position.)
+__device__ __forceinline__ unsigned f16_pack_scaled(float r0, float r1) {
+    float s0, s1;
     unsigned p;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(p) : "v"(r0), "s"(k4096));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(p) : "v"(r1), "s"(k4096));
-    return p;
-}
-__device__ __forceinline__ unsigned f16_pack_scaled_pad(float r0, float r1, float k4096) {   // + the two wait states a VALU write needs before an MFMA reads it
-    unsigned p;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(p) : "v"(r0), "s"(k4096));
-    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(p) : "v"(r1), "s"(k4096));
+    asm("v_ldexp_f32 %0, %1, 12" : "=v"(s0) : "v"(r0));
+    asm("v_ldexp_f32 %0, %1, 12" : "=v"(s1) : "v"(r1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p) : "v"(s0), "v"(s1));
     return p;
 }
 // host packers of the split images (split_pack.hip); sizes in uint16 INCLUDING the trailer
@@ -302,6 +304,8 @@ int launch_posterior(const PosteriorArgs& a, hipStream_t s);
 int launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab, int num_timesteps, int B,
                     long per, float* out, hipStream_t s);
 int launch_randn(float* out, long n, unsigned long long seed, unsigned long long offset, hipStream_t s);
+int launch_q_sample_prev(const float* x0, const int64_t* t, const float* tab, int num_timesteps, int B, long per, const unsigned long long* dstate,
+                         unsigned long long draw_offset, float* out, hipStream_t s);
 
 enum { TAB_SQRT_RECIP = 0, TAB_SQRT_RECIPM1, TAB_COEF1, TAB_COEF2, TAB_LOGVAR, TAB_ACP, TAB_ACP_PREV,
        TAB_SQRT_ACP, TAB_SQRT_1M_ACP, TAB_POST_LOGVAR, TAB_LOG_1M_ACP, TAB_ALPHA, NTAB };

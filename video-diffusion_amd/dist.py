@@ -80,8 +80,18 @@ def share_weights(model, state_dict_fn, rank):
     if rank != 0:
         model.mark_weights_received()     # state_dict() stays rank 0's: other ranks hold only the packed device image
     # use_gradient_method: the backward-data image travels the same way (only when the option is on: enable_guidance())
+    # Whether it is on is RANK 0's decision and travels first: ranks that disagreed would issue different collective sequences
+    # (one more broadcast on some of them) and hang or corrupt the next collective instead of raising
     bwd = model.guidance_weights() if hasattr(model, "guidance_weights") else None
-    if bwd is not None:
+    want = bwd is not None
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        flag = [want]
+        dist.broadcast_object_list(flag, src=0)
+        if flag[0] and not want:
+            model.enable_guidance()       # rank 0 has it: allocate the buffer the image is about to land in
+            bwd = model.guidance_weights()
+        want = bool(flag[0])
+    if want:
         broadcast_packed(bwd, src=0)
         if rank != 0:
             model.mark_guidance_received()

@@ -11,14 +11,15 @@ same graph: CARLA's 47 windows need two graphs (Tw = 20 and Tw = 14).
 
 Noise: the engine's counter-based generator (Philox4x32-10 + Box-Muller inside the posterior kernel) with a seed drawn
 from torch's global generator, so `torch.manual_seed` still makes a run reproducible; the draws are N(0, 1) like the
-reference's `th.randn_like`, not the same stream.  `observed_frames` in {'x_0', 'x_t'}; 'x_t_minus_1' needs a fresh
-q_sample per step from the host and stays on the eager path.
+reference's `th.randn_like`, not the same stream.  `observed_frames` in {'x_0', 'x_t', 'x_t_minus_1'}; with 'x_t_minus_1' every
+step first re-noises the clean observed frames to t - 1 inside the graph (q_sample from the same Philox stream), which is what
+p_sample_loop does on the host before each step (gaussian_diffusion.py:565-568).
 """
 import torch as th
 
 from . import _lib
 
-_OBS_MODES = {"x_0": 0, "x_t": 1}
+_OBS_MODES = {"x_0": 0, "x_t": 1, "x_t_minus_1": 2}
 
 
 class WindowExecutor:
@@ -45,7 +46,8 @@ class WindowExecutor:
         """Arm a window: copy its tensors into the executor's buffers, set the device counters, capture if new."""
         mode = model_kwargs.get("observed_frames", "x_0")
         if mode not in _OBS_MODES:
-            raise NotImplementedError(f"observed_frames={mode!r}: the window executor handles 'x_0' and 'x_t'")
+            raise NotImplementedError(f"observed_frames={mode!r}: the window executor handles 'x_0', 'x_t' and 'x_t_minus_1'")
+        self.diffusion._refuse_learned(x_init)                        # a learned variance cannot sample (gaussian_diffusion.py:283)
         B, T = x_init.shape[:2]
         bufs = self._buffers(B, T)
         # the engine holds ONE schedule: another diffusion may have been bound to this model since the last window
@@ -65,6 +67,8 @@ class WindowExecutor:
                 bufs[k].copy_(kw[k].view(bufs[k].shape))
             if mode == "x_0":
                 bufs["obs_src"].copy_(kw["obs_src"])
+            elif mode == "x_t_minus_1":                                # the CLEAN frames: the graph draws q_sample(x0, t - 1) from them
+                bufs["obs_src"].copy_(model_kwargs["x0"].to(device=bufs["obs_src"].device, dtype=th.float32))
             if seed is None:
                 seed = int(th.randint(0, 2 ** 62, (1,)).item())        # torch.manual_seed governs the run
             if t_start is None:

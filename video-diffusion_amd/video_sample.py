@@ -67,7 +67,7 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
         optimal_schedule_path=optimal_schedule_path, **(dict(distance=adaptive_distance) if adaptive else {})))
     timesteps = list(range(diffusion.num_timesteps))[::-1]
     t_tensors = None
-    use_graph = executor == "graph" and observed_frames in ("x_0", "x_t") and not use_gradient_method
+    use_graph = executor == "graph" and observed_frames in ("x_0", "x_t", "x_t_minus_1") and not use_gradient_method
     if use_graph:
         from .executor import WindowExecutor
         wex = getattr(model, "_window_executor", None)
