@@ -39,7 +39,10 @@ def main():
     tot = 0.0
     for M, K, N, res, cnt in LIN:
         a = torch.rand(M, K, device="cuda") - 0.5
-        ws = torch.randint(-2000, 2000, (3 * N * K,), device="cuda", dtype=torch.int16)
+        w = (torch.rand(N, K) - 0.5) * (12.0 / K) ** 0.5
+        wp = torch.empty(L.vd_split_image_u16(N, K), dtype=torch.int16)
+        _lib.check(L.vd_pack_linear_split(_lib.ptr(w), _lib.ptr(wp), N, K))
+        ws = wp.cuda()
         b = torch.rand(N, device="cuda")
         r = torch.rand(M, N, device="cuda") if res else None
         out = torch.empty(M, N, device="cuda")
@@ -50,7 +53,10 @@ def main():
     for C, Co, H in CONV2:
         nfr = 128
         x = torch.rand(nfr, H, H, C, device="cuda") - 0.5
-        ws = torch.randint(-2000, 2000, (27 * Co * C,), device="cuda", dtype=torch.int16)
+        wc = (torch.rand(Co, C, 3, 3) - 0.5) * (12.0 / (9 * C)) ** 0.5
+        wp = torch.empty(L.vd_split_image_u16(Co, 9 * C), dtype=torch.int16)
+        _lib.check(L.vd_pack_conv3_split(_lib.ptr(wc), _lib.ptr(wp), Co, C))
+        ws = wp.cuda()
         b = torch.rand(Co, device="cuda")
         out = torch.empty(nfr, H // 2, H // 2, Co, device="cuda")
         ms = timeit(lambda: _lib.check(L.vd_op_conv_split(_lib.ptr(x), C, nfr, H, H, 2, _lib.ptr(ws), _lib.ptr(b), None, _lib.ptr(out), Co,

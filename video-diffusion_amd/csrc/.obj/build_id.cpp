@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "5c1af29f18c1c358"; }
+extern "C" const char* vd_source_sha(void) { return "bc1a360091d3f91f"; }
