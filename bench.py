@@ -425,7 +425,10 @@ def main():
                     traffic_source = "profiles/pmc_dominant.json (rocprofv3 --pmc passes of this workload on this kernel source, not this run)"
                 elif rec.get("kernel") == name:
                     traffic_source = "profiles/pmc_dominant.json is stale (kernel source changed since the PMC passes): traffic withheld"
-            split_conv = name == "conv3x3_wino_r64_kernel"
+            split_conv = name in ("conv3x3_wino_r64_kernel", "conv3x3_wino_z128_kernel")
+            # multiplications a direct 3x3 conv spends per one the kernel executes: F(2x2,3x3) = 36 / 16; conv_wino_z128.hip folds the
+            # column half of the output transform into the accumulation (six MFMA groups per four positions): 36 / 24
+            wino_gain = 1.5 if name == "conv3x3_wino_z128_kernel" else 2.25
             pieces = 3 if math == "f16x3" else 6                              # piece products per element product
             # the dominant kernel runs on the 16-bit matrix pipe (fp32 operands carried as fp16 / bf16 pieces) unless
             # VD_MATH=fp32 keeps it on the fp32 MFMA: `peak` is the dense peak of the pipe it uses (f16 = bf16 rate)
@@ -439,9 +442,10 @@ def main():
                                       "kept busy is mfma_executed_frac")
             if name.startswith("conv3x3_wino"):
                 # `achieved` counts the ALGORITHMIC flops of a direct fp32 3x3 convolution (2*M*Cout*Cin*9).  Winograd
-                # F(2x2,3x3) executes 16/36 of the multiplications; the split kernel spends `pieces` piece products
-                # on each, so the matrix pipe executes achieved * pieces / 2.25 flops (fp32 kernel: achieved / 2.25)
-                ex = achieved * (pieces / 2.25 if split_conv else 1 / 2.25)
+                # F(2x2,3x3) executes 16/36 of the multiplications (24/36 with the folded column transform); the split kernel spends
+                # `pieces` piece products on each, so the matrix pipe executes achieved * pieces / wino_gain flops (fp32 kernel: achieved / 2.25)
+                ex = achieved * (pieces / wino_gain if split_conv else 1 / 2.25)
+                roofline["direct_over_executed_multiplications"] = wino_gain
                 roofline["piece_products"] = pieces if split_conv else 1
                 roofline["mfma_executed_tflops"] = round(ex, 2)
                 roofline["mfma_executed_frac"] = round(ex / peak, 4)

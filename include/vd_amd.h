@@ -278,6 +278,10 @@ int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, i
  * concat; tables from vd_op_conv_stats or from a statistics pass have the same layout) into the (A, B) pair of
  * vd_op_gn_fold, so the consumer's GroupNorm (unet.py:185-198) never reads the tensor for its statistics. */
 int vd_conv_stats_split(int Hout);
+/* Output channels per block of the Winograd kernel a stride-1 3x3 conv of this shape runs on under the split arithmetic: 128
+ * (conv_wino_z128.hip) or 64 (conv_wino_r64.hip).  Same weight image, same results up to summation order; tests use it to
+ * know which kernel they exercised. */
+int vd_conv_wino_block_couts(int nfr, int H, int Cin, int Cout);
 int vd_op_conv_stats(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const float* w_wino, const float* bias,
                      const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,
                      void* stream);

@@ -595,8 +595,26 @@ def pack_wino_split(w):
 @pytest.mark.parametrize("N,Cin,Cout,H,ups", [(3, 64, 128, 16, 0), (5, 32, 64, 8, 0), (2, 96, 160, 32, 0), (9, 64, 32, 8, 0),
                                                (1, 128, 64, 64, 0), (2, 64, 64, 8, 1), (6, 160, 192, 8, 0), (41, 32, 128, 32, 0),
                                                (37, 64, 256, 16, 0), (1100, 32, 64, 8, 0), (8, 64, 128, 32, 0), (64, 32, 128, 32, 0),
-                                               (3, 224, 64, 16, 1), (300, 64, 64, 16, 0), (16, 128, 192, 64, 0)])
+                                               (3, 224, 64, 16, 1), (300, 64, 64, 16, 0), (16, 128, 192, 64, 0), (2, 96, 384, 16, 0)])
 def test_conv3x3_winograd_split_is_fp32_accurate(N, Cin, Cout, H, ups):
+    _check_wino_split(N, Cin, Cout, H, ups)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H", [(41, 32, 128, 32), (64, 32, 128, 32), (16, 160, 128, 64), (128, 64, 256, 16), (43, 96, 128, 32),
+                                          (64, 64, 512, 16)])
+def test_conv3x3_winograd_128_cout_blocks(N, Cin, Cout, H):
+    """csrc/conv_wino_z128.hip: the same convolution with the column half of the output transform accumulated by the matrix
+    pipe (six (position, column) groups of MFMAs instead of four, 128 couts per block, the third weight piece formed in
+    registers).  The library picks it by grid fill (vd_conv_wino_block_couts); these shapes are ones it picks it for under
+    the default arithmetic -- one and several trips of the chunk-pair loop, one to four cout blocks, tile-group counts that are and
+    are not a multiple of 8 (both item orders).  Same bounds as the 64-cout kernel."""
+    L = _lib.lib()
+    if L.vd_math_mode() == 0:
+        assert L.vd_conv_wino_block_couts(N, H, Cin, Cout) == 128
+    _check_wino_split(N, Cin, Cout, H, 0)
+
+
+def _check_wino_split(N, Cin, Cout, H, ups):
     """csrc/conv_wino_r64.hip (maps >= 8x8; 8x8 maps go four frames to an item, incl. frame counts that are not a multiple of
     four): Winograd F(2x2,3x3) with the element products as piece products of the split fp32 operands (the process'
     arithmetic).  Held to the op tolerance against torch fp32, to the fp32-MFMA Winograd kernel's error against an fp64 conv

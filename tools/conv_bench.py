@@ -71,13 +71,24 @@ def main():
         tot_fl += fl * cnt
         extra = ""
         if stamps:
-            st = (ctypes.c_ulonglong * 8)()
+            st = (ctypes.c_ulonglong * 16)()
             L.vd_debug_r64_stamps.restype = ctypes.c_int
             L.vd_debug_r64_stamps.argtypes = [ctypes.c_void_p]
             assert L.vd_debug_r64_stamps(st) == 0
             t = list(st)
-            extra = (f"   item of block 7 (cycles): prologue {t[1]-t[0]}, loop {t[2]-t[1]} = {(t[2]-t[1]) / (Cin // 16):.0f}/chunk, output "
-                     f"transform {t[3]-t[2]}; {(t[3]-t[0]) / max(t[5]-t[4], 1) * 0.1:.2f} GHz")
+            ep = " | ".join(f"n{n}: Z {t[3+4*n]-(t[2] if n == 0 else t[6])}, barrier {t[4+4*n]-t[3+4*n]}, sum+store {t[5+4*n]-t[4+4*n]}, stats {t[6+4*n]-t[5+4*n]}"
+                            for n in range(2))
+            extra = (f"\n      item of block 7 (cycles): prologue {t[1]-t[0]}, loop {t[2]-t[1]} = {(t[2]-t[1]) / (Cin // 16):.0f}/chunk, output transform "
+                     f"{t[10]-t[2]} [{ep}]; {(t[10]-t[0]) / max(t[15]-t[14], 1) * 0.1:.2f} GHz")
+        if hasattr(L, "vd_debug_z128_stamps") and not ups and H >= 16 and Cout % 128 == 0 and os.environ.get("VD_CONV_Z128", "1") != "0":
+            st = (ctypes.c_ulonglong * 16)()
+            L.vd_debug_z128_stamps.restype = ctypes.c_int
+            L.vd_debug_z128_stamps.argtypes = [ctypes.c_void_p]
+            assert L.vd_debug_z128_stamps(st) == 0
+            t = list(st)
+            ep = " | ".join(f"n{n}: Z {t[3+2*n]-(t[2] if n == 0 else t[2+2*n])}, rest {t[4+2*n]-t[3+2*n]}" for n in range(4))
+            extra = (f"\n      z128 item of block 7 (cycles): prologue {t[1]-t[0]}, loop {t[2]-t[1]} = {(t[2]-t[1]) / (Cin // 16):.0f}/chunk, output transform "
+                     f"{t[10]-t[2]} [{ep}]; {(t[10]-t[0]) / max(t[15]-t[14], 1) * 0.1:.2f} GHz")
         print(f"{Cin:5d} -> {Cout:4d} @ {H:2d}{' ups' if ups else '    '} x{cnt:2d}: {ms * 1e3:8.1f} us  {fl / ms * 1e-9:6.1f} TFLOP/s direct-equivalent{extra}", flush=True)
     print(f"class total {tot_ms:.3f} ms per step, {tot_fl / tot_ms * 1e-9:.1f} TFLOP/s direct-equivalent ({_lib.lib().vd_version().decode()})")
 

@@ -4,7 +4,7 @@ launch of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes (FETC
 FETCH_SIZE x2 for wide coalesced reads), plus the MFMA-busy and LDS figures of the same passes.
   python tools/make_pmc_dominant.py gpurun_out/prof_r04/summary.json conv3x3_wino_r64_kernel r04
 Also the proof that the timed kernel executes all of the work: SQ_INSTS_MFMA per launch must equal the algorithmic FLOPs of the
-launch x piece products / 2.25 (Winograd) / 32768 (FLOPs of one 32x32x16 MFMA) -- asserted, and stored for bench.py to print."""
+launch x piece products / 2.25 (Winograd; 1.5 for conv_wino_z128.hip) / 32768 (FLOPs of one 32x32x16 MFMA) -- asserted, and stored for bench.py to print."""
 import hashlib
 import json
 import os
@@ -22,12 +22,14 @@ n = tot["dispatches"]
 stats = [v for k, v in d["stats"].items() if kernel in k]
 fetch, write = tot["FETCH_SIZE"] * 1024 / n, tot["WRITE_SIZE"] * 1024 / n
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KSRC = {"conv3x3_wino_r64_kernel": ["video-diffusion_amd/csrc/conv_wino_r64.hip", "video-diffusion_amd/csrc/vd_common.h"]}.get(kernel, [])
+KSRC = {"conv3x3_wino_r64_kernel": ["video-diffusion_amd/csrc/conv_wino_r64.hip", "video-diffusion_amd/csrc/vd_common.h"],
+        "conv3x3_wino_z128_kernel": ["video-diffusion_amd/csrc/conv_wino_z128.hip", "video-diffusion_amd/csrc/vd_common.h"]}.get(kernel, [])
 # the un-profiled bench line of the same box and command (tools/profile_bench.sh): algorithmic FLOPs per launch, arithmetic mode
 bench = json.load(open(os.path.join(os.path.dirname(summary), "bench.json")))
 assert bench["roofline"]["kernel"] == kernel, (bench["roofline"]["kernel"], kernel)
 pieces = bench["roofline"].get("piece_products", 6)
-mfma_expected = bench["roofline"]["alg_gflop_per_launch"] * 1e9 * pieces / 2.25 / 32768
+gain = bench["roofline"].get("direct_over_executed_multiplications", 2.25)       # 2.25: F(2x2,3x3); 1.5: with the folded column transform
+mfma_expected = bench["roofline"]["alg_gflop_per_launch"] * 1e9 * pieces / gain / 32768
 mfma_measured = tot["SQ_INSTS_MFMA"] / n
 assert abs(mfma_measured / mfma_expected - 1) < 1e-4, f"SQ_INSTS_MFMA per launch {mfma_measured} != expected {mfma_expected}: work skipped or duplicated"
 out = {

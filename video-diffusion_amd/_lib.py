@@ -10,8 +10,12 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libvdamd.so")
-SOURCES = ["igemm.hip", "conv_wino.hip", "conv_wino_r64.hip", "gemm_frag.hip", "gemm_split.hip", "split_pack.hip", "norm.hip", "backward.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "conv_wino.hip", "conv_wino_r64.hip", "conv_wino_z128.hip", "gemm_frag.hip", "gemm_split.hip", "split_pack.hip", "norm.hip", "backward.hip", "attn_spatial.hip", "attn_temporal.hip", "misc.hip", "engine.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vd_amd.h")
+# per-source flags on top of the common ones.  conv_wino_z128.hip: its main loop is ONE fully unrolled body of 288 MFMA slots; past
+# LLVM's default size limit for `#pragma unroll` (16 k IR instructions) hipcc silently keeps the loops and indexes the register
+# arrays through scratch
+SOURCE_FLAGS = {"conv_wino_z128.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _toolchain():
@@ -41,7 +45,7 @@ def source_sha():
     SOURCES, vd_common.h and include/vd_amd.h -- by CONTENT, so a checkout / rsync / snapshot with arbitrary mtimes can
     neither hide a stale binary nor force a rebuild of a fresh one.  The built library carries it (vd_source_sha())."""
     hipcc, flags = _toolchain()
-    return _sha("\0".join(flags), *[_read(os.path.join(_CSRC, s)) for s in SOURCES], _read(os.path.join(_CSRC, "vd_common.h")),
+    return _sha("\0".join(flags), repr(sorted(SOURCE_FLAGS.items())), *[_read(os.path.join(_CSRC, s)) for s in SOURCES], _read(os.path.join(_CSRC, "vd_common.h")),
                 _read(HEADER))[:16]
 
 
@@ -82,13 +86,14 @@ def build(force=False, verbose=False):
             def compile_one(src):
                 path = idsrc if src is None else os.path.join(_CSRC, src)
                 obj = os.path.join(objdir, os.path.basename(path).rsplit(".", 1)[0] + ".o")
-                want = _sha("\0".join(flags), _read(path), *hdr_bytes)
+                extra = SOURCE_FLAGS.get(src, [])
+                want = _sha("\0".join(flags + extra), _read(path), *hdr_bytes)
                 try:
                     have = open(obj + ".sha").read().strip()
                 except OSError:
                     have = ""
                 if force or have != want or not os.path.exists(obj):
-                    cmd = [hipcc, *flags, "-c", path, "-o", obj] if src is not None else [hipcc, "-O2", "-fPIC", "-c", path, "-o", obj]
+                    cmd = [hipcc, *flags, *extra, "-c", path, "-o", obj] if src is not None else [hipcc, "-O2", "-fPIC", "-c", path, "-o", obj]
                     if verbose:
                         print(" ".join(cmd), flush=True)
                     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -183,6 +188,7 @@ SIGNATURES = {
     "vd_profile_class_name": (ctypes.c_char_p, [_I]),
     "vd_op_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P]),
     "vd_conv_stats_split": (_I, [_I]),
+    "vd_conv_wino_block_couts": (_I, [_I, _I, _I, _I]),
     "vd_op_conv_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "vd_op_gn_affine": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "vd_pack_conv3_wino": (_I, [_P, _P, _I, _I]),

@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "bc1a360091d3f91f"; }
+extern "C" const char* vd_source_sha(void) { return "cd831a1a1c3fe141"; }

@@ -53,12 +53,14 @@ template <bool TF4> constexpr int lds_bytes() { return (NB + 1) * R64G<TF4>::XBU
 }  // namespace r64
 
 #ifdef VD_WINO_TIMING
-__device__ unsigned long long g_r64_stamp[8];
+// cycle stamps of ONE work item (wave 0 of block 7): 0 start, 1 loop start, 2 loop end; per cout tile n (3 + 4n ..): Z image
+// written, past the exchange barrier, output stored, statistics done; 14 / 15: the 100 MHz clock at start / end
+__device__ unsigned long long g_r64_stamp[16];
 #define R64_STAMP(i)                                                                                  \
     do {                                                                                              \
         if (threadIdx.x == 0 && blockIdx.x == 7) {                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                        \
-            g_r64_stamp[i] = (i) >= 4 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); \
+            g_r64_stamp[i] = (i) >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); \
             __builtin_amdgcn_sched_barrier(0);                                                        \
         }                                                                                             \
     } while (0)
@@ -295,7 +297,7 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
 #pragma unroll
             for (int p = 0; p < 3; ++p) bfr[j][n][p] = u32x4{0u, 0u, 0u, 0u};
 
-    R64_STAMP(0); R64_STAMP(4);
+    R64_STAMP(0); R64_STAMP(14);
     // ---- prologue: three patches and the weights of chunk 0 requested; group (0, 0) transformed whole, position 0 split,
     // column 0 of group (0, 1) in flight -- the state the loop expects at the top of a group
 #pragma unroll
@@ -470,7 +472,9 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                 *reinterpret_cast<f32x4*>(Zs + ((((wi * 2 + 1) * 2 + m) * 4 + c4) * 64 + lane) * 4) = f32x4{z1[4 * c4], z1[4 * c4 + 1], z1[4 * c4 + 2], z1[4 * c4 + 3]};
             }
         }
+        R64_STAMP(3 + 4 * n);
         __syncthreads();
+        R64_STAMP(4 + 4 * n);
         const float* zw = Zs + wi * 2048 + lane * 4;                 // Z[p + k][q] is plane wi + 2k
         float gsum[TF4 ? 4 : 1][2] = {};
 #pragma unroll
@@ -497,7 +501,8 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                 }
             }
         }
-        if (a.stats) {                                               // GroupNorm partial sums of the output (conv_wino.hip)
+        R64_STAMP(5 + 4 * n);
+        if (a.stats) {                                               // GroupNorm partial sums of the output
             constexpr int NFS = TF4 ? 4 : 1;
             __syncthreads();
             double* red = reinterpret_cast<double*>(smem);           // [wave 4][lh 2][frame NFS][lr 32][2]
@@ -521,8 +526,9 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                 }
             }
         }
+        R64_STAMP(6 + 4 * n);
     }
-    R64_STAMP(3); R64_STAMP(5);
+    R64_STAMP(15);
 }
 
 template <bool TF4, bool F16>

@@ -113,7 +113,7 @@ struct Arena {
 enum ProfClass { PC_IGEMM_128x128 = 0, PC_IGEMM_128x64, PC_IGEMM_64x128, PC_IGEMM_64x64, PC_GN_STATS, PC_GN_TEMPORAL,
                  PC_ATTN_SPATIAL, PC_ATTN_TEMPORAL, PC_OUT_CONV, PC_ELEMENTWISE, PC_POSTERIOR,
                  PC_CONV_128x128, PC_CONV_128x64, PC_CONV_64x128, PC_CONV_64x64, PC_CONV_WINO, PC_CONV_WINO_R64, PC_IGEMM_128x192,
-                 PC_CONV_WINO_R64_UPS, PC_COUNT };
+                 PC_CONV_WINO_R64_UPS, PC_CONV_WINO_Z128, PC_COUNT };
 // names of the kernels a class runs on: [0] split arithmetic (f16x3 | bf16x6), [1] VD_MATH=fp32
 static const char* kProfNames[PC_COUNT][2] = {
     {"gemm_split_kernel<128,128>", "gemm_frag_kernel<128,128>"}, {"gemm_split_kernel<128,64>", "gemm_frag_kernel<128,64>"},
@@ -125,7 +125,7 @@ static const char* kProfNames[PC_COUNT][2] = {
     {"igemm_kernel<64,128> 3x3", "igemm_kernel<64,128> 3x3"}, {"igemm_kernel<64,64> 3x3", "igemm_kernel<64,64> 3x3"},
     {"conv3x3_wino_kernel", "conv3x3_wino_kernel"}, {"conv3x3_wino_r64_kernel", "conv3x3_wino_r64_kernel"},
     {"gemm_split_kernel<128,192>", "gemm_split_kernel<128,192>"},
-    {"conv3x3_wino_r64_ups_kernel", "conv3x3_wino_r64_ups_kernel"}};
+    {"conv3x3_wino_r64_ups_kernel", "conv3x3_wino_r64_ups_kernel"}, {"conv3x3_wino_z128_kernel", "conv3x3_wino_z128_kernel"}};
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; char tag[56]; };
 struct Profiler {
     bool on = false;
@@ -160,7 +160,8 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     one.M = one.nfr * g.Ho * g.Wo;
     const bool wino = conv_wino_supported(one) || conv_wino_r64_supported(one);
     const bool split_gemm = gemm_split_supported(one) || conv_split_supported(one);
-    const int cls = wino ? (int)(g.ups_phase ? PC_CONV_WINO_R64_UPS : conv_wino_r64_supported(one) ? PC_CONV_WINO_R64 : PC_CONV_WINO)
+    const int cls = wino ? (int)(g.ups_phase ? PC_CONV_WINO_R64_UPS : conv_wino_z128_supported(one) ? PC_CONV_WINO_Z128
+                                                               : conv_wino_r64_supported(one) ? PC_CONV_WINO_R64 : PC_CONV_WINO)
                     : split_gemm && gemm_split_tile_class(one.M, g.Cout) == 4 ? (int)PC_IGEMM_128x192
                     : igemm_tile_class(one.M, g.Cout) + (g.ksz == 3 && !split_gemm ? (int)PC_CONV_128x128 : 0);   // 3x3 on the generic kernel
     char tag[56];
@@ -2147,6 +2148,7 @@ int vd_op_conv(const float* src0, const float* src1, int C0, int Cin, int nfr, i
 }
 
 int vd_conv_stats_split(int Hout) { return conv_wino_stats_split(Hout); }
+int vd_conv_wino_block_couts(int nfr, int H, int Cin, int Cout) { return conv_wino_z128_shape(nfr, H, Cin, Cout) ? 128 : 64; }
 
 int vd_op_conv_stats(const float* src0, int Cin, int nfr, int Hs, int Ws, int ups, const float* w_wino, const float* bias,
                      const float* res, const float* fbias, int fbias_ld, float* out, int Cout, double* gn_part,

@@ -38,9 +38,6 @@ __device__ __forceinline__ f32x16 mfma_piece(u32x4 a, u32x4 b, f32x16 c) {
 #ifndef VD_GS_PF3
 #define VD_GS_PF3 1        // 0: the A operand one chunk ahead for every tile (A/B)
 #endif
-#ifndef VD_GS_PF128
-#define VD_GS_PF128 0      // 1: three chunks of the A operand in flight for the 128x128 tile too (its SIDE launches are HBM-bound)
-#endif
 #ifndef VD_GS_RING6
 #define VD_GS_RING6 1      // 0: three weight slots for the 64x64 tile too (A/B)
 #endif
@@ -82,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     // A-operand prefetch distance in chunks.  A chunk of a 64-row tile is 12 .. 24 MFMAs (0.2 .. 0.4 us): one chunk ahead, the
     // split + store of the next chunk waits a full memory round trip every chunk, and a small-M launch (a B = 1 shard: 60 of
     // them per step) costs ~1 us per chunk whatever its size.  The small tiles have the registers for three chunks in flight.
-    constexpr int PF = ((BM == 64 && VD_GS_PF3) || (BM == 128 && BN == 128 && F16 && VD_GS_PF128)) ? 3 : 1;
+    constexpr int PF = (BM == 64 && VD_GS_PF3) ? 3 : 1;      // (three chunks in flight for the HBM-bound 128x128 SIDE launches too: measured, no gain -- r04i)
     constexpr int NPL = F16 ? 2 : 3;                                      // planes of the A tile
     constexpr int PLANE = BM * SROW, ABUF = NPL * PLANE;                  // bytes
     extern __shared__ __attribute__((aligned(16))) char smem_c[];         // [2][3 planes][BM][SROW]

@@ -196,6 +196,11 @@ size_t split_image_u16(size_t n_out, size_t k_total);            // n_out * k_to
 void pack_conv3_wino_split(const float* oihw, unsigned short* out, int O, int I);
 bool conv_wino_r64_supported(const IgemmArgs& a);        // wsplit == 2
 int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s);
+// the same convolution with the column half of the output transform on the matrix pipe, 64 tiles x 128 couts per block
+// (conv_wino_z128.hip): f16x3, maps >= 16 x 16, Cout % 128 == 0; same weight image
+bool conv_wino_z128_supported(const IgemmArgs& a);
+bool conv_wino_z128_shape(int nfr, int H, int Cin, int Cout);     // the shape half of that decision (grid fill; conv_wino_z128.hip)
+int launch_conv_wino_z128(const IgemmArgs& a, hipStream_t s);
 // Upsample (nearest x2) + conv3x3 in its sub-pixel form (conv_wino_r64.hip): four phase kernels per real cout over the
 // LOW-resolution map, one of the four Winograd columns structurally zero and skipped.  IgemmArgs::ups_phase selects it;
 // the GroupNorm table then has conv_wino_ups_stats_split(Hs) entries per frame.
