@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--prefix-cache", action="store_true",
                     help="with --executor graph: the observed frames' activations before the first attention layer once per "
                          "window (vd_set_window_prefix_cache); never the headline -- the default run reports it as an extra object")
+    ap.add_argument("--suffix-skip", action="store_true",
+                    help="with --executor graph: everything behind the last attention layer without the purely observed frames "
+                         "(vd_set_window_suffix_skip); never the headline -- the default run reports it as an extra object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32-ref", action="store_true")
@@ -172,9 +175,9 @@ class DropInStepper:
 class GraphStepper:
     """The window executor (vd_window_*): one hipGraph per window shape, step index and Philox counter on the device."""
 
-    def __init__(self, model, diff, kw, seed, prefix_cache=False):
+    def __init__(self, model, diff, kw, seed, prefix_cache=False, suffix_skip=False):
         from video_diffusion_amd.executor import WindowExecutor
-        self.ex = WindowExecutor(model, diff, prefix_cache=prefix_cache)
+        self.ex = WindowExecutor(model, diff, prefix_cache=prefix_cache, suffix_skip=suffix_skip)
         self.kw = {**kw, "x_t_minus_1": kw["x0"], "observed_frames": "x_0"}
         self.x = kw["x0"].clone().float().contiguous()
         self.seed = seed
@@ -295,7 +298,7 @@ def main():
     # the number in the EXACT-split arithmetic (bf16x6, the default of earlier rounds) or with every matrix product on the fp32
     # MFMA, the same benchmark is run first in child processes with VD_MATH set -- started before this process touches the GPU.
     math = os.environ.get("VD_MATH") or "f16x3"
-    fp32_ref = x6_ref = pc_ref = None
+    fp32_ref = x6_ref = pc_ref = ss_ref = None
     # (never under a profiler: its preloaded library has already initialised the GPU in this process, and starting
     # another program from such a process is not allowed on the GPU boxes)
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(
@@ -334,6 +337,33 @@ def main():
                                   "opt-in, NOT the headline"}
             except Exception:                                        # noqa: BLE001
                 pc_ref = {"error": (child.stderr or child.stdout)[-300:]}
+            # the window suffix skip (opt-in): the headline window, and the window shapes of BASELINE configs[2] (MineRL: 20 frames, 13
+            # of them observed) and configs[4] (CARLA 128x128, 20 frames, 10 observed, DDIM-50), each with and without it
+            def graph_child(extra):
+                c = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--executor", "graph", "--no-cpu-baseline",
+                                    "--no-roofline", "--no-fp32-ref", "--no-dropin", "--no-full-window", *extra], env=dict(os.environ),
+                                   capture_output=True, text=True)
+                try:
+                    return json.loads([l for l in c.stdout.splitlines() if l.startswith("{")][-1])
+                except Exception:                                    # noqa: BLE001
+                    return {"error": (c.stderr or c.stdout)[-300:]}
+            try:
+                ref = graph_child(["--suffix-skip"])
+                ss_ref = {"value": ref["value"], "ms_per_step": ref["ms_per_step"], "suffix_frames_per_window": ref["config"].get("suffix_frames"),
+                          "note": "window executor with vd_set_window_suffix_skip: behind the last attention layer (decoder blocks at 32x32 / "
+                                  "64x64, both Upsample convs, the head) the captured step runs on the frames that are not pure observations; "
+                                  "those frames' samples equal the full step's to the bit (tests/test_gpu_engine.py), the observed frames' "
+                                  "entries of the window are meaningless and never read (scripts/video_sample.py:170-186); opt-in, NOT the headline"}
+                for name, shape, nsteps in (("configs2_window_20f_13obs", ["--frames", "20", "--obs", "13", "--steps", "10", "--warmup", "3"], 250),
+                                            ("configs4_window_128px_20f_10obs_ddim50", ["--image-size", "128", "--frames", "20", "--obs", "10", "--respacing", "ddim50",
+                                                                                          "--steps", "5", "--warmup", "2"], 50)):
+                    a, b = graph_child(shape), graph_child(shape + ["--suffix-skip"])
+                    ss_ref[name] = {"ms_per_step": a["ms_per_step"], "ms_per_step_suffix_skip": b["ms_per_step"],
+                                    "sec_per_window": round(a["ms_per_step"] * nsteps / 1e3, 3),
+                                    "sec_per_window_suffix_skip": round(b["ms_per_step"] * nsteps / 1e3, 3),
+                                    "suffix_frames_per_window": b["config"].get("suffix_frames"), "steps_per_window": nsteps}
+            except Exception as e:                                   # noqa: BLE001
+                ss_ref = {**(ss_ref or {}), "error": repr(e)[-300:]}
 
     # rehearsal knobs for a one-GPU box (the N > 1 path is the driver's to run on an 8-GPU node): VD_BENCH_BACKEND=gloo
     # and VD_BENCH_ALL_ON_DEVICE0=1 put every rank on device 0 (RCCL refuses two ranks on one GPU, gloo does not)
@@ -365,7 +395,8 @@ def main():
 
     kw = make_window(B, T, S, n_obs, seed=1234 + rank, device=device)
     assert not args.prefix_cache or args.executor == "graph", "--prefix-cache is a mode of the window executor (--executor graph)"
-    stepper = GraphStepper(model, diff, kw, seed=5 + rank, prefix_cache=args.prefix_cache) if args.executor == "graph" else \
+    assert not args.suffix_skip or args.executor == "graph", "--suffix-skip is a mode of the window executor (--executor graph)"
+    stepper = GraphStepper(model, diff, kw, seed=5 + rank, prefix_cache=args.prefix_cache, suffix_skip=args.suffix_skip) if args.executor == "graph" else \
         Stepper(model, diff, kw, seed=5 + rank)
     nts = diff.num_timesteps
     order = list(range(nts))[::-1]
@@ -485,8 +516,9 @@ def main():
         "lib_source_sha": __import__("video_diffusion_amd")._lib.lib().vd_source_sha().decode(),
         "config": {"workload": workload, "batch_per_gpu": B, "frames": T, "image_size": S, "respaced_steps": nts,
                    "parallelism": f"batch-shard x{world} (no collective in the step)", "rccl_ranks": world,
-                   "executor": args.executor + ("+prefix_cache" if args.prefix_cache else ""),
-                   **({"cached_frames": stepper.ex.cached_frames} if args.prefix_cache else {})},
+                   "executor": args.executor + ("+prefix_cache" if args.prefix_cache else "") + ("+suffix_skip" if args.suffix_skip else ""),
+                   **({"cached_frames": stepper.ex.cached_frames} if args.prefix_cache else {}),
+                   **({"suffix_frames": stepper.ex.suffix_frames} if args.suffix_skip else {})},
         "roofline": roofline,
     }
     if dropin is not None:
@@ -503,6 +535,8 @@ def main():
         line["bf16x6_exact_split"] = x6_ref
     if pc_ref is not None:
         line["window_prefix_cache_opt_in"] = pc_ref
+    if ss_ref is not None:
+        line["window_suffix_skip_opt_in"] = ss_ref
     if classes is not None:
         line["kernel_classes"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                       "tflops": round(v["gflop"] / v["ms"], 2) if v["gflop"] else None,

@@ -190,6 +190,20 @@ int vd_window_graphs(vd_engine* e);            /* captured graphs held by the en
 int vd_set_window_prefix_cache(vd_engine* e, int on);
 int vd_window_prefix_frames(vd_engine* e);
 
+/* Window suffix skip (opt-in, off by default; the sibling of the prefix cache at the other end of the network).  Behind its
+ * LAST attention layer the UNet treats frames as independent batch entries again -- the remaining decoder ResBlocks, the
+ * Upsample convs and the output head (unet.py:820-839) -- and the caller of a window keeps only its latent frames
+ * (scripts/video_sample.py:170-186), while a purely observed frame (obs_mask = 1, latent_mask = 0) re-enters the network as
+ * the observation whatever the step wrote to it (unet.py:958-983: observed_frames 'x_0' and 'x_t_minus_1' with
+ * cond_emb_type='channel'; NOT 'x_t', where its input is its own running sample).  With the skip on, the captured step
+ * gathers every other frame out of the last attention layer's output and out of the skip tensors the remaining blocks read
+ * (rows and GroupNorm partial sums), runs those blocks and the head on that compact batch with the kernel variants the full
+ * batch would get, and writes eps = 0 for the skipped frames: every frame that is not a pure observation receives the eps
+ * -- and so the sample -- of the full step, bit for bit; the skipped frames' entries of the window tensor are meaningless.
+ * vd_window_suffix_frames: frames the suffix of the armed window runs on (0: all of them -- skip off or nothing to skip). */
+int vd_set_window_suffix_skip(vd_engine* e, int on);
+int vd_window_suffix_frames(vd_engine* e);
+
 /* The posterior arithmetic alone, given eps (same formulas; mode 0 p_sample, 1 ddim). */
 int vd_posterior_update(vd_engine* e, int mode, int B, long long per_sample, const float* x, const float* eps,
                         const long long* t, int clip_denoised, float eta, const float* noise,

@@ -820,6 +820,50 @@ def test_window_prefix_cache_matches_the_uncached_window():
     model.check_device_errors()
 
 
+def test_window_suffix_skip_leaves_every_read_frame_bit_identical():
+    """vd_set_window_suffix_skip (opt-in): behind the last attention layer the captured step runs on the frames that are not
+    pure observations -- gathered out of the attention output and the decoder's skip tensors -- with the kernel variants the
+    full batch gets (IgemmArgs::nfr_sel).  Every such frame of the window must equal the plain executor's to the BIT after all
+    steps (same Philox stream); the skipped frames are finite and not compared (scripts/video_sample.py:170-186 never reads
+    them).  Covered: 'x_0' and 'x_t_minus_1', a second window with new contents (same graph), another frame set (new graph),
+    per-item frame sets, a padding frame (any = 0: not skipped), 'x_t' and a window without observations (skip not
+    applicable: suffix_frames == 0), combined with the prefix cache, a model without scale-shift, and a model whose only
+    decoder attention sits at its first level (the suffix starts inside an Upsample block)."""
+    from video_diffusion_amd.executor import WindowExecutor
+    for extra in (dict(), dict(use_scale_shift_norm=False), dict(attention_resolutions="4")):
+        cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=6, image_size=32, num_channels=64, num_res_blocks=1,
+                                                                  rp_alpha=6, rp_beta=6, rp_gamma=6, timestep_respacing="ddim10"), **extra}
+        model, diff = engine(cfg)
+        plain, skip, both = WindowExecutor(model, diff), WindowExecutor(model, diff, suffix_skip=True), \
+            WindowExecutor(model, diff, prefix_cache=True, suffix_skip=True)
+        for wi, (B, T, n_obs, obsf, tweak) in enumerate([(2, 6, 2, "x_0", None), (2, 6, 2, "x_0", None), (2, 6, 3, "x_t_minus_1", None),
+                                                         (2, 6, 2, "x_0", "per_item"), (2, 6, 2, "x_0", "padding"),
+                                                         (2, 6, 2, "x_t", None), (2, 6, 0, "x_0", None), (3, 5, 4, "x_0", None)]):
+            c = _rand_window(B, T, 32, n_obs, seed=170 + wi)
+            if tweak == "per_item":                                    # item 1 also observes frame 4
+                c["obs_mask"][1, 4] = 1; c["latent_mask"][1, 4] = 0
+                c["x0"][1, 4] = torch.rand(3, 32, 32) * 2 - 1
+            if tweak == "padding":                                     # frame 5 of item 0 is in no mask
+                c["latent_mask"][0, 5] = 0
+            read = ~((c["obs_mask"].reshape(B, T) == 1) & (c["latent_mask"].reshape(B, T) == 0))     # frames that are not pure observations
+            n_run = int(read.sum()) if obsf != "x_t" and 0 < int(read.sum()) < B * T else 0
+            kw = kwargs_of(c, observed_frames=obsf)
+            x_init = c["x"].cuda().clone()
+            want = plain.begin(x_init, kw, seed=1900 + wi).run().clone().cpu()
+            for ex in (skip, both):
+                ex.begin(x_init, kw, seed=1900 + wi)
+                assert ex.suffix_frames == n_run, (wi, ex.suffix_frames, n_run)
+                got = ex.run().clone().cpu()
+                assert torch.isfinite(got).all()
+                if ex is skip:
+                    assert torch.equal(got[read], want[read]), (extra, wi, obsf, (got[read] - want[read]).abs().max())
+                else:                                                  # the prefix cache folds GroupNorm sums in another fp64 grouping
+                    close(got[read], want[read], atol=2e-6, rtol=2e-6)
+                if n_run:
+                    assert not torch.equal(got[~read], want[~read])    # really skipped
+    model.check_device_errors()
+
+
 def test_window_executor_survives_a_rebound_schedule_and_refuses_interleaving():
     """One model, two diffusions (ddim10, then ddim5, then ddim10 again): vd_set_schedule frees the tables a captured
     graph holds as kernel arguments, so it must drop the graphs; same-size executor buffers land on the same addresses,

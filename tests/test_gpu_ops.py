@@ -694,6 +694,48 @@ def test_upsample_conv_sub_pixel_form_is_fp32_accurate(N, Cin, Cout, H):
     close(tot[..., 1], (o64 * o64).sum((1, 2)).cpu(), atol=1e-3, rtol=1e-5)
 
 
+@pytest.mark.parametrize("H,Cin,Cout,kind", [(8, 128, 128, "ups"), (8, 128, 128, "s1"), (16, 256, 128, "s1"), (16, 128, 128, "ups"),
+                                             (32, 64, 64, "s1"), (32, 32, 128, "s1")])
+def test_conv_frame_subset_and_order_invariance(H, Cin, Cout, kind):
+    """A frame's output AND its GroupNorm partial sums must not depend on which frames share its launch, nor on its place among
+    them: the window suffix skip and the prefix cache run layers on gathered frame subsets and promise the full launch's bits.
+    (Round 4 found the 8x8 kernel's statistics depending on the frame's place in a four-frame item: hipcc had contracted
+    `ss += y * y` into an fma in one unrolled copy of the loop and not in the other.)"""
+    L = _lib.lib()
+    N = 12
+    g = torch.Generator().manual_seed(3)
+    x = dev(torch.rand(N, H, H, Cin, generator=g) - 0.5)
+    w = (torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * (3.0 / (9 * Cin)) ** 0.5
+    b = dev(torch.rand(Cout, generator=g))
+    Ho = 2 * H if kind == "ups" else H
+    if kind == "ups":
+        wp = torch.empty(L.vd_split_image_u16(4 * Cout, 16 * Cin), dtype=torch.int16)
+        _lib.check(L.vd_pack_conv3_wino_ups(_lib.ptr(w.contiguous()), _lib.ptr(wp), Cout, Cin))
+        split = L.vd_conv_ups_stats_split(H)
+    else:
+        wp, split = pack_wino_split(w), L.vd_conv_stats_split(H)
+    wd = dev(wp)
+
+    def run(xx):
+        n = xx.shape[0]
+        out = torch.empty(n, Ho, Ho, Cout, device="cuda")
+        part = torch.zeros(n, split, Cout, 2, dtype=torch.float64, device="cuda")
+        if kind == "ups":
+            _lib.check(L.vd_op_conv_wino_ups(_lib.ptr(xx), Cin, n, H, _lib.ptr(wd), _lib.ptr(b), _lib.ptr(out), Cout, _lib.ptr(part),
+                                             _lib.current_stream()))
+        else:
+            _lib.check(L.vd_op_conv_wino_split(_lib.ptr(xx), Cin, n, H, H, 0, _lib.ptr(wd), _lib.ptr(b), None, None, 0, _lib.ptr(out), Cout,
+                                               _lib.ptr(part), _lib.current_stream()))
+        torch.cuda.synchronize()
+        return out, part
+
+    of, pf = run(x)
+    for sel in ([2, 3, 4, 5, 8, 9, 10, 11], [11, 2, 7, 0, 5], [6], [3, 2, 1, 0, 7, 6, 5, 4, 11, 10, 9]):
+        oc, pc = run(x[sel].contiguous())
+        assert torch.equal(oc, of[sel]), (sel, (oc - of[sel]).abs().max())
+        assert torch.equal(pc, pf[sel]), (sel, (pc - pf[sel]).abs().max())
+
+
 def pack_conv_split(w):
     O, I = w.shape[:2]
     out = torch.empty(_lib.lib().vd_split_image_u16(O, 9 * I), dtype=torch.int16)

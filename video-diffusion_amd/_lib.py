@@ -168,6 +168,8 @@ SIGNATURES = {
     "vd_window_generation": (_U, [_P]),
     "vd_set_window_prefix_cache": (_I, [_P, _I]),
     "vd_window_prefix_frames": (_I, [_P]),
+    "vd_set_window_suffix_skip": (_I, [_P, _I]),
+    "vd_window_suffix_frames": (_I, [_P]),
     "vd_window_begin": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _U, _L, _P]),
     "vd_window_run": (_I, [_P, _I, _P]),
     "vd_window_graphs": (_I, [_P]),

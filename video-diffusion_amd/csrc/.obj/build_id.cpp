@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "cd831a1a1c3fe141"; }
+extern "C" const char* vd_source_sha(void) { return "8f7719b008d10f7a"; }

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(IgemmArgs a, WinoG
                 for (int h = 0; h < (TF4 ? 2 : 1); ++h) {            // TF4: rows 0..7 / 8..15 are two frames
                     float s = 0.f, ss = 0.f;
 #pragma unroll
-                    for (int r = h * (TF4 ? 8 : 0); r < (TF4 ? 8 * h + 8 : 16); ++r) { s += y[r]; ss += y[r] * y[r]; }
+                    for (int r = h * (TF4 ? 8 : 0); r < (TF4 ? 8 * h + 8 : 16); ++r) { s += y[r]; ss = __builtin_fmaf(y[r], y[r], ss); }     // (explicit: see conv_wino_r64.hip)
                     const int fs = TF4 ? 2 * m + h : 0;              // frame slot of the block
                     gsum[fs][n][0] += s; gsum[fs][n][1] += ss;
                 }

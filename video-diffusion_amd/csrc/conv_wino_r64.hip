@@ -497,7 +497,9 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int fs = TF4 ? 2 * m + (r >> 3) : 0;
-                    gsum[fs][0] += y[r]; gsum[fs][1] += y[r] * y[r];
+                    // explicit fma: left to -ffp-contract, hipcc fused the square into the sum in one unrolled copy of this loop
+                    // and not in the other -- a frame's statistics then depended on its place in a four-frame item (r04m)
+                    gsum[fs][0] += y[r]; gsum[fs][1] = __builtin_fmaf(y[r], y[r], gsum[fs][1]);
                 }
             }
         }
@@ -613,8 +615,8 @@ int conv_wino_r64_ksplit(int nfr, int Hl, int Cin, int Cout) {
     return best;
 }
 
-size_t conv_wino_r64_ksplit_floats(int nfr, int Hl, int Cin, int Cout) {
-    const int S = conv_wino_r64_ksplit(nfr, Hl, Cin, Cout);
+size_t conv_wino_r64_ksplit_floats(int nfr, int Hl, int Cin, int Cout, int nfr_sel) {
+    const int S = conv_wino_r64_ksplit(nfr_sel ? nfr_sel : nfr, Hl, Cin, Cout);
     return S > 1 ? (size_t)S * nfr * Hl * Hl * Cout : 0;
 }
 
@@ -660,8 +662,8 @@ int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
     g.xcd_order = g.nbx % 8 == 0;
     // (the grouped cout walk of the sub-pixel form changes nothing here: 2 .. 8 cout blocks per patch, headline 27.55 ms with groups of 0 / 2 / 4)
     // split-K only with scratch from the caller (the engine's arena; the single-operator entry points run one slice)
-    g.ksplit = a.ksplit_ws && a.ksplit_ws_floats >= conv_wino_r64_ksplit_floats(a.nfr, Hl, a.Cin, a.Cout)
-                   ? conv_wino_r64_ksplit(a.nfr, Hl, a.Cin, a.Cout) : 1;
+    g.ksplit = a.ksplit_ws && a.ksplit_ws_floats >= conv_wino_r64_ksplit_floats(a.nfr, Hl, a.Cin, a.Cout, a.nfr_sel)
+                   ? conv_wino_r64_ksplit(a.nfr_sel ? a.nfr_sel : a.nfr, Hl, a.Cin, a.Cout) : 1;
     IgemmArgs k = a;
     if (g.ksplit > 1) {
         k.out = a.ksplit_ws; k.ldo = a.Cout; k.bias = nullptr; k.fbias = nullptr; k.res = nullptr; k.stats = nullptr;

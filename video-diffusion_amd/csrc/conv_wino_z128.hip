@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
             for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)y[r]), osrc, oo[m][r], nso, 0);
             if (a.stats) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { gsum[0] += y[r]; gsum[1] += y[r] * y[r]; }
+                for (int r = 0; r < 16; ++r) { gsum[0] += y[r]; gsum[1] = __builtin_fmaf(y[r], y[r], gsum[1]); }
             }
         }
         if (a.stats) {                                               // GroupNorm partial sums of the output (conv_wino_r64.hip)
@@ -379,7 +379,7 @@ bool conv_wino_z128_shape(int nfr, int H, int Cin, int Cout) {
 }
 
 bool conv_wino_z128_supported(const IgemmArgs& a) {
-    return conv_wino_r64_supported(a) && a.ups == 0 && !a.ups_phase && conv_wino_z128_shape(a.nfr, a.Hs, a.Cin, a.Cout);
+    return conv_wino_r64_supported(a) && a.ups == 0 && !a.ups_phase && conv_wino_z128_shape(a.nfr_sel ? a.nfr_sel : a.nfr, a.Hs, a.Cin, a.Cout);
 }
 
 int launch_conv_wino_z128(const IgemmArgs& a, hipStream_t s) {

@@ -162,8 +162,8 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     const bool split_gemm = gemm_split_supported(one) || conv_split_supported(one);
     const int cls = wino ? (int)(g.ups_phase ? PC_CONV_WINO_R64_UPS : conv_wino_z128_supported(one) ? PC_CONV_WINO_Z128
                                                                : conv_wino_r64_supported(one) ? PC_CONV_WINO_R64 : PC_CONV_WINO)
-                    : split_gemm && gemm_split_tile_class(one.M, g.Cout) == 4 ? (int)PC_IGEMM_128x192
-                    : igemm_tile_class(one.M, g.Cout) + (g.ksz == 3 && !split_gemm ? (int)PC_CONV_128x128 : 0);   // 3x3 on the generic kernel
+                    : split_gemm && gemm_split_tile_class(igemm_sel_M(one), g.Cout) == 4 ? (int)PC_IGEMM_128x192
+                    : igemm_tile_class(igemm_sel_M(one), g.Cout) + (g.ksz == 3 && !split_gemm ? (int)PC_CONV_128x128 : 0);   // 3x3 on the generic kernel
     char tag[56];
     snprintf(tag, sizeof(tag), "M=%d N=%d K=%d k%d s%d%s%s%s", g.M, g.Cout, g.Cin, g.ksz, g.stride, g.ups ? " ups" : "",
              g.affA ? " pro" : (g.act ? " act" : ""), g.res ? " res" : "");
@@ -201,6 +201,19 @@ struct PrefixPlan {
     PrefixStore* store = nullptr;
 };
 
+// Window suffix skip (vd_window_begin, opt-in).  Behind the LAST attention layer the network treats frames as independent batch
+// entries again (ResBlocks, Upsample, the output head: unet.py:820-839), and the caller keeps only the latent frames of a window
+// (scripts/video_sample.py:170-186) while an observed frame's sample is replaced by the observation before the network sees it
+// again (unet.py:958-983, modes 'x_0' and 'x_t_minus_1').  A forward with this plan gathers the `n` listed frames (every frame
+// that is not a pure observation) out of the last attention layer's output and out of each skip tensor the remaining decoder
+// blocks read -- rows and GroupNorm partial sums -- runs those blocks and the head on the compact batch, and scatters eps
+// into a zeroed full-size tensor.  Kernel variants are chosen for the full frame count (IgemmArgs::nfr_sel): the listed frames'
+// eps are those of the full forward, bit for bit.
+struct SuffixPlan { int n = 0; const int* list = nullptr; };
+
+// frames a layer call stands for when it runs on a part of them (conv_args -> IgemmArgs::nfr_sel); set around the compact suffix
+static thread_local int g_sel_nfr = 0;
+
 }  // namespace vd
 
 using namespace vd;
@@ -216,6 +229,7 @@ struct vd_engine {
     std::vector<std::vector<Layer>> input_blocks, output_blocks;
     std::vector<Layer> middle;
     int n_before_attn = 0, pos_res = 0, pos_ch = 0, final_ch = 0;
+    int suf_blk = -2, suf_layer = -1;   // last attention layer: output block (-1: none in the decoder, the suffix starts at block 0) and layer in it
     int p_posenc = -1, p_te0w, p_te0b, p_te2w, p_te2b, p_outgw, p_outgb, p_outw, p_outb;
     size_t film_w_off = 0, film_b_off = 0, te_w_off = 0, te_b_off = 0;
     int film_total = 0, te_total = 0;
@@ -234,6 +248,7 @@ struct vd_engine {
     float* d_tmap = nullptr; float rescale = 1.f;
     // workspace: activations of one (B, T) window [0, ws_tail), then t_model [B] and the eps scratch
     char* ws = nullptr; size_t ws_cap = 0;
+    bool ws_suf = false;
     int ws_B = 0, ws_T = 0; size_t ws_tail = 0;      // the window shape ws_tail was computed for (dry run of the topology)
     std::unordered_map<long long, size_t> ws_peaks;  // (B << 32 | T) -> arena peak
     // ---- use_gradient_method: second packed image (backward-data weights) + the tape of the guided step's forward
@@ -248,7 +263,7 @@ struct vd_engine {
     double* d_part = nullptr; size_t part_cap = 0;   // NLL partial sums
     // ---- window executor (vd_window_*): device-resident step state + one captured graph per window signature
     struct WinKey {
-        int B, T, obs_mode, sampler, clip; float eta;
+        int B, T, obs_mode, sampler, clip, flags; float eta;      // flags: 1 prefix cache, 2 suffix skip
         const void *x, *obs_src, *obs, *lat, *km, *fidx;
         bool operator==(const WinKey& o) const { return std::memcmp(this, &o, sizeof(WinKey)) == 0; }
     };
@@ -256,11 +271,12 @@ struct vd_engine {
         WinKey key; hipGraph_t graph; hipGraphExec_t exec;
         // window prefix cache: which frames are step-invariant (part of the signature: the compact batch size is baked into the
         // captured launches), the two device lists and the persistent tensors the captured step reads and writes
-        std::vector<unsigned char> inv; int n_inv = 0;
+        std::vector<unsigned char> inv; int n_inv = 0, n_suf = 0;   // n_suf: frames the suffix runs on (0: all of them)
         int* d_lists = nullptr;                  // [n_act active frames | n_inv invariant frames]
         PrefixStore* store = nullptr;
     };
     bool prefix_cache_on = false;                // vd_set_window_prefix_cache
+    bool suffix_skip_on = false;                 // vd_set_window_suffix_skip
     static void free_graph(WinGraph& g) {
         (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph);
         if (g.d_lists) (void)hipFree(g.d_lists);
@@ -333,7 +349,7 @@ struct vd_engine {
     }
 
     int build();
-    int forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixPlan* pp = nullptr);
+    int forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixPlan* pp = nullptr, const SuffixPlan* sp = nullptr);
     int ensure_ws(int B, int T);
     int res_block(const ResP& r, Tens x0, const Tens* x1, int N, const float* film_all, const float* emb_unused,
                   hipStream_t st, Arena& ar, Tens* out);
@@ -499,6 +515,10 @@ int vd_engine::build() {
             output_blocks.push_back(blk);
         }
     }
+    suf_blk = -1; suf_layer = -1;
+    for (size_t i = 0; i < output_blocks.size(); ++i)
+        for (size_t l = 0; l < output_blocks[i].size(); ++l)
+            if (output_blocks[i][l].type == 2) { suf_blk = (int)i; suf_layer = (int)l; }
     final_ch = ch;
     p_outgw = add("out.0.weight", {ch}); p_outgb = add("out.0.bias", {ch});
     const int oc = cfg.learn_sigma ? 6 : 3;                                                    // script_util.py:129-131
@@ -665,9 +685,10 @@ static double* stats_table(Arena& ar, int N, int Hout, int Cout, int* split) {
 // request over every batch 1..N: the prefix-cache forward runs the same layer on a compact batch (fewer frames = a smaller
 // grid = possibly MORE slices), and the arena must hold that too
 static size_t ksplit_scratch(const Arena& ar, int N, int H, int cin, int cout) {
-    if (!ar.dry) return conv_wino_r64_ksplit_floats(N, H, cin, cout);
+    if (!ar.dry) return conv_wino_r64_ksplit_floats(N, H, cin, cout, g_sel_nfr);
     size_t m = 0;
     for (int n = 1; n <= N; ++n) m = std::max(m, conv_wino_r64_ksplit_floats(n, H, cin, cout));
+    for (int n = 1; n <= N; ++n) m = std::max(m, conv_wino_r64_ksplit_floats(n, H, cin, cout, N));     // a compact suffix: slices chosen for N frames
     return m;
 }
 
@@ -676,6 +697,7 @@ static IgemmArgs conv_args(Tens x0, const Tens* x1, int N, int ksz, int stride, 
     g.src0 = x0.p; g.C0 = x0.C; g.Cin = x0.C;
     if (x1) { g.src1 = x1->p; g.Cin += x1->C; }
     g.nfr = N; g.Hs = x0.H; g.Ws = x0.H; g.ups = ups; g.stride = stride; g.pad = ksz == 3 ? 1 : 0; g.ksz = ksz;
+    g.nfr_sel = g_sel_nfr;
     const int Hl = x0.H << ups;
     g.Ho = g.Wo = (Hl + 2 * g.pad - ksz) / stride + 1;
     g.M = N * g.Ho * g.Wo;
@@ -701,7 +723,8 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     if (r.skw >= 0 && !no_side) {
         gsk = conv_args(x0, x1, N, 1, 1, 0);
         set_w(gsk, r.skw); gsk.Cout = r.cout; gsk.ldo = r.cout; gsk.side_hw = HW;
-        IgemmArgs one = gsk; one.nfr = std::max(1, std::min(N, igemm_frames_per_launch(gsk))); one.M = one.nfr * HW;
+        IgemmArgs one = gsk; one.nfr = std::max(1, std::min(N, igemm_frames_per_launch(gsk)));
+        one.M = (g_sel_nfr ? std::max(g_sel_nfr, one.nfr) : one.nfr) * HW;                     // (the tile class is chosen for the whole layer call)
         one.wfrag = one.wfrag ? one.wfrag : reinterpret_cast<const float*>(0x1000);      // dry run: no weight image yet, the shape decides
         fuse_skip = params[r.skw].kind == PK_LINF && split_math() && gemm_split_side_supported(one);
     }
@@ -866,10 +889,12 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
 }
 
 // ------------------------------------------------------------------------------------------ forward
-int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixPlan* pp) {
+int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixPlan* pp, const SuffixPlan* sp) {
     const int B = in.B, T = in.T, N = B * T, S = cfg.image_size, mc = cfg.num_channels;
     int rc;
     VD_REQUIRE(!pp || (!tape && !ar.dry && pp->store && n_before_attn > 0), "prefix plan: executor steps only");
+    VD_REQUIRE(!sp || (!tape && sp->n > 0 && sp->n <= N && (ar.dry || sp->list)), "suffix plan: executor steps only, at least one frame");
+    struct SelGuard { ~SelGuard() { g_sel_nfr = 0; } } sel_guard;      // (every return path leaves the selection hint cleared)
     const int Npre = pp ? pp->n : N;                                 // frames the blocks before the first attention layer run on
     float* x8 = ar.get<float>((size_t)Npre * S * S * STEM_KPAD);    // im2col of the network input
     float* tfr = ar.get<float>(N);
@@ -915,11 +940,12 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
             film = fc;
         }
     }
-    auto run = [&](const std::vector<Layer>& blk, Tens in0, const Tens* in1, Tens* outp) -> int {
+    auto run = [&](const std::vector<Layer>& blk, Tens in0, const Tens* in1, Tens* outp, size_t l0 = 0, size_t l1 = ~(size_t)0) -> int {
         const int N = Nrun;
         Tens cur = in0;
         const Tens* second = in1;
-        for (const Layer& L : blk) {
+        for (size_t li = l0; li < std::min(l1, blk.size()); ++li) {
+            const Layer& L = blk[li];
             Tens nxt{};
             if (L.type == 1) {
                 if ((rc = res_block(res[L.idx], cur, second, N, film, nullptr, st, ar, &nxt))) return rc;
@@ -1008,31 +1034,74 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
         }
     }
     if ((rc = run(middle, h, nullptr, &h))) return rc;
+    // window suffix skip: from behind the last attention layer on, the listed frames only
+    const int Nsuf = sp ? sp->n : N;
+    bool compact = false;
+    auto gather_t = [&](const Tens& t) -> Tens {                      // rows and GroupNorm partial sums of the listed frames
+        const size_t per = (size_t)t.H * t.H * t.C;
+        Tens c{ar.get<float>((size_t)Nsuf * per), t.C, t.H, nullptr, t.split};
+        if (t.part) c.part = ar.get<double>((size_t)Nsuf * t.split * t.C * 2);
+        if (!ar.dry) {
+            if (launch_gather_rows(t.p, sp->list, Nsuf, per, c.p, st)) return Tens{};
+            if (t.part && launch_gather_rows(reinterpret_cast<const float*>(t.part), sp->list, Nsuf, (size_t)t.split * t.C * 4,
+                                             reinterpret_cast<float*>(c.part), st)) return Tens{};
+        }
+        return c;
+    };
+    auto go_compact = [&]() -> int {
+        float* fc = ar.get<float>((size_t)Nsuf * film_total);
+        if (!ar.dry && (rc = launch_gather_rows(film_full, sp->list, Nsuf, film_total, fc, st))) return rc;
+        h = gather_t(h);
+        VD_REQUIRE(ar.dry || h.p, "suffix skip: gather");
+        film = fc; Nrun = Nsuf; g_sel_nfr = N; compact = true;
+        return 0;
+    };
+    if (sp && suf_blk < 0 && (rc = go_compact())) return rc;
     for (size_t i = 0; i < output_blocks.size(); ++i) {
         Tens skip = hs.back(); hs.pop_back();
-        if ((rc = run(output_blocks[i], h, &skip, &h))) return rc;      // cat([h, hs.pop()]) read in place
+        if (sp && !compact && (int)i == suf_blk) {
+            if ((rc = run(output_blocks[i], h, &skip, &h, 0, suf_layer + 1))) return rc;        // cat([h, hs.pop()]) read in place
+            if ((rc = go_compact())) return rc;
+            if ((rc = run(output_blocks[i], h, nullptr, &h, suf_layer + 1))) return rc;
+            continue;
+        }
+        if (compact) { skip = gather_t(skip); VD_REQUIRE(ar.dry || skip.p, "suffix skip: gather"); }
+        if ((rc = run(output_blocks[i], h, &skip, &h))) return rc;
     }
     float *A, *Bf, *mrh = nullptr;
-    if ((rc = gn_fold(h, nullptr, N, p_outgw, p_outgb, nullptr, 0, st, ar, &A, &Bf, &mrh))) return rc;
+    if ((rc = gn_fold(h, nullptr, Nrun, p_outgw, p_outgb, nullptr, 0, st, ar, &A, &Bf, &mrh))) return rc;
     if (tape) { tape->head = h; tape->headA = A; tape->headB = Bf; tape->head_mr = mrh; }
+    const int oc = cfg.learn_sigma ? 6 : 3;
+    float* eps_c = compact ? ar.get<float>((size_t)Nsuf * oc * S * S) : nullptr;
     if (!ar.dry) {
         VD_REQUIRE(h.H == S && h.C == final_ch, "output head shape");
-        { ProfScope ps(PC_OUT_CONV, 2.0 * N * S * S * h.C * 27.0, 4.0 * N * S * S * (h.C + 3.0), st);
-          rc = launch_out_conv(h.p, A, Bf, W(p_outw), W(p_outb), N, S, S, h.C, cfg.learn_sigma ? 6 : 3, in.eps, st); }
+        { ProfScope ps(PC_OUT_CONV, 2.0 * Nrun * S * S * h.C * 27.0, 4.0 * Nrun * S * S * (h.C + 3.0), st);
+          rc = launch_out_conv(h.p, A, Bf, W(p_outw), W(p_outb), Nrun, S, S, h.C, oc, compact ? eps_c : in.eps, st); }
         if (rc) return rc;
+        if (compact) {                                               // the other frames' eps: zeros (their samples stay finite; nobody reads them)
+            VD_HIP(hipMemsetAsync(in.eps, 0, (size_t)N * oc * S * S * sizeof(float), st));
+            if ((rc = launch_scatter_rows(eps_c, sp->list, Nsuf, (size_t)oc * S * S, in.eps, st))) return rc;
+        }
     }
     VD_REQUIRE(!ar.overflow, "workspace overflow: the forward asked for more than the dry run measured (this step's output is invalid)");
     return 0;
 }
 
 int vd_engine::ensure_ws(int B, int T) {
-    if (B == ws_B && T == ws_T && ws) return 0;      // the common case: every step of a window
-    const long long key = ((long long)B << 32) | (unsigned)T;
+    if (B == ws_B && T == ws_T && ws && ws_suf == suffix_skip_on) return 0;      // the common case: every step of a window
+    // with the window suffix skip enabled the arena also holds the gathered skip tensors: sized for the worst list (every frame)
+    const long long key = ((long long)B << 32) | (unsigned)T | (suffix_skip_on ? 1ll << 61 : 0);
     auto it = ws_peaks.find(key);
     if (it == ws_peaks.end()) {
         Arena dry; dry.dry = true;
         FwdIn fi{}; fi.B = B; fi.T = T;
         int rc = forward(fi, nullptr, dry);
+        if (!rc && suffix_skip_on) {
+            Arena dry2; dry2.dry = true;
+            SuffixPlan wp; wp.n = B * T;
+            rc = forward(fi, nullptr, dry2, nullptr, &wp);
+            dry.peak = std::max(dry.peak, dry2.peak);
+        }
         if (rc) return rc;
         it = ws_peaks.emplace(key, dry.peak).first;
     }
@@ -1049,7 +1118,7 @@ int vd_engine::ensure_ws(int B, int T) {
         VD_HIP(hipMalloc(reinterpret_cast<void**>(&ws), need));
         ws_cap = need;
     }
-    ws_B = B; ws_T = T; ws_tail = tail;
+    ws_B = B; ws_T = T; ws_tail = tail; ws_suf = suffix_skip_on;
     return 0;
 }
 
@@ -1547,7 +1616,7 @@ static int step_launches(vd_engine* e, int mode, int B, int T, const float* x, c
                          const float* lat, const float* km, const long long* fidx, const long long* t, int obs_mode,
                          int clip, float eta, const float* noise, unsigned long long seed, unsigned long long offset,
                          const unsigned long long* rng, float* sample, float* xstart, float* mean, float* eps_out,
-                         hipStream_t st, const PrefixPlan* pp = nullptr) {
+                         hipStream_t st, const PrefixPlan* pp = nullptr, const SuffixPlan* sp = nullptr) {
     int rc;
     // every sampler entry point comes through here (vd_p_sample / vd_ddim_sample / vd_p_mean_variance / the window executor): a
     // 6-channel network output must never reach the 3-channel posterior kernel
@@ -1560,7 +1629,7 @@ static int step_launches(vd_engine* e, int mode, int B, int T, const float* x, c
                        e->rescale, B, e->num_timesteps, tm, e->d_err);
     Arena ar; ar.base = e->ws; ar.cap = e->ws_tail;                   // the activations end where t_model and the eps scratch begin
     FwdIn fi{B, T, x, obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
-    if ((rc = e->forward(fi, st, ar, pp))) return rc;
+    if ((rc = e->forward(fi, st, ar, pp, sp))) return rc;
     PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
                      mode, eta, seed, offset, sample, xstart, mean, rng};
     if (e->mean_type == 1) pa.x0_given = eps;        // START_X: pred_xstart = process_xstart(model_output) (gaussian_diffusion.py:326-341)
@@ -1700,7 +1769,12 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     const int N = B * T;
     std::vector<unsigned char> inv;
     int n_inv = 0;
-    if (e->prefix_cache_on && obs_mode == 0 && e->cfg.cond_emb_type == 0 && e->n_before_attn > 0) {
+    // window suffix skip (opt-in): the same frames -- pure observations -- are not read back by the caller and re-enter the
+    // network as the observation ('x_0', 'x_t_minus_1'; NOT 'x_t', where an observed frame's input is its own running sample):
+    // everything behind the last attention layer runs without them
+    const bool use_pre = e->prefix_cache_on && obs_mode == 0 && e->cfg.cond_emb_type == 0 && e->n_before_attn > 0;
+    const bool want_suf = e->suffix_skip_on && obs_mode != 1 && e->cfg.cond_emb_type == 0 && e->suf_blk >= -1 && !e->attn.empty();
+    if (use_pre || want_suf) {
         std::vector<float> hm(2 * (size_t)N);
         VD_HIP(hipMemcpyAsync(hm.data(), obs, N * sizeof(float), hipMemcpyDeviceToHost, st));
         VD_HIP(hipMemcpyAsync(hm.data() + N, lat, N * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1709,6 +1783,8 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
         for (int n = 0; n < N; ++n) { inv[n] = hm[n] == 1.f && hm[N + n] == 0.f; n_inv += inv[n]; }
         if (n_inv == 0) inv.clear();
     }
+    const bool pre_on = use_pre && n_inv > 0, suf_on = want_suf && n_inv > 0 && n_inv < N;
+    key.flags = (pre_on ? 1 : 0) | (suf_on ? 2 : 0);
     auto build_pass = [&](vd_engine::WinGraph& g) -> int {               // the invariant frames' prefix, eagerly, into the store
         float* tm = reinterpret_cast<float*>(e->ws + e->ws_tail);
         float* eps = reinterpret_cast<float*>(e->ws + e->ws_tail + (((size_t)B * sizeof(float) + 255) & ~(size_t)255));
@@ -1726,7 +1802,7 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     for (size_t i = 0; i < e->win_graphs.size(); ++i)
         if (e->win_graphs[i].key == key && e->win_graphs[i].inv == inv) {
             e->win_cur = (int)i;
-            return n_inv ? build_pass(e->win_graphs[i]) : 0;           // same buffers, possibly new contents: the cache is per window
+            return pre_on ? build_pass(e->win_graphs[i]) : 0;          // same buffers, possibly new contents: the cache is per window
         }
     // A new signature.  Everything a launch needs lazily (kernel attributes, CU count, the workspace) is set up by one
     // eager forward into the eps scratch before the capture; x is not touched by it.
@@ -1748,15 +1824,19 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     vd_engine::WinGraph wg{};
     wg.key = key; wg.inv = inv; wg.n_inv = n_inv;
     PrefixPlan plan;
-    if (n_inv) {
+    SuffixPlan splan;
+    if (pre_on || suf_on) {
         std::vector<int> lists;
         for (int n = 0; n < N; ++n) if (!inv[n]) lists.push_back(n);
         for (int n = 0; n < N; ++n) if (inv[n]) lists.push_back(n);
         VD_HIP(hipMalloc(reinterpret_cast<void**>(&wg.d_lists), N * sizeof(int)));
+        VD_HIP(hipMemcpy(wg.d_lists, lists.data(), N * sizeof(int), hipMemcpyHostToDevice));
+        wg.n_suf = suf_on ? N - n_inv : 0;
+        splan.n = N - n_inv; splan.list = wg.d_lists;
+    }
+    if (pre_on) {
         wg.store = new PrefixStore();
-        rc = (int)hipMemcpy(wg.d_lists, lists.data(), N * sizeof(int), hipMemcpyHostToDevice);
-        if (rc) set_error("prefix cache: frame lists");
-        if (!rc) rc = build_pass(wg);
+        rc = build_pass(wg);
         if (!rc && hipStreamSynchronize(st) != hipSuccess) { set_error("prefix cache: first pass"); rc = -2; }
         if (rc) { g_prof.on = prof; wg.graph = nullptr; wg.exec = nullptr; if (wg.d_lists) (void)hipFree(wg.d_lists);
                   for (float* p : wg.store->tens) if (p) (void)hipFree(p); for (double* p : wg.store->parts) if (p) (void)hipFree(p); delete wg.store; return rc; }
@@ -1766,7 +1846,7 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     rc = obs_mode == 2 ? launch_q_sample_prev(obs_src, reinterpret_cast<const int64_t*>(e->d_win_t), e->d_tab, e->num_timesteps, B, (long)per,
                                               e->d_win_rng, (unsigned long long)B * per / 2, e->d_win_xtm1, st) : 0;
     if (!rc) rc = step_launches(e, sampler, B, T, x, net_obs_src, obs, lat, km, fidx, e->d_win_t, obs_mode, clip, eta, nullptr, 0, 0,
-                                e->d_win_rng, x, nullptr, nullptr, nullptr, st, n_inv ? &plan : nullptr);
+                                e->d_win_rng, x, nullptr, nullptr, nullptr, st, pre_on ? &plan : nullptr, suf_on ? &splan : nullptr);
     if (!rc) {
         hipLaunchKernelGGL(win_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->d_win_t, e->d_win_rng, B,
                            (unsigned long long)B * per);
@@ -1809,7 +1889,18 @@ int vd_set_window_prefix_cache(vd_engine* e, int on) {
 
 int vd_window_prefix_frames(vd_engine* e) {
     VD_REQUIRE(e, "null engine");
-    return e->win_cur >= 0 ? e->win_graphs[e->win_cur].n_inv : 0;
+    return e->win_cur >= 0 && e->win_graphs[e->win_cur].store ? e->win_graphs[e->win_cur].n_inv : 0;
+}
+
+int vd_set_window_suffix_skip(vd_engine* e, int on) {
+    VD_REQUIRE(e, "null engine");
+    e->suffix_skip_on = on != 0;
+    return 0;
+}
+
+int vd_window_suffix_frames(vd_engine* e) {
+    VD_REQUIRE(e, "null engine");
+    return e->win_cur >= 0 ? e->win_graphs[e->win_cur].n_suf : 0;
 }
 
 unsigned long long vd_window_generation(vd_engine* e) { return e ? e->win_gen : 0; }

@@ -418,7 +418,7 @@ bool gemm_split_supported(const IgemmArgs& a) {
 }
 
 bool gemm_split_side_supported(const IgemmArgs& a) {
-    return gemm_split_supported(a) && a.act == 0 && a.zcount <= 1 && gemm_split_tile_class(a.M, a.Cout) == 0 &&
+    return gemm_split_supported(a) && a.act == 0 && a.zcount <= 1 && gemm_split_tile_class(igemm_sel_M(a), a.Cout) == 0 &&
            a.side_hw > 0 && a.side_hw % 128 == 0 && a.M % a.side_hw == 0;
 }
 
@@ -465,7 +465,7 @@ int gemm_split_stats_rows(int M, int Cout) {
 }
 
 int launch_gemm_split(const IgemmArgs& a, int tile_class, hipStream_t s) {
-    if (tile_class == 0) tile_class = gemm_split_tile_class(a.M, a.Cout);
+    if (tile_class == 0) tile_class = gemm_split_tile_class(igemm_sel_M(a), a.Cout);
     if (a.stats) {
         const int rows = tile_class == 2 || tile_class == 3 ? 32 : 64;
         VD_REQUIRE(a.zcount <= 1 && a.stats_hw > 0 && a.stats_hw % rows == 0 && a.M % a.stats_hw == 0 &&

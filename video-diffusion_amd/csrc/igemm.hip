@@ -206,14 +206,14 @@ static int launch_igemm_one(const IgemmArgs& a, hipStream_t s) {
         VD_REQUIRE(conv_wino_r64_supported(a), "sub-pixel Upsample conv: shape not covered by conv_wino_r64.hip");
         return launch_conv_wino_r64(a, s);
     }
-    if (gemm_split_supported(a) || conv_split_supported(a)) return launch_gemm_split(a, igemm_tile_class(a.M, a.Cout), s);
+    if (gemm_split_supported(a) || conv_split_supported(a)) return launch_gemm_split(a, igemm_tile_class(igemm_sel_M(a), a.Cout), s);
     if (conv_wino_z128_supported(a)) return launch_conv_wino_z128(a, s);
     if (conv_wino_r64_supported(a)) return launch_conv_wino_r64(a, s);
     VD_REQUIRE(!a.wsplit, "split weight image given for a shape the split kernels do not cover");
-    if (gemm_frag_supported(a)) return launch_gemm_frag(a, igemm_tile_class(a.M, a.Cout), s);
+    if (gemm_frag_supported(a)) return launch_gemm_frag(a, igemm_tile_class(igemm_sel_M(a), a.Cout), s);
     if (conv_wino_supported(a)) return launch_conv_wino(a, s);
     VD_REQUIRE(a.w != nullptr, "this shape runs on the generic kernel and needs [tap][Cout][Cin] weights");
-    switch (igemm_tile_class(a.M, a.Cout)) {
+    switch (igemm_tile_class(igemm_sel_M(a), a.Cout)) {
         case 0: return launch_t<128, 128>(a, s);
         case 1: return launch_t<128, 64>(a, s);
         case 2: return launch_t<64, 128>(a, s);
@@ -256,6 +256,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     for (int f0 = 0; f0 < a.nfr; f0 += per) {
         IgemmArgs b = a;
         b.nfr = std::min(per, a.nfr - f0);
+        b.nfr_sel = a.nfr_sel ? a.nfr_sel : a.nfr;
         b.M = b.nfr * a.Ho * a.Wo;
         b.src0 = a.src0 + (size_t)f0 * HWi * a.C0;
         if (a.src1) b.src1 = a.src1 + (size_t)f0 * HWi * (a.Cin - a.C0);

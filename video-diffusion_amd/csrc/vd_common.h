@@ -39,6 +39,9 @@ struct IgemmArgs {
     int C0, Cin;
     int nfr, Hs, Ws;     // stored source dims
     int ups;             // 1: source is read through a nearest x2 upsample (unet.py:69)
+    int nfr_sel = 0;     // frames of the WHOLE layer call when this launch is a part of one (a frame range of a big window, the compact batch
+                         // of a window suffix): kernel variants that are chosen by grid size (split-K, conv_wino_z128.hip) are chosen for it,
+                         // so a frame's arithmetic does not depend on which other frames share its launch.  0: nfr
     int ups_phase = 0;   // with ups = 1: wwino holds the sub-pixel image (pack_conv3_wino_ups); conv_wino_r64.hip
     // gemm_split.hip, 1x1 over a (virtually concatenated) input, 128x128 tile: the column blocks 0 also write
     // side[m][k] = SiLU(A[m][k] * sideA[frame][k] + sideB[frame][k]) -- the GroupNorm(+FiLM)+SiLU image the ResBlock's first
@@ -109,6 +112,8 @@ int launch_gemm_frag(const IgemmArgs& a, int tile_class, hipStream_t s);
 void pack_linear_frag(const float* w, float* out_base, int rows, int K, int n_total, int row0);
 // Winograd F(2x2,3x3) path (conv_wino.hip): 2.25x fewer MFMAs than the direct 3x3 kernels
 bool conv_wino_supported(const IgemmArgs& a);
+// rows of the whole layer call a launch belongs to (IgemmArgs::nfr_sel): what the tile classes are chosen for
+inline int igemm_sel_M(const IgemmArgs& a) { return a.nfr_sel > a.nfr ? a.nfr_sel * a.Ho * a.Wo : a.M; }
 int conv_wino_stats_split(int Hout);
 // ---- exact three-way bf16 split of a pair of fp32 values (conv_wino_r64.hip, VD_MATH=bf16x6), plain VALU only: v_pk_*_f32
 // and v_dot2c_f32_bf16 do not overlap the bf16 MFMA (tools/mfma_bf16_coissue.hip).  Every piece is rounded to NEAREST
@@ -207,7 +212,7 @@ int launch_conv_wino_z128(const IgemmArgs& a, hipStream_t s);
 void pack_conv3_wino_ups(const float* oihw, unsigned short* out, int O, int I);     // image of 4*O phase kernels
 int conv_wino_ups_stats_split(int Hs);
 int conv_wino_r64_ksplit(int nfr, int Hl, int Cin, int Cout);            // slices of the channel loop a small grid is cut into (1: none)
-size_t conv_wino_r64_ksplit_floats(int nfr, int Hl, int Cin, int Cout);  // floats of scratch the caller then provides in ksplit_ws
+size_t conv_wino_r64_ksplit_floats(int nfr, int Hl, int Cin, int Cout, int nfr_sel = 0);  // floats of scratch the caller then provides in ksplit_ws (slices chosen for nfr_sel frames)
 bool gemm_split_supported(const IgemmArgs& a);
 bool gemm_split_side_supported(const IgemmArgs& a);   // IgemmArgs::side (the ResBlock's activation image from the skip conv's A tiles)            // fp32-accurate GEMM on the bf16 matrix cores (gemm_split.hip)
 bool conv_split_supported(const IgemmArgs& a);          // 3x3, stride 1|2: the same kernel over an implicit im2col A

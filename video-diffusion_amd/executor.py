@@ -23,12 +23,16 @@ _OBS_MODES = {"x_0": 0, "x_t": 1, "x_t_minus_1": 2}
 
 
 class WindowExecutor:
-    def __init__(self, model, diffusion, prefix_cache=False):
+    def __init__(self, model, diffusion, prefix_cache=False, suffix_skip=False):
         """prefix_cache: compute the observed frames' activations before the first attention layer once per window instead
-        of once per step ('x_0' mode, cond_emb_type='channel'; include/vd_amd.h: vd_set_window_prefix_cache)."""
+        of once per step ('x_0' mode, cond_emb_type='channel'; include/vd_amd.h: vd_set_window_prefix_cache).
+        suffix_skip: run everything behind the last attention layer without the purely observed frames ('x_0' and
+        'x_t_minus_1'; vd_set_window_suffix_skip): the other frames' samples are those of the full step, the observed frames'
+        entries of the returned window are meaningless (infer_video keeps only the latent frames, video_sample.py:170-186)."""
         self.model = diffusion._bind(model)
         self.diffusion = diffusion
         self.prefix_cache = bool(prefix_cache)
+        self.suffix_skip = bool(suffix_skip)
         self.stream = th.cuda.Stream(device=self.model.device)        # a capture needs a non-default stream
         self._bufs = {}
         self.x = None
@@ -75,6 +79,7 @@ class WindowExecutor:
                 t_start = self.diffusion.num_timesteps - 1
             obs_src = bufs["x"] if mode == "x_t" else bufs["obs_src"]
             _lib.check(_lib.lib().vd_set_window_prefix_cache(self.model._handle, 1 if self.prefix_cache else 0))
+            _lib.check(_lib.lib().vd_set_window_suffix_skip(self.model._handle, 1 if self.suffix_skip else 0))
             _lib.check(_lib.lib().vd_window_begin(
                 self.model._handle, B, T, _lib.ptr(bufs["x"]), _lib.ptr(obs_src), _lib.ptr(bufs["obs_mask"]),
                 _lib.ptr(bufs["latent_mask"]), _lib.ptr(bufs["kinda_marg_mask"]), _lib.ptr(bufs["frame_indices"]),
@@ -108,6 +113,11 @@ class WindowExecutor:
     def cached_frames(self):
         """Frames of the armed window whose prefix activations come from the cache (0: cache off or nothing observed)."""
         return int(_lib.lib().vd_window_prefix_frames(self.model._handle))
+
+    @property
+    def suffix_frames(self):
+        """Frames the armed window's suffix (everything behind the last attention layer) runs on (0: all of them)."""
+        return int(_lib.lib().vd_window_suffix_frames(self.model._handle))
 
     @property
     def graphs(self):

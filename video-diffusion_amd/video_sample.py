@@ -40,7 +40,7 @@ def get_masks(x0, num_obs):
 @torch.no_grad()
 def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size=1, optimal_schedule_path=None, *,
                 use_gradient_method=False, observed_frames="x_0", sampler="p_sample", eta=0.0, executor="eager",
-                adaptive_distance="lpips", prefix_cache=False):
+                adaptive_distance="lpips", prefix_cache=False, suffix_skip=False):
     """video_sample.py:50-190.  Returns (samples ndarray (B,T,C,H,W), None).
 
     'adaptive-*' modes (:74,94-95,104-118,176-183): the strategy sees the current samples before every window and hands
@@ -54,7 +54,9 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
     at the headline window, profiles/r03a_*), so the graph is an option -- a host too slow to stay ahead, one launch per
     step to trace -- not the default.  `prefix_cache` (graph executor, 'x_0' mode): the observed frames' activations before
     the first attention layer once per window instead of once per step (executor.py; 2.6 % at 4 observed frames of 16, 12 %
-    at 10 of 20, profiles/r03x_*)."""
+    at 10 of 20, profiles/r03x_*).  `suffix_skip` (graph executor, 'x_0' / 'x_t_minus_1'): everything behind the last attention
+    layer runs without the purely observed frames, whose step output this function never reads (write_back keeps the latent
+    frames only); the latent frames are those of the full step (executor.py, include/vd_amd.h: vd_set_window_suffix_skip)."""
     adaptive = "adaptive" in mode
     B, T, C, H, W = batch.shape
     device = model.device
@@ -71,8 +73,8 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
     if use_graph:
         from .executor import WindowExecutor
         wex = getattr(model, "_window_executor", None)
-        if wex is None or wex.diffusion is not diffusion or wex.prefix_cache != bool(prefix_cache):
-            wex = model._window_executor = WindowExecutor(model, diffusion, prefix_cache=prefix_cache)
+        if wex is None or wex.diffusion is not diffusion or wex.prefix_cache != bool(prefix_cache) or wex.suffix_skip != bool(suffix_skip):
+            wex = model._window_executor = WindowExecutor(model, diffusion, prefix_cache=prefix_cache, suffix_skip=suffix_skip)
     while True:
         if adaptive:
             schedule.set_videos(samples)
@@ -201,6 +203,9 @@ def main(argv=None):
                     help="adaptive-* modes: frame embedding for the farthest-point selection (lpips needs set_lpips_embedder)")
     ap.add_argument("--executor", default="eager", choices=["graph", "eager"],
                     help="eager: one p_sample call per step (default); graph: one captured hipGraph per window shape (executor.py)")
+    ap.add_argument("--suffix_skip", type=str2bool, nargs="?", const=True, default=False,
+                    help="with --executor graph and observed_frames x_0 / x_t_minus_1: run the network behind its last attention layer "
+                         "on the non-observed frames only")
     ap.add_argument("--prefix_cache", type=str2bool, nargs="?", const=True, default=False,
                     help="with --executor graph and observed_frames x_0: compute the observed frames' encoder prefix once per window")
     ap.add_argument("--eval_dir", default=None,
@@ -249,7 +254,8 @@ def run(args, create=None, device=None):
         batch = torch.rand(len(idx), args.T, 3, args.image_size, args.image_size, generator=g) * 2 - 1
         recon, _ = infer_video(args.inference_mode, model, diffusion, batch, args.max_frames, args.obs_length,
                                args.step_size, observed_frames=args.observed_frames, executor=args.executor,
-                               adaptive_distance=args.adaptive_distance, prefix_cache=getattr(args, "prefix_cache", False))
+                               adaptive_distance=args.adaptive_distance, prefix_cache=getattr(args, "prefix_cache", False),
+                               suffix_skip=getattr(args, "suffix_skip", False))
         for p in save_samples(recon, str(out_dir), first_index=idx[0], sample_idx=args.sample_idx):
             logger.info(f"*** Saved {p} ***")
     vdist.barrier()
