@@ -70,6 +70,9 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #else
 #define R64_STAMP(i)
 #endif
+#ifndef VD_R64_B2REG
+#define VD_R64_B2REG 1     // f16x3: the third weight piece 2^-12 b0 formed in registers (conv_wino_z128.hip) instead of loaded (A/B: 0)
+#endif
 #ifndef VD_R64_ABL
 #define VD_R64_ABL 0       // timing-only builds of the main loop (results WRONG; tools/build_variant.sh): bit 0 no weight reloads, 1 no
 #endif                     // transform / split, 2 no patch requests, 3 no patch reads, 4 no MFMA -- never set in the product library
@@ -275,7 +278,15 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     u32x4 bfr[4][2][3];
     // (n, piece) offsets 0 .. 3072 ride in the instruction's 12-bit immediate, the last two behind a second scalar base: two
     // scalar adds per position instead of six (every instruction of a one-wave-per-SIMD stream is an issue slot)
+    constexpr bool B2R = F16 && VD_R64_B2REG;                        // piece 2 = 2^-12 x piece 0: four v_pk_mul_f16 instead of a 1 KiB load
+    const unsigned two_m12 = 0x0c000c00u;
+    auto b_third = [&](int j, int n) {
+        asm("v_pk_mul_f16 %0, %4, %8\n\tv_pk_mul_f16 %1, %5, %8\n\tv_pk_mul_f16 %2, %6, %8\n\tv_pk_mul_f16 %3, %7, %8"
+            : "=&v"(bfr[j][n][2][0]), "=&v"(bfr[j][n][2][1]), "=&v"(bfr[j][n][2][2]), "=&v"(bfr[j][n][2][3])
+            : "v"(bfr[j][n][0][0]), "v"(bfr[j][n][0][1]), "v"(bfr[j][n][0][2]), "v"(bfr[j][n][0][3]), "s"(two_m12));
+    };
     auto b_load_one = [&](int chunk, int j, int n, int p) {
+        if (B2R && p == 2) return;
         const int idx = n * 3 + p, so = chunk * ustride + bsb + j * bstep;
         bfr[j][n][p] = idx < 4 ? __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane + idx * 1024u, so, 0))
                                : __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(usrc, blane + (idx - 4) * 1024u, so + 4096, 0));
@@ -316,9 +327,10 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                 for (int r = 0; r < 16; ++r)
                     if (j != JS) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[m][j][n][r]));
     __builtin_amdgcn_sched_barrier(0);
-    // every patch requested so far has landed; the (NP - 1) * 6 weight loads may be in flight
-    if constexpr (NP == 4) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    // every patch requested so far has landed; the (NP - 1) * 6 (4: two loads per fragment) weight loads may be in flight
+    if constexpr (NP == 4 && !B2R) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
+    else if constexpr (NP == 4 || !B2R) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");      // (NP - 1) * (6 | 4) weight loads
+    else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (JS < 0 || (JS == 3 ? c < 3 : c > 0)) { t_read(0, 0, c); t_fma(c, 0); t_fma(c, 1); }
@@ -372,8 +384,11 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
 #pragma unroll
                 for (int k = 0; k < NSLOT; ++k) {
                     const int q = k >> 1, n = k & 1;
-                    if (m == 0 && li == NP - 1 && k == 0 && cpar == 0)
-                        asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the 18 youngest requests are weight loads
+                    if (m == 0 && li == NP - 1 && k == 0 && cpar == 0) {
+                        // the 18 (12: two loads per fragment) youngest requests are weight loads
+                        if constexpr (B2R) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    }
                     // the patch requests of the chunk pair, one per slot
                     if (cpar == 1 && !(VD_R64_ABL & 4)) {
                         if constexpr (F16) {
@@ -386,6 +401,7 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                     if (VD_R64_ABL & 16) {}
                     else if constexpr (F16) acc[m][j][n] = r64_mfma<true>(af[cur][PA3[q]], bfr[j][n][PB3[q]], acc[m][j][n]);
                     else acc[m][j][n] = r64_mfma<false>(af[cur][PA6[q]], bfr[j][n][PB6[q]], acc[m][j][n]);
+                    if (B2R && m == 0 && (k == 1 || k == 2)) b_third(j, k - 1);      // first read in slot 4 / 5; the M-tile group m = 1 finds it in place
                     if (VD_R64_ABL & 2) {}
                     else if constexpr (F16) {
                         if (k < 4) f16_slot_a(cur, nxt, k, jn, k == 3);

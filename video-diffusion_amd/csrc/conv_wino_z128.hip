@@ -368,6 +368,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
 static double z128_fill(int items, int cus) { return (double)items / ((double)cus * ((items + cus - 1) / cus)); }
 
 bool conv_wino_z128_shape(int nfr, int H, int Cin, int Cout) {
+#ifdef VD_Z128_OFF                                   // kernel-experiment builds (tools/build_variant.sh): every shape on conv_wino_r64.hip
+    return false;
+#endif
     if (!f16_math() || H < 16 || (H & (H - 1)) || Cout % 128 || Cin % 32 || conv_wino_r64_ksplit(nfr, H, Cin, Cout) != 1) return false;
     static const int cus = [] {
         int dev = 0, n = 0;

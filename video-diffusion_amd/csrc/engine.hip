@@ -582,11 +582,10 @@ static IgemmArgs linear_args(int M, int K, int Nout) {
 // the split GEMM runs it in one launch, its epilogue writes the per-channel partial sums -- allocate the table (also in the
 // arena's dry run) and let the tensor carry it; otherwise the tensor stays without and gn_fold runs a statistics pass
 void vd_engine::gemm_stats_table(Arena& ar, int M, int K, int Nout, Tens* t) {
-    static const bool off = getenv("VD_NO_GEMM_STATS") != nullptr;                  // A/B switch
     IgemmArgs g = linear_args(M, K, Nout);
     g.wfrag = reinterpret_cast<const float*>(this);                                  // any non-null pointer: the shape test only
     const int HW = t->H * t->H, rows = gemm_split_stats_rows(M, Nout);
-    if (off || !gemm_split_supported(g) || igemm_frames_per_launch(g) < M || HW % rows || M % HW) return;
+    if (!gemm_split_supported(g) || igemm_frames_per_launch(g) < M || HW % rows || M % HW) return;
     t->split = HW / rows;
     t->part = ar.get<double>((size_t)(M / HW) * t->split * Nout * 2);
 }
@@ -594,11 +593,10 @@ void vd_engine::gemm_stats_table(Arena& ar, int M, int K, int Nout, Tens* t) {
 // the same for a 3x3 conv that runs on the split GEMM's implicit-im2col mode (the stride-2 Downsample convs): the rows of
 // its output are the Ho x Wo pixels of consecutive frames
 void vd_engine::conv_split_stats_table(Arena& ar, const IgemmArgs& conv, int Cout, Tens* t) {
-    static const bool off = getenv("VD_NO_GEMM_STATS") != nullptr;
     IgemmArgs g = conv;
     g.wfrag = reinterpret_cast<const float*>(this); g.wsplit = split_math(); g.Cout = Cout; g.ldo = Cout; g.res_ld = Cout;
     const int HW = g.Ho * g.Wo, rows = gemm_split_stats_rows(g.M, Cout);
-    if (off || !conv_split_supported(g) || igemm_frames_per_launch(g) < g.nfr || HW % rows) return;
+    if (!conv_split_supported(g) || igemm_frames_per_launch(g) < g.nfr || HW % rows) return;
     t->split = HW / rows;
     t->part = ar.get<double>((size_t)g.nfr * t->split * Cout * 2);
 }
@@ -646,11 +644,8 @@ int vd_engine::gn_fold(const Tens& x0, const Tens* x1, int N, int gw, int gb,
 
 // GroupNorm(+FiLM) + SiLU of a (virtually concatenated) tensor into y in ONE launch: the activation pass folds the statistics
 // itself (norm.hip: affine_act_fold_kernel).  For consumers that need nothing but y; not with a tape (the backward pass reads
-// A, B and mean / rstd).  VD_NO_GN_FOLD_FUSE: A/B switch (decided per process: the arena layout follows it).
-static bool gn_fold_fused() {
-    static const bool off = getenv("VD_NO_GN_FOLD_FUSE") != nullptr;
-    return !off;
-}
+// A, B and mean / rstd).
+static bool gn_fold_fused() { return true; }
 int vd_engine::gn_act(const Tens& x0, const Tens* x1, int N, int gw, int gb, const float* film, int film_ld, int act, float* y,
                       hipStream_t st, Arena& ar) {
     const int HW = x0.H * x0.H, C = x0.C + (x1 ? x1->C : 0);
@@ -716,11 +711,10 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     // The skip convolution (1x1 over the block input, unet.py:159-166) reads the tensor the first GroupNorm+SiLU reads: where
     // it runs on the 128x128 tile of gemm_split.hip its column blocks 0 write that activation image from the rows they stage
     // (IgemmArgs::side) -- the block input, the largest tensor of a decoder block, is read once instead of twice.  Decided by
-    // shape alone (the dry run lays the arena out the same way); VD_NO_SKIP_SIDE: A/B switch.
-    static const bool no_side = getenv("VD_NO_SKIP_SIDE") != nullptr;
+    // shape alone (the dry run lays the arena out the same way).
     IgemmArgs gsk{};
     bool fuse_skip = false;
-    if (r.skw >= 0 && !no_side) {
+    if (r.skw >= 0) {
         gsk = conv_args(x0, x1, N, 1, 1, 0);
         set_w(gsk, r.skw); gsk.Cout = r.cout; gsk.ldo = r.cout; gsk.side_hw = HW;
         IgemmArgs one = gsk; one.nfr = std::max(1, std::min(N, igemm_frames_per_launch(gsk)));

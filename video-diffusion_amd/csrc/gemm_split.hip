@@ -41,6 +41,9 @@ __device__ __forceinline__ f32x16 mfma_piece(u32x4 a, u32x4 b, f32x16 c) {
 #ifndef VD_GS_RING6
 #define VD_GS_RING6 1      // 0: three weight slots for the 64x64 tile too (A/B)
 #endif
+#ifndef VD_GS_B2REG
+#define VD_GS_B2REG 1      // f16x3: the third weight piece 2^-12 b0 formed in registers (four v_pk_mul_f16 per fragment) instead of loaded (A/B: 0)
+#endif
 #ifndef VD_GS_SKIP
 #define VD_GS_SKIP 0       // kernel-experiment builds: bit 0 no weight loads, 1 no A staging, 2 no split VALU (timing only)
 #endif
@@ -188,12 +191,21 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
             if constexpr (!F16) *reinterpret_cast<u32x2*>(d + 2 * PLANE) = p3;
         }
     };
+    // f16x3: piece 2 of a weight fragment is 2^-12 x piece 0 (split_pack.hip) -- exact in fp16 arithmetic, subnormals included -- so it
+    // is not fetched: a third less weight traffic from the L2 (the ablation builds of r04o: the weight loads are 20 % of this kernel)
+    const unsigned two_m12 = 0x0c000c00u;
+    auto b_third = [&](int slot, int j) {
+        if constexpr (F16 && VD_GS_B2REG)
+            asm("v_pk_mul_f16 %0, %4, %8\n\tv_pk_mul_f16 %1, %5, %8\n\tv_pk_mul_f16 %2, %6, %8\n\tv_pk_mul_f16 %3, %7, %8"
+                : "=&v"(bfr[slot][j][2][0]), "=&v"(bfr[slot][j][2][1]), "=&v"(bfr[slot][j][2][2]), "=&v"(bfr[slot][j][2][3])
+                : "v"(bfr[slot][j][0][0]), "v"(bfr[slot][j][0][1]), "v"(bfr[slot][j][0][2]), "v"(bfr[slot][j][0][3]), "s"(two_m12));
+    };
     auto b_load = [&](int slot, int kstep) {      // kstep = global 16-wide k step
         const int so = kstep * ncoblk * 3072;
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < (F16 && VD_GS_B2REG ? 2 : 3); ++p)
                 bfr[slot][j][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p * 1024, so, 0));
     };
     const int aoff = (wm * (BM / 2) + lr) * SROW + lh * 16;
@@ -268,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     // stops spilling: 256 registers + 44 bytes of scratch -> 236, none.)
     auto b_load_one = [&](int slot, int kstep, int idx) {                // idx = j * 3 + p
         const int j = idx / 3, p2 = idx - 3 * j;
+        if (F16 && VD_GS_B2REG && p2 == 2) return;                        // formed from piece 0 by b_third
         bfr[slot][j][p2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p2 * 1024, kstep * ncoblk * 3072, 0));
     };
     auto a_prefetch_one = [&](int chunk, int rs, int j) {
@@ -304,6 +317,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         const int g = 2 * chunk + ks;
         const char* Acur = smem_c + (chunk & 1) * ABUF;
         char* Anext = smem_c + ((chunk + 1) & 1) * ABUF;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b_third(gslot, j);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -453,9 +468,8 @@ static int launch_gs(const IgemmArgs& a, hipStream_t s) {
 // instead of 128 columns, and their grids come out in whole rounds of 2 blocks per CU (N = 1536 at M = 8192: 512 blocks
 // instead of 768; N = 384 at M = 32768: 512 instead of 768)
 int gemm_split_tile_class(int M, int Cout) {
-    static const bool off = getenv("VD_GS_NO192") != nullptr;         // A/B switch
     const int base = igemm_tile_class(M, Cout);
-    if (off || base != 0 || Cout % 192) return base;
+    if (base != 0 || Cout % 192) return base;
     return (long)((M + 127) / 128) * (Cout / 192) >= 384 ? 4 : base;
 }
 

@@ -275,8 +275,6 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
 // Tile choice: big tiles when the grid still fills 256 CUs x 2 blocks, smaller ones otherwise.
 // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
 int igemm_tile_class(int M, int Cout) {
-    static const char* force = getenv("VD_TILE");          // experiment switch for tools/bench_conv.py
-    if (force) return atoi(force);
     const long t128 = (long)((M + 127) / 128) * ((Cout + 127) / 128);
     if (Cout <= 64) return M >= 128 * 512 ? 1 : 3;
     if (t128 >= 512) return 0;
