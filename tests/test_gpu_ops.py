@@ -601,7 +601,7 @@ def test_conv3x3_winograd_split_is_fp32_accurate(N, Cin, Cout, H, ups):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H", [(41, 32, 128, 32), (64, 32, 128, 32), (16, 160, 128, 64), (128, 64, 256, 16), (43, 96, 128, 32),
-                                          (64, 64, 512, 16)])
+                                          (64, 64, 512, 16), (16, 320, 128, 64)])
 def test_conv3x3_winograd_128_cout_blocks(N, Cin, Cout, H):
     """csrc/conv_wino_z128.hip: the same convolution with the column half of the output transform accumulated by the matrix
     pipe (six (position, column) groups of MFMAs instead of four, 128 couts per block, the third weight piece formed in

@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "665eb5580451b407"; }
+extern "C" const char* vd_source_sha(void) { return "071f328f42b4f42d"; }

@@ -360,9 +360,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     Z128_STAMP(15);
 }
 
-// Which of the two kernels a shape gets.  An item here is worth two of conv_wino_r64.hip's (measured r04k, same box, us per launch
-// at 128 frames: 128 -> 128 @ 64^2 435 | 466, 256 -> 256 @ 32^2 357 | 365 - 381, 640 -> 256 @ 32^2 816 | 828; loop 5.5 k cycles per
-// chunk and 128 couts against 2 x 3.0 k, per-item overhead 21 - 25 k cycles against 2 x 15 - 17 k), so it wins where its grid fills
+// Which of the two kernels a shape gets.  An item here is worth two of conv_wino_r64.hip's (loop 5.5 k cycles per chunk and 128
+// couts against 2 x 2.6 - 3.0 k, per-item overhead 21 - 25 k cycles against 2 x 15 - 17 k), so it can win where its grid fills
 // the chip's last round as well as the other one's does -- and loses where halving the item count leaves CUs idle (384 couts at
 // 16^2, 128 frames: 384 items = 1.5 rounds of 256 CUs against 3.0; 200 | 161 us): decided by the fill of the last round.
 static double z128_fill(int items, int cus) { return (double)items / ((double)cus * ((items + cus - 1) / cus)); }
@@ -372,6 +371,10 @@ bool conv_wino_z128_shape(int nfr, int H, int Cin, int Cout) {
     return false;
 #endif
     if (!f16_math() || H < 16 || (H & (H - 1)) || Cout % 128 || Cin % 32 || conv_wino_r64_ksplit(nfr, H, Cin, Cout) != 1) return false;
+    // 1.5 x the MFMAs for half the per-item overhead and half the vector work: pays while the channel loop is short.  Same box,
+    // us per launch, this kernel | conv_wino_r64.hip (r04q, after the latter stopped loading the third weight piece):
+    // 128 -> 128 @ 64^2 411 - 428 | 432 - 451, 256 -> 256 @ 32^2 344 - 356 | 361 - 370, 640 -> 256 @ 32^2 805 | 758 - 774
+    if (Cin > 320) return false;
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
