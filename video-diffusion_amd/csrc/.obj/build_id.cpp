@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "071f328f42b4f42d"; }
+extern "C" const char* vd_source_sha(void) { return "87fce257449bf7c4"; }

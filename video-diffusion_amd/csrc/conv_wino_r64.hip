@@ -327,10 +327,17 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                 for (int r = 0; r < 16; ++r)
                     if (j != JS) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[m][j][n][r]));
     __builtin_amdgcn_sched_barrier(0);
-    // every patch requested so far has landed; the (NP - 1) * 6 (4: two loads per fragment) weight loads may be in flight
-    if constexpr (NP == 4 && !B2R) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
-    else if constexpr (NP == 4 || !B2R) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");      // (NP - 1) * (6 | 4) weight loads
-    else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    // patch 0 has landed in every wave; patches 1, 2 (first read behind the loop's first barrier, which waits for them: 2 * NX requests)
+    // and the (NP - 1) * 6 (4: two loads per fragment) weight loads may be in flight
+    {
+        constexpr int W = 2 * NX + (NP - 1) * (B2R ? 4 : 6);
+        static_assert(W == 20 || W == 24 || W == 28 || W == 30 || W == 34, "wait count of the prologue");
+        if constexpr (W == 20) asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
+        else if constexpr (W == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+        else if constexpr (W == 28) asm volatile("s_waitcnt vmcnt(28)\n\ts_barrier" ::: "memory");
+        else if constexpr (W == 30) asm volatile("s_waitcnt vmcnt(30)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(34)\n\ts_barrier" ::: "memory");
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (JS < 0 || (JS == 3 ? c < 3 : c > 0)) { t_read(0, 0, c); t_fma(c, 0); t_fma(c, 1); }

@@ -204,7 +204,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[z][m][n][r]));
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");     // the three patches have landed in every wave (the 8 youngest requests are weights)
+    // patch 0 has landed in every wave: the 2 * NX + 8 youngest requests are patches 1, 2 (first read behind the loop's first barrier,
+    // which waits for them) and the weights
+    asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
+    static_assert(NX == 6, "the wait count above");
 #pragma unroll
     for (int idx = 0; idx < 16; ++idx) frag_read(0, 0, idx);
 #pragma unroll
