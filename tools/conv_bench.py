@@ -80,7 +80,7 @@ def main():
                             for n in range(2))
             extra = (f"\n      item of block 7 (cycles): prologue {t[1]-t[0]}, loop {t[2]-t[1]} = {(t[2]-t[1]) / (Cin // 16):.0f}/chunk, output transform "
                      f"{t[10]-t[2]} [{ep}]; {(t[10]-t[0]) / max(t[15]-t[14], 1) * 0.1:.2f} GHz")
-        if hasattr(L, "vd_debug_z128_stamps") and not ups and H >= 16 and Cout % 128 == 0 and os.environ.get("VD_CONV_Z128", "1") != "0":
+        if hasattr(L, "vd_debug_z128_stamps") and not ups and L.vd_conv_wino_block_couts(nfr, H, Cin, Cout) == 128:
             st = (ctypes.c_ulonglong * 16)()
             L.vd_debug_z128_stamps.restype = ctypes.c_int
             L.vd_debug_z128_stamps.argtypes = [ctypes.c_void_p]
