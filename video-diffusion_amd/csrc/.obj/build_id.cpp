@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "87fce257449bf7c4"; }
+extern "C" const char* vd_source_sha(void) { return "fe6896cd3f4388c6"; }

@@ -210,6 +210,20 @@ __global__ __launch_bounds__(256) void affine_act_fold_kernel(const float* __res
     const int tid = threadIdx.x;
     const int pl = tid / tpp, c = (tid - pl * tpp) * 4;
     const int C1 = C - C0, cg = C / 32;
+    // the first four rows of this thread are requested BEFORE the fold: all blocks of a launch are resident at once and fold at the
+    // same time -- without this HBM idles for the fold's two dependent round trips at the start of every launch
+    const int p_begin = blockIdx.x * per, p_end = min(HW, p_begin + per);
+    const float* src; int ld;
+    if (c < C0) { src = src0 + (size_t)n * HW * C0 + c; ld = C0; } else { src = src1 + (size_t)n * HW * C1 + (c - C0); ld = C1; }
+    float* dst = y + (size_t)n * HW * C + c;
+    auto ld4 = [&](const float* q) { return (VD_AA_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : *reinterpret_cast<const f32x4*>(q); };
+    int p = p_begin + pl;
+    const bool head = p + 3 * ppi < p_end;
+    f32x4 v0[4] = {};
+    if (head) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v0[u] = ld4(src + (size_t)(p + u * ppi) * ld);
+    }
     {
         const bool second = c >= C0;
         const int split = second ? f.split1 : f.split0, ld = second ? C1 : C0, cc = second ? c - C0 : c;
@@ -253,17 +267,16 @@ __global__ __launch_bounds__(256) void affine_act_fold_kernel(const float* __res
         }
         A[e] = Ae; B[e] = Be;
     }
-    const int p_begin = blockIdx.x * per, p_end = min(HW, p_begin + per);
-    const float* src; int ld;
-    if (c < C0) { src = src0 + (size_t)n * HW * C0 + c; ld = C0; } else { src = src1 + (size_t)n * HW * C1 + (c - C0); ld = C1; }
-    float* dst = y + (size_t)n * HW * C + c;
     auto one = [&](f32x4 v) {
         f32x4 r = v * A + B;
         if (act) { r.x = silu_f(r.x); r.y = silu_f(r.y); r.z = silu_f(r.z); r.w = silu_f(r.w); }
         return r;
     };
-    auto ld4 = [&](const float* q) { return (VD_AA_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : *reinterpret_cast<const f32x4*>(q); };
-    int p = p_begin + pl;
+    if (head) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(dst + (size_t)(p + u * ppi) * C) = one(v0[u]);
+        p += 4 * ppi;
+    }
     for (; p + 3 * ppi < p_end; p += 4 * ppi) {
         f32x4 v[4];
 #pragma unroll
