@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "fe6896cd3f4388c6"; }
+extern "C" const char* vd_source_sha(void) { return "b4bcfae032fb7a24"; }

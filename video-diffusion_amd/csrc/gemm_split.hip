@@ -44,6 +44,9 @@ __device__ __forceinline__ f32x16 mfma_piece(u32x4 a, u32x4 b, f32x16 c) {
 #ifndef VD_GS_B2REG
 #define VD_GS_B2REG 1      // f16x3: the third weight piece 2^-12 b0 formed in registers (four v_pk_mul_f16 per fragment) instead of loaded (A/B: 0)
 #endif
+#ifndef VD_GS_RING3_192
+#define VD_GS_RING3_192 0  // 1: 128x192 tile with two k-steps of weights ahead (the registers the un-fetched third piece freed).  Measured r04v,
+#endif                     // same box: qkv 8192 x 512 x 1536 41.4 -> 43.3 us, 32768 x 384 x 1152 95.5 -> 97.6, class 4.03 -> 4.08 ms: not a latency problem
 #ifndef VD_GS_SKIP
 #define VD_GS_SKIP 0       // kernel-experiment builds: bit 0 no weight loads, 1 no A staging, 2 no split VALU (timing only)
 #endif
@@ -75,10 +78,13 @@ __device__ __forceinline__ void split3(f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3)
 template <int BM, int BN, bool ACT, bool CONV, bool F16 = true, bool SIDE = false>      // F16: VD_MATH=f16x3 (default) | bf16x6 (vd_common.h)
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32;
-    // weight ring slots (k-steps ahead = RING - 1): 2 for the 128x192 tile (256 registers per wave), 3 for the others -- and 6
+    // weight ring slots (k-steps ahead = RING - 1): 2 for the 128x192 tile (256 registers per wave; 3 under f16x3, whose ring holds two
+    // pieces per fragment), 3 for the others -- and 6
     // for the 64x64 tile: its k-step is 6 MFMAs (0.1 us), its launches are the small-M ones (one block per CU, nothing else
     // to hide behind), and two steps ahead left every weight fragment a full L2 round trip short
-    constexpr int RING = NI >= 3 ? 2 : (BM == 64 && BN == 64 && VD_GS_RING6) ? 6 : 3;
+    constexpr bool B2R = F16 && VD_GS_B2REG;                           // the third weight piece lives in ONE register set (b2), not in the ring
+    constexpr int RING = NI >= 3 ? (B2R && VD_GS_RING3_192 ? 3 : 2) : (BM == 64 && BN == 64 && VD_GS_RING6) ? 6 : 3;
+    constexpr int BP = B2R ? 2 : 3;                                     // fetched pieces per fragment
     // A-operand prefetch distance in chunks.  A chunk of a 64-row tile is 12 .. 24 MFMAs (0.2 .. 0.4 us): one chunk ahead, the
     // split + store of the next chunk waits a full memory round trip every chunk, and a small-M launch (a B = 1 shard: 60 of
     // them per step) costs ~1 us per chunk whatever its size.  The small tiles have the registers for three chunks in flight.
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     for (int j = 0; j < NI; ++j) bo[j] = (unsigned)min((int)blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1) * 3072u + lane * 16u;
 
     f32x4 ra[PF][AR];
-    u32x4 bfr[RING][NI][3], afr[2][MI][NPL];     // [ring slot][tile][piece]
+    u32x4 bfr[RING][NI][BP], b2[NI], afr[2][MI][NPL];     // [ring slot][tile][piece]; b2: 2^-12 x piece 0 of the k-step being multiplied
     // SIDE: this block's frame, the affine pair of the chunk in flight, and the image rows of this thread
     static_assert(!SIDE || (BM == 128 && !CONV && !ACT), "side output: 128-row tiles of a plain 1x1");
     const bool side_on = SIDE && blockIdx.y == 0;
@@ -195,9 +201,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     // is not fetched: a third less weight traffic from the L2 (the ablation builds of r04o: the weight loads are 20 % of this kernel)
     const unsigned two_m12 = 0x0c000c00u;
     auto b_third = [&](int slot, int j) {
-        if constexpr (F16 && VD_GS_B2REG)
+        if constexpr (B2R)
             asm("v_pk_mul_f16 %0, %4, %8\n\tv_pk_mul_f16 %1, %5, %8\n\tv_pk_mul_f16 %2, %6, %8\n\tv_pk_mul_f16 %3, %7, %8"
-                : "=&v"(bfr[slot][j][2][0]), "=&v"(bfr[slot][j][2][1]), "=&v"(bfr[slot][j][2][2]), "=&v"(bfr[slot][j][2][3])
+                : "=&v"(b2[j][0]), "=&v"(b2[j][1]), "=&v"(b2[j][2]), "=&v"(b2[j][3])
                 : "v"(bfr[slot][j][0][0]), "v"(bfr[slot][j][0][1]), "v"(bfr[slot][j][0][2]), "v"(bfr[slot][j][0][3]), "s"(two_m12));
     };
     auto b_load = [&](int slot, int kstep) {      // kstep = global 16-wide k step
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int p = 0; p < (F16 && VD_GS_B2REG ? 2 : 3); ++p)
+            for (int p = 0; p < BP; ++p)
                 bfr[slot][j][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p * 1024, so, 0));
     };
     const int aoff = (wm * (BM / 2) + lr) * SROW + lh * 16;
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     // stops spilling: 256 registers + 44 bytes of scratch -> 236, none.)
     auto b_load_one = [&](int slot, int kstep, int idx) {                // idx = j * 3 + p
         const int j = idx / 3, p2 = idx - 3 * j;
-        if (F16 && VD_GS_B2REG && p2 == 2) return;                        // formed from piece 0 by b_third
+        if (p2 >= BP) return;                                             // formed from piece 0 by b_third
         bfr[slot][j][p2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, bo[j] + p2 * 1024, kstep * ncoblk * 3072, 0));
     };
     auto a_prefetch_one = [&](int chunk, int rs, int j) {
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
                 const int t = i * NI + j;
                 f32x16 c = acc[i][j];
                 if constexpr (F16) {             // a1 * (2^-12 b0) + a0 * b1 + a0 * b0
-                    c = mfma_piece<true>(afr[aslot][i][1], bfr[gslot][j][2], c);
+                    c = mfma_piece<true>(afr[aslot][i][1], B2R ? b2[j] : bfr[gslot][j][BP - 1], c);
                     c = mfma_piece<true>(afr[aslot][i][0], bfr[gslot][j][1], c);
                     c = mfma_piece<true>(afr[aslot][i][0], bfr[gslot][j][0], c);
                 } else {
