@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "b4bcfae032fb7a24"; }
+extern "C" const char* vd_source_sha(void) { return "8aa51d74ba317c45"; }

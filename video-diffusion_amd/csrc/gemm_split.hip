@@ -47,6 +47,9 @@ __device__ __forceinline__ f32x16 mfma_piece(u32x4 a, u32x4 b, f32x16 c) {
 #ifndef VD_GS_RING3_192
 #define VD_GS_RING3_192 0  // 1: 128x192 tile with two k-steps of weights ahead (the registers the un-fetched third piece freed).  Measured r04v,
 #endif                     // same box: qkv 8192 x 512 x 1536 41.4 -> 43.3 us, 32768 x 384 x 1152 95.5 -> 97.6, class 4.03 -> 4.08 ms: not a latency problem
+#ifndef VD_GS_XCD
+#define VD_GS_XCD 1        // XCD-aware block -> tile mapping (A/B: 0)
+#endif
 #ifndef VD_GS_SKIP
 #define VD_GS_SKIP 0       // kernel-experiment builds: bit 0 no weight loads, 1 no A staging, 2 no split VALU (timing only)
 #endif
@@ -95,7 +98,19 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // block -> tile.  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), and each XCD has its own L2: with the
+    // plain (x, y) = (row tile, column tile) mapping the N / BN column tiles of one row tile run on different XCDs at different
+    // times and every one of them streams the A rows in again (qkv, N = 1152: six passes over A).  Here an XCD keeps its own row
+    // tiles and walks their column tiles back to back: A comes in once per XCD, the (small) weight image is what all share.
+    // Same box (r04w): 32768 x 384 x 1152 95.5 -> 90 us, 131072 x 640 x 256 205 -> 180, 131072 x 512 x 256 160 -> 148; launches whose
+    // row tiles all fit the chip at once (8192 rows: 64 tiles) lose 5 % and keep the plain mapping.
+    int bxi = blockIdx.x, byi = blockIdx.y;
+    if (VD_GS_XCD && gridDim.y > 1 && (gridDim.x & 7) == 0 && gridDim.x >= 128) {
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, loc = lin >> 3;
+        byi = loc % gridDim.y;
+        bxi = (loc / gridDim.y) * 8 + xcd;
+    }
+    const int m0 = bxi * BM, n0 = byi * BN;
     // staging thread -> (row of the tile, 16-byte quad of the 32-wide chunk).  The two 8-lane groups of a 16-lane ds_write_b64
     // unit take rows FOUR apart (80-byte rows: 4 * 80 B = 16 banks mod 32, i.e. disjoint bank halves); with adjacent rows the
     // second row wrapped onto four banks of the first and a third of the LDS cycles were conflict cycles (PMC r02l / r03p:
@@ -135,13 +150,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     const auto bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, (CONV ? 9 : 1) * a.Cin * a.Cout * 6, 0x00020000);
     unsigned bo[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) bo[j] = (unsigned)min((int)blockIdx.y * (BN / 32) + wn * NI + j, ncoblk - 1) * 3072u + lane * 16u;
+    for (int j = 0; j < NI; ++j) bo[j] = (unsigned)min(byi * (BN / 32) + wn * NI + j, ncoblk - 1) * 3072u + lane * 16u;
 
     f32x4 ra[PF][AR];
     u32x4 bfr[RING][NI][BP], b2[NI], afr[2][MI][NPL];     // [ring slot][tile][piece]; b2: 2^-12 x piece 0 of the k-step being multiplied
     // SIDE: this block's frame, the affine pair of the chunk in flight, and the image rows of this thread
     static_assert(!SIDE || (BM == 128 && !CONV && !ACT), "side output: 128-row tiles of a plain 1x1");
-    const bool side_on = SIDE && blockIdx.y == 0;
+    const bool side_on = SIDE && byi == 0;
     const float* sAp = SIDE ? a.sideA + (size_t)(m0 / (SIDE ? a.side_hw : 1)) * a.Cin + lq * 4 : nullptr;
     const float* sBp = SIDE ? a.sideB + (size_t)(m0 / (SIDE ? a.side_hw : 1)) * a.Cin + lq * 4 : nullptr;
     f32x4 sA = {0.f, 0.f, 0.f, 0.f}, sB = sA;
