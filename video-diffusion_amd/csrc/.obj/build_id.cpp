@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "8aa51d74ba317c45"; }
+extern "C" const char* vd_source_sha(void) { return "d22cb2d55434ea9e"; }

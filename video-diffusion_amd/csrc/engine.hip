@@ -211,6 +211,8 @@ struct PrefixPlan {
 // eps are those of the full forward, bit for bit.
 struct SuffixPlan { int n = 0; const int* list = nullptr; };
 
+static inline int out_t_cols(int Cout) { return (9 * Cout + 31) / 32 * 32; }       // columns of the head's (cout, tap) GEMM
+
 // frames a layer call stands for when it runs on a part of them (conv_args -> IgemmArgs::nfr_sel); set around the compact suffix
 static thread_local int g_sel_nfr = 0;
 
@@ -343,6 +345,9 @@ struct vd_engine {
         if (kind == PK_CONV3S) p.packed = p.numel * 3 / 2 + 2 * O;
         if (kind == PK_CONV3W) p.packed = split_conv() ? (size_t)16 * O * p.shape[1] * 3 / 2 + 2 * O : (size_t)16 * O * p.shape[1];
         if (kind == PK_CONV3WU) p.packed = (size_t)4 * 16 * O * p.shape[1] * 3 / 2 + 8 * O;
+        // output head: [tap][O][I] (out_conv_bwd, the op entry point) + [out_t_cols(O)][I], rows co * 9 + tap: the head as a 1x1 GEMM over
+        // (cout, tap) columns followed by a 9-tap gather (misc.hip: out_gather_kernel)
+        if (kind == PK_OUTCONV) p.packed = p.numel + (size_t)out_t_cols((int)O) * p.shape[1];
         params.push_back(p);
         pidx[name] = (int)params.size() - 1;
         return (int)params.size() - 1;
@@ -1067,10 +1072,18 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
     if (tape) { tape->head = h; tape->headA = A; tape->headB = Bf; tape->head_mr = mrh; }
     const int oc = cfg.learn_sigma ? 6 : 3;
     float* eps_c = compact ? ar.get<float>((size_t)Nsuf * oc * S * S) : nullptr;
+    float* head_t = ar.get<float>((size_t)Nrun * S * S * out_t_cols(oc));
     if (!ar.dry) {
         VD_REQUIRE(h.H == S && h.C == final_ch, "output head shape");
-        { ProfScope ps(PC_OUT_CONV, 2.0 * Nrun * S * S * h.C * 27.0, 4.0 * Nrun * S * S * (h.C + 3.0), st);
-          rc = launch_out_conv(h.p, A, Bf, W(p_outw), W(p_outb), Nrun, S, S, h.C, oc, compact ? eps_c : in.eps, st); }
+        { // out = conv3x3(silu(gn(h))) with 3 | 6 outputs (unet.py:744-749,838): T[pixel][cout * 9 + tap] = silu(A h + B) . w[cout][:][tap] as ONE
+          // 1x1 GEMM over the 27 | 54 (cout, tap) columns (the generic kernel: GroupNorm affine + SiLU in its operand load), then
+          // eps[cout][y][x] = bias + sum over the 9 taps of T at the neighbour the tap points to (out_gather_kernel)
+          ProfScope ps(PC_OUT_CONV, 2.0 * Nrun * S * S * h.C * 27.0, 4.0 * Nrun * S * S * (h.C + 3.0), st);
+          IgemmArgs g = conv_args(h, nullptr, Nrun, 1, 1, 0);
+          g.w = W(p_outw) + (size_t)9 * oc * h.C; g.wsplit = 0; g.affA = A; g.affB = Bf; g.act = 1;
+          g.out = head_t; g.ldo = out_t_cols(oc); g.Cout = out_t_cols(oc);
+          rc = launch_igemm(g, st);
+          if (!rc) rc = launch_out_gather(head_t, W(p_outb), Nrun, S, S, out_t_cols(oc), oc, compact ? eps_c : in.eps, st); }
         if (rc) return rc;
         if (compact) {                                               // the other frames' eps: zeros (their samples stay finite; nobody reads them)
             VD_HIP(hipMemsetAsync(in.eps, 0, (size_t)N * oc * S * S * sizeof(float), st));
@@ -1465,10 +1478,14 @@ int vd_load_weight(vd_engine* e, const char* name, const float* host, long long 
         src = tmp.data();
     } else if (p.kind == PK_CONV3 || p.kind == PK_OUTCONV) {
         const int O = (int)p.shape[0], I = (int)p.shape[1];
-        tmp.assign((size_t)9 * O * I, 0.f);
+        tmp.assign(p.packed, 0.f);
         for (int o = 0; o < O; ++o)
             for (int i = 0; i < I; ++i)
                 for (int t = 0; t < 9; ++t) tmp[((size_t)t * O + o) * I + i] = host[((size_t)o * I + i) * 9 + t];
+        if (p.kind == PK_OUTCONV)
+            for (int o = 0; o < O; ++o)
+                for (int i = 0; i < I; ++i)
+                    for (int t = 0; t < 9; ++t) tmp[(size_t)9 * O * I + ((size_t)o * 9 + t) * I + i] = host[((size_t)o * I + i) * 9 + t];
         src = tmp.data();
     } else if (p.kind == PK_POSENC) {
         const int C = (int)p.shape[1], HW = (int)(p.shape[2] * p.shape[3]);

@@ -288,6 +288,45 @@ int launch_out_conv(const float* x, const float* affA, const float* affB, const 
     return 0;
 }
 
+// ------------------------------------------------------------------ output head as GEMM + gather (engine.hip: forward)
+// T[pixel][co * 9 + tap] holds what tap `tap` of output channel co contributes FROM this pixel; output pixel (y, x) sums the entry of
+// tap (dy, dx) at pixel (y + dy - 1, x + dx - 1).  Block = 16 x 16 output pixels: the 18 x 18 halo of T rows is staged through LDS
+// with coalesced 16-byte loads (rows padded to an odd number of quads: lanes of a row walk different banks), then 9 * Cout LDS reads
+// per pixel.  NCHW out.
+template <int LDT>
+__global__ __launch_bounds__(256) void out_gather_kernel(const float* __restrict__ T, const float* __restrict__ bias, int H, int W, int Cout,
+                                                         float* __restrict__ out) {
+    constexpr int ROW = LDT + 4;                                      // floats per staged pixel
+    __shared__ __attribute__((aligned(16))) float tile[(OT + 2) * (OT + 2) * ROW];
+    const int n = blockIdx.z, y0 = blockIdx.y * OT, x0 = blockIdx.x * OT;
+    const int tid = threadIdx.x, ty = tid / OT, tx = tid % OT;
+    for (int i = tid; i < (OT + 2) * (OT + 2) * (LDT / 4); i += 256) {
+        const int pix = i / (LDT / 4), q = i - pix * (LDT / 4);
+        const int iy = y0 + pix / (OT + 2) - 1, ix = x0 + pix % (OT + 2) - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4*>(T + (((size_t)n * H + iy) * W + ix) * LDT + q * 4);
+        *reinterpret_cast<f32x4*>(tile + pix * ROW + q * 4) = v;
+    }
+    __syncthreads();
+    const int oy = y0 + ty, ox = x0 + tx;
+    if (oy >= H || ox >= W) return;
+    for (int co = 0; co < Cout; ++co) {
+        float acc = bias[co];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) acc += tile[((ty + tap / 3) * (OT + 2) + tx + tap % 3) * ROW + co * 9 + tap];
+        out[(((size_t)n * Cout + co) * H + oy) * W + ox] = acc;
+    }
+}
+
+int launch_out_gather(const float* T, const float* bias, int nfr, int H, int W, int ldt, int Cout, float* out_nchw, hipStream_t s) {
+    VD_REQUIRE((ldt == 32 || ldt == 64) && 9 * Cout <= ldt, "output head: 3 or 6 output channels");
+    const dim3 grid((W + OT - 1) / OT, (H + OT - 1) / OT, nfr);
+    if (ldt == 32) hipLaunchKernelGGL(out_gather_kernel<32>, grid, dim3(256), 0, s, T, bias, H, W, Cout, out_nchw);
+    else hipLaunchKernelGGL(out_gather_kernel<64>, grid, dim3(256), 0, s, T, bias, H, W, Cout, out_nchw);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
 __device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned long long key, unsigned (&o)[4]) {
     unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0x5eed5eedu, c3 = 0;
