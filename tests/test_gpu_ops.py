@@ -337,6 +337,33 @@ def test_attention_spatial(N, L, C, heads):
     close(out.cpu(), ref, **TOL)
 
 
+@pytest.mark.parametrize("qmag,kmag,vmag", [(1.0, 1.0, 1.0), (1e-3, 1.0, 1e-3), (30.0, 0.5, 100.0), (1e-6, 1e-6, 1e3), (200.0, 0.05, 1e-4)])
+def test_attention_spatial_accuracy_over_magnitudes(qmag, kmag, vmag):
+    """The split arithmetic of csrc/attn_spatial.hip against an fp64 softmax(q k^T) v.  f16x3 scales every query row to the top of
+    fp16's range (a power of two, undone on the scores) and the softmax weights by 2^14: tiny, large and mixed operand magnitudes
+    must come out at fp32-level accuracy relative to the output's scale -- an un-scaled fp16 remainder would lose the second piece of a
+    1e-3-sized q entirely (error 1e-3 relative), an overflow would give inf."""
+    N, L, C, heads = 2, 256, 384, 4
+    Fd = C // heads
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(N, L, heads, Fd, generator=g) * m for m in (qmag, kmag, vmag))
+    q[0, 3] *= 7.0                                                     # rows of different magnitude inside one query tile
+    q[1, 40] *= 1e-2
+    qkv = torch.stack([q, k, v], dim=2).reshape(N, L, 3 * C).contiguous()
+    out = torch.empty(N, L, C, device="cuda")
+    buf = dev(qkv)
+    _lib.check(_lib.lib().vd_op_attn_spatial(_lib.ptr(buf), N, L, C, heads, _lib.ptr(out), _lib.current_stream()))
+    torch.cuda.synchronize()
+    qd, kd, vd = (t.double().permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = (torch.softmax((qd * Fd ** -0.5) @ kd.transpose(-1, -2), -1) @ vd).permute(0, 2, 1, 3).reshape(N, L, C)
+    ref32 = (torch.softmax((qd.float() * Fd ** -0.5) @ kd.float().transpose(-1, -2), -1) @ vd.float()).permute(0, 2, 1, 3).reshape(N, L, C)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    scale = ref.abs().max()
+    e_got, e_f32 = (got - ref).abs().max() / scale, (ref32.double() - ref).abs().max() / scale
+    assert e_got <= max(4.0 * e_f32, 2e-6), (e_got, e_f32)
+
+
 def test_attention_spatial_peaked_scores():
     """Online-softmax rescale path: one key dominates late in the sequence (guide rule: force the rare branch)."""
     N, L, C, heads = 1, 128, 64, 4

@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "d22cb2d55434ea9e"; }
+extern "C" const char* vd_source_sha(void) { return "191e07a2e728d98a"; }

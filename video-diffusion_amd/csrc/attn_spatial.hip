@@ -132,8 +132,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(AttnSpatialArgs a) {
 // The same attention on the bf16 matrix cores at fp32 accuracy (default; VD_MATH=fp32 keeps the kernel above).
 // q*scale, k, v and the softmax weights p are each split EXACTLY into three bf16 pieces (vd_common.h: split_a/split_b)
 // and every product runs as six piece products of v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the arithmetic of
-// VD_MATH=bf16x6 in gemm_split.hip / conv_wino_r64.hip: 6 x 32 cycles per 16 k instead of 8 x 64 (this kernel keeps the exact
-// split in every mode but fp32: 0.7 ms of a 23 ms step).
+// VD_MATH=bf16x6 in gemm_split.hip / conv_wino_r64.hip: 6 x 32 cycles per 16 k instead of 8 x 64.  (VD_MATH=f16x3: below.)
 //   S^T = K . Q^T : A = K tile (three bf16 planes in LDS, rows of FK bf16 + 16 bytes: conflict-free ds_read_b128),
 //                   B = Q^T pieces, split once per wave and kept in registers
 //   O^T += V^T . P^T : B = P^T, the S^T accumulator registers split in place (k order of an accumulator tile:
@@ -162,20 +161,57 @@ __device__ __forceinline__ void split_f4(f32x4 v, u32x2_t& p1, u32x2_t& p2, u32x
     p1 = u32x2_t{a, b}; p2 = u32x2_t{c, d}; p3 = u32x2_t{e, f};
 }
 
+// f16x3 (vd_common.h; the default arithmetic): K and V are the "a" side -- a0 = f16(x), a1 = f16((x - a0) * 2^12) -- Q^T and P^T the "b"
+// side -- b0 = f16(y), b1 = f16(y - b0), b2 = 2^-12 b0 -- and a product is a1 b2 + a0 b1 + a0 b0 on v_mfma_f32_32x32x16_f16: half the MFMAs,
+// two LDS planes instead of three, 2.5 instead of 5.5 vector instructions per split value.  The b side must sit near the top of fp16's
+// range for b1 to stay normal (gemm_split.hip scales its weight rows on the host): every query row is scaled by a power of two to
+// max |q| in [2^13, 2^14) -- undone on the scores, exactly -- and the softmax weights (<= 1) by 2^14, undone with the final 1 / l.
+__device__ __forceinline__ void split_a16(f32x4 v, u32x2_t& p0, u32x2_t& p1) {
+    asm volatile("s_nop 1" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));     // (the transcendental hazard above)
+    p0 = u32x2_t{f16_pack(v.x, v.y), f16_pack(v.z, v.w)};
+    p1 = u32x2_t{f16_pack_scaled(f16_rem_lo(p0.x, v.x), f16_rem_hi(p0.x, v.y)), f16_pack_scaled(f16_rem_lo(p0.y, v.z), f16_rem_hi(p0.y, v.w))};
+}
+__device__ __forceinline__ void split_b16(f32x4 v, u32x2_t& b0, u32x2_t& b1, u32x2_t& b2) {
+    asm volatile("s_nop 1" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    b0 = u32x2_t{f16_pack(v.x, v.y), f16_pack(v.z, v.w)};
+    b1 = u32x2_t{f16_pack(f16_rem_lo(b0.x, v.x), f16_rem_hi(b0.x, v.y)), f16_pack(f16_rem_lo(b0.y, v.z), f16_rem_hi(b0.y, v.w))};
+    const unsigned two_m12 = 0x0c000c00u;
+    asm("v_pk_mul_f16 %0, %2, %4\n\tv_pk_mul_f16 %1, %3, %4" : "=&v"(b2.x), "=&v"(b2.y) : "v"(b0.x), "v"(b0.y), "s"(two_m12));
+}
+// pieces of eight values in the order an MFMA B operand wants them: [piece] = {lo quad, hi quad}
+template <bool F16>
+__device__ __forceinline__ void split_b8(f32x4 v0, f32x4 v1, u32x4_t (&out)[3]) {
+    u32x2_t a1, a2, a3, b1, b2, b3;
+    if constexpr (F16) { split_b16(v0, a1, a2, a3); split_b16(v1, b1, b2, b3); }
+    else { split_f4(v0, a1, a2, a3); split_f4(v1, b1, b2, b3); }
+    out[0] = u32x4_t{a1.x, a1.y, b1.x, b1.y};
+    out[1] = u32x4_t{a2.x, a2.y, b2.x, b2.y};
+    out[2] = u32x4_t{a3.x, a3.y, b3.x, b3.y};
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 attn_mfma(u32x4_t a, u32x4_t b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
 constexpr int attn_rowv(int F) {           // bytes per V row: >= 64 per 32-feature tile, a multiple of 8, dwords = 16 mod 32
     int b = ((F + 31) / 32) * 64;
     while ((b / 4) % 32 != 16) b += 8;
     return b;
 }
 
-template <int F>
+template <int F, bool F16>
 __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kernel(AttnSpatialArgs a) {
     constexpr int KS = (F + 15) / 16, FK = KS * 16;     // k-steps of the QK^T contraction (zero padded)
     constexpr int FT = (F + 31) / 32;                   // 32-wide output tiles over F
     constexpr int ROWK = FK * 2 + 16, ROWV = attn_rowv(F);
     constexpr int KPL = 32 * ROWK, VPL = 32 * ROWV;
-    __shared__ __attribute__((aligned(16))) char Ks[3 * KPL];
-    __shared__ __attribute__((aligned(16))) char Vs[3 * VPL];
+    constexpr int NPL = F16 ? 2 : 3;                    // planes of K and V (the "a" side)
+    constexpr int NPP = F16 ? 3 : 6;                    // piece products
+    // (a piece, b piece) per product, small terms first: f16x3 a1 b2, a0 b1, a0 b0; bf16x6 the six of gemm_split.hip
+    constexpr int PA[6] = {F16 ? 1 : 0, F16 ? 0 : 1, F16 ? 0 : 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+    __shared__ __attribute__((aligned(16))) char Ks[NPL * KPL];
+    __shared__ __attribute__((aligned(16))) char Vs[NPL * VPL];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -188,21 +224,31 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
     u32x4_t qp[KS][3];
     const int qi = q0 + lr;
     const bool qok = qi < a.L;
+    f32x4 qv[KS][2];
+    float qmax = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int f0 = ks * 16 + lh * 8;
-        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        qv[ks][0] = f32x4{0.f, 0.f, 0.f, 0.f}; qv[ks][1] = qv[ks][0];
         if (qok && f0 < F) {
-            v0 = *reinterpret_cast<const f32x4*>(base + (size_t)qi * C3 + f0) * a.scale;
-            v1 = *reinterpret_cast<const f32x4*>(base + (size_t)qi * C3 + f0 + 4) * a.scale;
+            qv[ks][0] = *reinterpret_cast<const f32x4*>(base + (size_t)qi * C3 + f0) * a.scale;
+            qv[ks][1] = *reinterpret_cast<const f32x4*>(base + (size_t)qi * C3 + f0 + 4) * a.scale;
         }
-        u32x2_t a1, a2, a3, b1, b2, b3;
-        split_f4(v0, a1, a2, a3);
-        split_f4(v1, b1, b2, b3);
-        qp[ks][0] = u32x4_t{a1.x, a1.y, b1.x, b1.y};
-        qp[ks][1] = u32x4_t{a2.x, a2.y, b2.x, b2.y};
-        qp[ks][2] = u32x4_t{a3.x, a3.y, b3.x, b3.y};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qmax = fmaxf(qmax, fmaxf(fabsf(qv[ks][0][e]), fabsf(qv[ks][1][e])));
     }
+    // f16x3: the query row times 2^e with max |q 2^e| in [2^13, 2^14); the scores leave through 2^-e
+    float qs = 1.f, qs_inv = 1.f;
+    if constexpr (F16) {
+        qmax = fmaxf(qmax, __shfl_xor(qmax, 32));
+        if (qmax > 0.f && qmax < INFINITY) {
+            const int ex = (int)((__builtin_bit_cast(unsigned, qmax) >> 23) & 0xff) - 126;       // qmax = m 2^ex, m in [0.5, 1) (a subnormal row: a smaller e, harmless)
+            const int e = max(-100, min(100, 14 - ex));
+            qs = ldexpf(1.f, e); qs_inv = ldexpf(1.f, -e);
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) split_b8<F16>(qv[ks][0] * qs, qv[ks][1] * qs, qp[ks]);
     f32x16 o[FT];
 #pragma unroll
     for (int t = 0; t < FT; ++t)
@@ -212,8 +258,8 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
 
     // padding that is read but never staged: K columns F..FK (they enter the contraction) and V columns F..FT*32 (they
     // only feed output rows that are not stored; zeroed so that no NaN pattern meets a zero weight)
-    for (int i = tid; i < 3 * KPL / 4; i += 256) reinterpret_cast<unsigned*>(Ks)[i] = 0u;
-    for (int i = tid; i < 3 * VPL / 4; i += 256) reinterpret_cast<unsigned*>(Vs)[i] = 0u;
+    for (int i = tid; i < NPL * KPL / 4; i += 256) reinterpret_cast<unsigned*>(Ks)[i] = 0u;
+    for (int i = tid; i < NPL * VPL / 4; i += 256) reinterpret_cast<unsigned*>(Vs)[i] = 0u;
 
     // transposed-read addresses of this lane: row (lane&15)>>2 of the 4-key block, columns 16*((lane>>4)&1) + 4*(lane&3)
     const int trow = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -248,12 +294,13 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
             if (i < 32 * (F / 4)) {
                 const int r = i / (F / 4), c4 = i - r * (F / 4);
                 u32x2_t k1, k2, k3, v1, v2, v3;
-                split_f4(pk[u], k1, k2, k3);
-                split_f4(pv[u], v1, v2, v3);
+                if constexpr (F16) { split_a16(pk[u], k1, k2); split_a16(pv[u], v1, v2); }
+                else { split_f4(pk[u], k1, k2, k3); split_f4(pv[u], v1, v2, v3); }
                 char* kd = Ks + r * ROWK + c4 * 8;
                 char* vd = Vs + r * ROWV + c4 * 8;
-                *reinterpret_cast<u32x2_t*>(kd) = k1; *reinterpret_cast<u32x2_t*>(kd + KPL) = k2; *reinterpret_cast<u32x2_t*>(kd + 2 * KPL) = k3;
-                *reinterpret_cast<u32x2_t*>(vd) = v1; *reinterpret_cast<u32x2_t*>(vd + VPL) = v2; *reinterpret_cast<u32x2_t*>(vd + 2 * VPL) = v3;
+                *reinterpret_cast<u32x2_t*>(kd) = k1; *reinterpret_cast<u32x2_t*>(kd + KPL) = k2;
+                *reinterpret_cast<u32x2_t*>(vd) = v1; *reinterpret_cast<u32x2_t*>(vd + VPL) = v2;
+                if constexpr (!F16) { *reinterpret_cast<u32x2_t*>(kd + 2 * KPL) = k3; *reinterpret_cast<u32x2_t*>(vd + 2 * VPL) = v3; }
             }
         }
         __syncthreads();
@@ -265,14 +312,13 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8_t kf[3];
+            u32x4_t kf[NPL];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8_t*>(Ks + p * KPL + koff + ks * 32);
-            constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+            for (int p = 0; p < NPL; ++p) kf[p] = *reinterpret_cast<const u32x4_t*>(Ks + p * KPL + koff + ks * 32);
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[q]], __builtin_bit_cast(bf16x8_t, qp[ks][PB[q]]), st, 0, 0, 0);
+            for (int q = 0; q < NPP; ++q) st = attn_mfma<F16>(kf[PA[q]], qp[ks][PB[q]], st);
         }
+        if constexpr (F16) st *= qs_inv;                            // the query row's scale leaves (exact)
         // lane (query lr, half lh) holds keys k0 + (r&3) + 8*(r>>2) + 4*lh
         float mloc = -INFINITY;
 #pragma unroll
@@ -296,37 +342,31 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
             for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
         // P^T pieces of the two k-steps (keys 0..15 and 16..31 of the tile): registers 8s .. 8s+7
         u32x4_t pp[2][3];
+        constexpr float PSC = F16 ? 16384.f : 1.f;                    // f16x3: the weights times 2^14 (undone with 1 / l)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x2_t a1, a2, a3, b1, b2, b3;
-            split_f4(f32x4{st[8 * s], st[8 * s + 1], st[8 * s + 2], st[8 * s + 3]}, a1, a2, a3);
-            split_f4(f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]}, b1, b2, b3);
-            pp[s][0] = u32x4_t{a1.x, a1.y, b1.x, b1.y};
-            pp[s][1] = u32x4_t{a2.x, a2.y, b2.x, b2.y};
-            pp[s][2] = u32x4_t{a3.x, a3.y, b3.x, b3.y};
-        }
+        for (int s = 0; s < 2; ++s)
+            split_b8<F16>(f32x4{st[8 * s], st[8 * s + 1], st[8 * s + 2], st[8 * s + 3]} * PSC,
+                          f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]} * PSC, pp[s]);
         // O^T += V^T . P^T
 #pragma unroll
         for (int t = 0; t < FT; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8_t vf[3];
+                u32x4_t vf[NPL];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NPL; ++p) {
                     const char* vb = Vs + p * VPL + voff + (16 * s) * ROWV + t * 64;
                     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb));
                     const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + 8 * ROWV));
                     typedef short s16x8_t __attribute__((ext_vector_type(8)));
-                    vf[p] = __builtin_bit_cast(bf16x8_t, s16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
+                    vf[p] = __builtin_bit_cast(u32x4_t, s16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
                 }
-                constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
-                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[q]], __builtin_bit_cast(bf16x8_t, pp[s][PB[q]]), o[t], 0, 0, 0);
+                for (int q = 0; q < NPP; ++q) o[t] = attn_mfma<F16>(vf[PA[q]], pp[s][PB[q]], o[t]);
             }
     }
     if (!qok) return;
-    const float inv = 1.0f / l;
+    const float inv = (F16 ? 1.f / 16384.f : 1.f) / l;
     float* op = a.out + ((size_t)n * a.L + qi) * a.C + h * F;
 #pragma unroll
     for (int t = 0; t < FT; ++t)
@@ -344,10 +384,11 @@ int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s) {
     VD_REQUIRE(a.C % a.heads == 0, "channels divisible by heads");
     const int F = a.C / a.heads;
     dim3 grid((a.L + 127) / 128, a.heads, a.nfr);
-    const bool fp32_mfma = math_mode() == MATH_FP32;
+    const int mode = math_mode();
     switch (F) {
-#define VD_CASE(FV) case FV: if (fp32_mfma) hipLaunchKernelGGL((attn_spatial_kernel<FV>), grid, dim3(256), 0, s, a); \
-                             else hipLaunchKernelGGL((attn_spatial_split_kernel<FV>), grid, dim3(256), 0, s, a); break;
+#define VD_CASE(FV) case FV: if (mode == MATH_FP32) hipLaunchKernelGGL((attn_spatial_kernel<FV>), grid, dim3(256), 0, s, a); \
+                             else if (mode == MATH_F16X3) hipLaunchKernelGGL((attn_spatial_split_kernel<FV, true>), grid, dim3(256), 0, s, a); \
+                             else hipLaunchKernelGGL((attn_spatial_split_kernel<FV, false>), grid, dim3(256), 0, s, a); break;
         VD_CASE(8) VD_CASE(16) VD_CASE(24) VD_CASE(32) VD_CASE(40) VD_CASE(48) VD_CASE(56) VD_CASE(64) VD_CASE(80) VD_CASE(96) VD_CASE(112) VD_CASE(128)
 #undef VD_CASE
         default:
