@@ -1,1 +1,1 @@
-extern "C" const char* vd_source_sha(void) { return "191e07a2e728d98a"; }
+extern "C" const char* vd_source_sha(void) { return "ae0b9ab56542b183"; }

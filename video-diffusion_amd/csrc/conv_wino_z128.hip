@@ -377,7 +377,10 @@ bool conv_wino_z128_shape(int nfr, int H, int Cin, int Cout) {
     // 1.5 x the MFMAs for half the per-item overhead and half the vector work: pays while the channel loop is short.  Same box,
     // us per launch, this kernel | conv_wino_r64.hip (r04q, after the latter stopped loading the third weight piece):
     // 128 -> 128 @ 64^2 411 - 428 | 432 - 451, 256 -> 256 @ 32^2 344 - 356 | 361 - 370, 640 -> 256 @ 32^2 805 | 758 - 774
-    if (Cin > 320) return false;
+#ifndef VD_Z128_MAX_CIN
+#define VD_Z128_MAX_CIN 320
+#endif
+    if (Cin > VD_Z128_MAX_CIN) return false;
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
