@@ -74,27 +74,45 @@ def parse_args():
     return ap.parse_args()
 
 
+def rank_env(base, rank, world, port):
+    """Environment of rank `rank` of a `world`-rank job on ONE node (what torch.distributed.run would set); pure, so a CPU test
+    can hold it to the contract: RANK = LOCAL_RANK in [0, world), rendezvous on 127.0.0.1, dmabuf IPC for RCCL."""
+    assert 0 <= rank < world and 0 < port < 65536
+    return {**base, "RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+            "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` by itself: one child per GPU, started before this process has made any GPU call
     (a process that has initialised the GPU must not start other programs on these boxes).  No exec: children are
-    ordinary subprocesses, rank 0's stdout is ours, and we leave with the worst return code."""
+    ordinary subprocesses, rank 0's stdout is ours, and we leave with the worst return code.  Ranks > 0 keep their stderr
+    in gpurun_out/rank<r>.err (a rank that dies on the 8-GPU node must leave its reason somewhere)."""
     from video_diffusion_amd import _lib
     _lib.build()                                  # hipcc only; the ranks then find the library fresh
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    errdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
+    os.makedirs(errdir, exist_ok=True)
+    procs, errs = [], []
     for r in range(args.gpus):
-        env = {**os.environ, "RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
-               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+        err = open(os.path.join(errdir, f"rank{r}.err"), "w") if r else None
+        errs.append(err)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=rank_env(dict(os.environ), r, args.gpus, port),
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=err))
     worst = 0
-    for p in procs:
+    for r, p in enumerate(procs):
         rc = p.wait()
+        if errs[r] is not None:
+            errs[r].close()
         if rc != 0:
             worst = rc if worst == 0 or abs(rc) > abs(worst) else worst
+            if r:
+                try:
+                    sys.stderr.write(f"[bench] rank {r} exited {rc}: " + open(os.path.join(errdir, f"rank{r}.err")).read()[-2000:] + "\n")
+                except OSError:
+                    pass
     return worst
 
 
@@ -367,9 +385,10 @@ def main():
 
     # rehearsal knobs for a one-GPU box (the N > 1 path is the driver's to run on an 8-GPU node): VD_BENCH_BACKEND=gloo
     # and VD_BENCH_ALL_ON_DEVICE0=1 put every rank on device 0 (RCCL refuses two ranks on one GPU, gloo does not)
-    rank, local_rank, world = vdist.init(backend=os.environ.get("VD_BENCH_BACKEND"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py measures the HIP engine: it needs a GPU (no CPU fallback)"
+    # the rank's GPU is chosen before the process group exists and handed to it (dist.init: set_device, then init_process_group(device_id=...))
+    rank, local_rank, world = vdist.init(backend=os.environ.get("VD_BENCH_BACKEND"), device_index=0 if os.environ.get("VD_BENCH_ALL_ON_DEVICE0") else None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if os.environ.get("VD_BENCH_ALL_ON_DEVICE0"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -392,6 +411,9 @@ def main():
         return sd_holder["sd"]
 
     vdist.share_weights(model, make_sd, rank)           # one RCCL broadcast of the packed buffer
+    import torch.distributed as tdist
+    rccl_ranks = tdist.get_world_size() if tdist.is_initialized() else 1   # what the group says after the broadcast, not what the flags asked for
+    assert rccl_ranks == args.gpus, f"process group has {rccl_ranks} ranks, --gpus {args.gpus}"
 
     kw = make_window(B, T, S, n_obs, seed=1234 + rank, device=device)
     assert not args.prefix_cache or args.executor == "graph", "--prefix-cache is a mode of the window executor (--executor graph)"
@@ -515,7 +537,7 @@ def main():
         "sec_per_clip_batch": round(nts * elapsed / args.steps, 2),
         "lib_source_sha": __import__("video_diffusion_amd")._lib.lib().vd_source_sha().decode(),
         "config": {"workload": workload, "batch_per_gpu": B, "frames": T, "image_size": S, "respaced_steps": nts,
-                   "parallelism": f"batch-shard x{world} (no collective in the step)", "rccl_ranks": world,
+                   "parallelism": f"batch-shard x{world} (no collective in the step)", "rccl_ranks": rccl_ranks,
                    "executor": args.executor + ("+prefix_cache" if args.prefix_cache else "") + ("+suffix_skip" if args.suffix_skip else ""),
                    **({"cached_frames": stepper.ex.cached_frames} if args.prefix_cache else {}),
                    **({"suffix_frames": stepper.ex.suffix_frames} if args.suffix_skip else {})},

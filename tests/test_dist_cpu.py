@@ -224,3 +224,49 @@ def test_task_to_indices_mapping():
     assert vdist.indices_for_task(3, 8, dataset_len=27) == [24, 25, 26]
     assert vdist.task_ids(5, 0, 1) == [0, 1, 2, 3, 4]
     assert vdist.max_over_ranks(3.5) == 3.5                  # single-process fallthrough
+
+
+def test_bench_rank_environment_is_well_formed():
+    """The N-rank child environment bench.py's self_launch builds (what the driver's torch.distributed.run would set)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for world in (1, 2, 4, 8):
+        envs = [bench.rank_env({"PATH": "/x", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, r, world, 29511) for r in range(world)]
+        assert sorted(int(e["RANK"]) for e in envs) == list(range(world))
+        for r, e in enumerate(envs):
+            assert e["LOCAL_RANK"] == e["RANK"] == str(r) and e["WORLD_SIZE"] == e["LOCAL_WORLD_SIZE"] == str(world)
+            assert e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29511"     # the container hostname may not resolve
+            assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["PATH"] == "/x"       # dmabuf IPC: RCCL fails without it on this pool
+    assert bench.rank_env({}, 0, 1, 1)["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    import pytest
+    with pytest.raises(AssertionError):
+        bench.rank_env({}, 2, 2, 29500)
+
+
+def test_dist_init_picks_the_gpu_before_the_group_exists(monkeypatch):
+    """RCCL: torch.cuda.set_device(local_rank) FIRST, then init_process_group(device_id=that device) -- the order of the
+    reference's dist_util.py:100-110; a group without device_id guesses its GPU at the first collective."""
+    calls = []
+    monkeypatch.setenv("RANK", "3"); monkeypatch.setenv("LOCAL_RANK", "3"); monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.append(("set_device", d)))
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(dist, "init_process_group", lambda **kw: calls.append(("init", kw)))
+    monkeypatch.setattr(dist, "get_world_size", lambda: 8)
+    monkeypatch.setattr(dist, "get_rank", lambda: 3)
+    assert vdist.init() == (3, 3, 8)
+    assert calls[0] == ("set_device", 3) and calls[1][0] == "init"
+    kw = calls[1][1]
+    assert kw["backend"] == "nccl" and kw["rank"] == 3 and kw["world_size"] == 8 and kw["device_id"] == torch.device("cuda", 3)
+    # a rank whose GPU does not exist fails before it joins (not inside the first collective)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    import pytest
+    with pytest.raises(RuntimeError, match="LOCAL_RANK 3"):
+        vdist.init()
+    # the one-GPU rehearsal: gloo, every rank on device 0, no device_id
+    calls.clear()
+    assert vdist.init(backend="gloo", device_index=0) == (3, 3, 8)
+    assert calls[0] == ("set_device", 0) and "device_id" not in calls[1][1] and calls[1][1]["backend"] == "gloo"

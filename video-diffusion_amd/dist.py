@@ -18,15 +18,31 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend=None):
-    """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them)."""
+def init(backend=None, device_index=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
+
+    With RCCL the process' GPU is chosen BEFORE the group exists and handed to it (`device_id`): a process group created
+    without it guesses the device at its first collective from the current one, so a barrier / object broadcast issued before
+    `torch.cuda.set_device` would run on GPU 0 from every rank (a hang or an invalid-argument on the 8-GPU node; the
+    reference does the same in dist_util.py:100-110: set_device, then init_process_group).  `device_index` overrides
+    LOCAL_RANK (the one-GPU rehearsal puts every rank on device 0 over gloo)."""
     rank, local_rank, world = env_world()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dev = local_rank if device_index is None else device_index
+    if backend == "nccl":
+        if not torch.cuda.is_available():
+            raise RuntimeError("dist.init: backend nccl (RCCL) needs a GPU")
+        if dev >= torch.cuda.device_count():
+            raise RuntimeError(f"dist.init: LOCAL_RANK {local_rank} -> device {dev}, but this process sees {torch.cuda.device_count()} GPUs")
+    if torch.cuda.is_available() and dev < torch.cuda.device_count():
+        torch.cuda.set_device(dev)             # (a gloo job on a box with fewer GPUs than ranks keeps the current device)
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        assert dist.get_world_size() == world and dist.get_rank() == rank
     return rank, local_rank, world
 
 
