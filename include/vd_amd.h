@@ -105,7 +105,13 @@ int vd_set_model_mean_type(vd_engine* e, int type);
 /* Timestep indices outside [0, num_timesteps) make the reference raise IndexError (_extract_into_tensor,
  * gaussian_diffusion.py:1019-1031).  The step entry points stay asynchronous: such a batch element is written as NaN
  * and a sticky device flag is set; this call copies the flags to the host (it SYNCHRONISES), clears them, and the host
- * mirror raises IndexError.  bit 0: timestep index out of range. */
+ * mirror raises IndexError.  bit 0: timestep index out of range.
+ * bit 1: the network output a step consumed was not finite.  The reference would carry the NaN into its sample; here the clamp
+ * of clip_denoised would turn it into a plausible -1, so the posterior kernels keep such an element NaN and set this bit
+ * (vd_p_sample, vd_ddim_sample, vd_p_mean_variance, vd_posterior_update, vd_posterior_from_xstart, vd_vb_terms, vd_guided_step,
+ * the window executor's captured step).  In the default f16x3 arithmetic (two fp16 pieces per fp32 operand) this is how an
+ * activation beyond fp16's range (|x| > 65504) anywhere in the network shows: VD_MATH=bf16x6 carries the full fp32 range.
+ * The host mirror raises FloatingPointError. */
 int vd_device_errors(vd_engine* e, int* flags);
 
 /* Bytes of engine-owned workspace a (B, T) window needs; allocated lazily by the first call. */
@@ -164,7 +170,9 @@ int vd_prior_bpd(vd_engine* e, int B, int T, const float* x_start, const float* 
  * instead of ~330 kernel launches per step from the host (BASELINE configs[4]: two signatures, Tw = 20 and Tw = 14).
  * vd_window_begin arms the counters (and captures if the signature is new: one eager forward, then the capture; `stream`
  * must not be the default stream); vd_window_run replays n_steps steps t_start, t_start-1, ...; x holds the result.
- * observed_frames: x_0 or x_t only.  Noise is always the in-kernel Philox stream (seed, offset + step*B*per + i):
+ * observed_frames: 0 x_0, 1 x_t, 2 x_t_minus_1 as p_sample_loop runs it (obs_src = the CLEAN frames, re-noised to t - 1 inside
+ * every step from the second half of the step's Philox range, gaussian_diffusion.py:565-568), 3 x_t_minus_1 with obs_src read as it
+ * is at every step (a direct p_sample caller: scripts/video_sample.py:149-166 hands x0).  Noise is always the in-kernel Philox stream (seed, offset + step*B*per + i):
  * identical to vd_p_sample(noise = NULL, seed, offset + step*B*per). */
 int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, const float* obs_mask,
                     const float* latent_mask, const float* kinda_marg_mask, const long long* frame_indices,

@@ -781,6 +781,49 @@ def test_window_executor_equals_eager_steps_bit_for_bit():
     model.check_device_errors()
 
 
+@pytest.mark.gpu
+def test_window_executor_x_t_minus_1_as_handed_equals_the_direct_p_sample_caller():
+    """scripts/video_sample.py:149-166 calls p_sample directly with x_t_minus_1 = x0 (a clean placeholder read as it is at every
+    step); only p_sample_loop re-noises (gaussian_diffusion.py:565-568).  infer_video's graph executor therefore runs
+    `renoise=False` (C ABI observed_frames = 3): step k == vd_p_sample(observed_frames 'x_t_minus_1', obs_src = the caller's tensor,
+    noise = NULL, seed, offset k*B*per), to the bit -- the same conditional distribution as infer_video's eager loop
+     -- and it differs from the re-noising form."""
+    from video_diffusion_amd import _lib
+    from video_diffusion_amd.executor import WindowExecutor
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=6, image_size=32, num_channels=64, num_res_blocks=1,
+                                                              rp_alpha=6, rp_beta=6, rp_gamma=6, timestep_respacing="ddim10")}
+    model, diff = engine(cfg)
+    diff._bind(model)
+    L = _lib.lib()
+    ex = WindowExecutor(model, diff)
+    B, T, n_obs, seed = 2, 6, 2, 77
+    c = _rand_window(B, T, 32, n_obs, seed=91)
+    kw = kwargs_of(c, observed_frames="x_t_minus_1")
+    x_init = c["x0"].cuda().clone()
+    ex.begin(x_init, kw, seed=seed, renoise=False)
+    got = ex.run(diff.num_timesteps).clone()
+    cur = x_init.clone()
+    per = cur[0].numel()
+    k = model._pack_kwargs(cur, kw)
+    assert k["obs_mode"] == 2
+    for step, ti in enumerate(range(diff.num_timesteps)[::-1]):
+        t = torch.full((B,), ti, dtype=torch.int64, device="cuda")
+        nxt = torch.empty_like(cur)
+        _lib.check(L.vd_p_sample(model._handle, B, T, _lib.ptr(cur), _lib.ptr(k["obs_src"]), _lib.ptr(k["obs_mask"]), _lib.ptr(k["latent_mask"]),
+                                 _lib.ptr(k["kinda_marg_mask"]), _lib.ptr(k["frame_indices"]), _lib.ptr(t), 2, 1, None, seed, step * B * per,
+                                 _lib.ptr(nxt), None, None, _lib.current_stream()))
+        cur = nxt
+    assert torch.equal(cur, got) and torch.isfinite(got).all(), float((cur - got).abs().max())
+    ex.begin(x_init, kw, seed=seed, renoise=True)
+    renoised = ex.run(diff.num_timesteps).clone()
+    assert not torch.equal(renoised[:, n_obs:], got[:, n_obs:])          # the latent frames see different observations
+    # infer_video asks for the as-handed form
+    import inspect
+    from video_diffusion_amd import video_sample
+    assert "renoise=False" in inspect.getsource(video_sample.infer_video)
+    model.check_device_errors()
+
+
 def test_window_prefix_cache_matches_the_uncached_window():
     """vd_set_window_prefix_cache (opt-in): the observed frames' activations before the first attention layer are computed
     once per window, the captured step runs those blocks on the other frames only.  Per frame it is the same arithmetic
@@ -1236,3 +1279,44 @@ def test_cond_emb_variants_and_learn_sigma_match_reference_golden(name):
         close(sample.cpu(), rec[f"{name}_t{t_val}_psample"], atol=1e-4, rtol=1e-4)
         s2, _ = diff._step(1, model, x, t, True, None, kwargs_of(c), 1.0, c["noise"])
         close(s2.cpu(), rec[f"{name}_t{t_val}_ddim_eta1"], atol=2e-4, rtol=2e-4)
+
+
+def test_fp16_range_overflow_is_loud_in_the_product():
+    """f16x3 carries fp32 operands as fp16 pieces: |x| > 65504 becomes inf and the product NaN.  That NaN must not
+    leave through clip_denoised's clamp as a plausible -1 (fmaxf(NaN, -1) = -1): the posterior kernel keeps the element NaN and
+    sets bit 1 of the sticky device word, check_device_errors raises FloatingPointError naming VD_MATH=bf16x6, and every product
+    loop (p_sample_loop, ddim_sample_loop, infer_video) checks at its end.  A 6e4 input is inside the range and stays silent."""
+    from video_diffusion_amd import video_sample
+    if vda._lib.lib().vd_version().decode().find("f16x3") < 0:
+        pytest.skip("the fp16 exponent range only binds the f16x3 arithmetic")
+    cfg = json.loads(str(load_npz("unet_tiny.npz")["cfg_json"]))
+    model, diff = engine(cfg)
+    rec = load_npz("unet_tiny.npz")
+    c = case_inputs(rec, 0)
+    kw = kwargs_of(c)
+    x = c["x"].cuda().clone()
+    t = c["t"].cuda()
+    model.check_device_errors()
+    ok = x.clone(); ok[0, -1, 0, 3, 3] = 6.0e4                        # inside fp16's range: finite, no flag
+    out = diff.p_sample(model, ok, t, clip_denoised=True, model_kwargs=kw)
+    assert torch.isfinite(out["sample"]).all()
+    model.check_device_errors()
+    bad = x.clone(); bad[0, -1, 0, 3, 3] = 7.0e4                      # a latent frame's pixel beyond 65504: the stem GEMM's operand overflows
+    out = diff.p_sample(model, bad, t, clip_denoised=True, model_kwargs=kw)
+    assert not torch.isfinite(out["sample"]).all() and not torch.isfinite(out["pred_xstart"]).all()   # NOT clamped into [-1, 1]
+    with pytest.raises(FloatingPointError, match="bf16x6"):
+        model.check_device_errors()
+    model.check_device_errors()                                       # the word is cleared by the read
+    out = diff.ddim_sample(model, bad, t, clip_denoised=True, model_kwargs=kw)
+    with pytest.raises(FloatingPointError):
+        model.check_device_errors()
+    # the loops notice by themselves: p_sample_loop from a noise tensor that carries the outlier
+    with pytest.raises(FloatingPointError):
+        diff.p_sample_loop(model, tuple(x.shape), noise=bad, clip_denoised=True, model_kwargs=kw)
+    # ... and so does the sampling driver: an observed frame beyond the range in the test-set batch
+    B, T = x.shape[:2]
+    batch = torch.rand(B, T, 3, x.shape[-1], x.shape[-1]) * 2 - 1
+    batch[0, 0, 1, 2, 2] = 7.0e4
+    with pytest.raises(FloatingPointError):
+        video_sample.infer_video("independent", model, diff, batch, max_frames=T, obs_length=2, step_size=T - 2)
+    model.check_device_errors()

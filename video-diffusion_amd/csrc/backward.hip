@@ -587,7 +587,9 @@ __global__ __launch_bounds__(256) void guided_grad_kernel(GuidedArgs a) {
         const float* tb = a.tab + (int)tl;
         const float x = a.x[i], e = a.eps[i];
         const float x0r = tb[TAB_SQRT_RECIP * NT] * x - tb[TAB_SQRT_RECIPM1 * NT] * e;
-        const float x0 = a.clip ? fminf(fmaxf(x0r, -1.0f), 1.0f) : x0r;
+        const bool bad = !(fabsf(x0r) <= 3.4028234e38f);              // (posterior_kernel: a non-finite eps must not be clamped into range)
+        if (bad && a.err) atomicOr(a.err, VD_ERR_NONFINITE);
+        const float x0 = (a.clip && !bad) ? fminf(fmaxf(x0r, -1.0f), 1.0f) : x0r;
         const float mean = tb[TAB_COEF1 * NT] * x0 + tb[TAB_COEF2 * NT] * x;
         const float nz = tl != 0 ? 1.0f : 0.0f;
         const float smp = mean + nz * expf(0.5f * tb[TAB_LOGVAR * NT]) * a.noise[i];

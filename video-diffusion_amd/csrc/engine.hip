@@ -260,7 +260,7 @@ struct vd_engine {
     std::vector<float*> attn_cap_t, attn_cap_s;
     int attn_seq = 0;
     int mean_type = 0;                               // what the network's output IS: 0 eps (ModelMeanType.EPSILON), 1 x_0 (START_X)
-    int* d_err = nullptr;                            // sticky device flags: bit 0 = timestep index out of range
+    int* d_err = nullptr;                            // sticky device flags: bit 0 = timestep index out of range, bit 1 = network output not finite
     int device = -1;
     double* d_part = nullptr; size_t part_cap = 0;   // NLL partial sums
     // ---- window executor (vd_window_*): device-resident step state + one captured graph per window signature
@@ -982,6 +982,9 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
             }
             cur = nxt;
             second = nullptr;
+            // a request the dry run did not see was served from the arena's base (Arena::get): stop before anything else is enqueued on
+            // top of the aliased tensors -- inside a capture this also keeps the broken step out of the graph
+            VD_REQUIRE(!ar.overflow, "workspace overflow: the forward asked for more than the dry run measured (this step's output is invalid)");
         }
         *outp = cur;
         return 0;
@@ -1643,6 +1646,7 @@ static int step_launches(vd_engine* e, int mode, int B, int T, const float* x, c
     if ((rc = e->forward(fi, st, ar, pp, sp))) return rc;
     PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
                      mode, eta, seed, offset, sample, xstart, mean, rng};
+    pa.err = e->d_err;
     if (e->mean_type == 1) pa.x0_given = eps;        // START_X: pred_xstart = process_xstart(model_output) (gaussian_diffusion.py:326-341)
     ProfScope ps(PC_POSTERIOR, 0.0, 4.0 * B * per * 5.0, st);
     return launch_posterior(pa, st);
@@ -1698,6 +1702,7 @@ int vd_vb_terms(vd_engine* e, int B, int T, const float* x_start, const float* x
     if (rc) return rc;
     VbArgs a{x_start, x_t, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, latent_mask, B, T, per,
              clip, pred_xstart, e->d_part, nblk, vb, xstart_mse, mse};
+    a.err = e->d_err;
     return launch_vb_terms(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1737,7 +1742,10 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     if (rc) return rc;
     VD_REQUIRE(e->d_tab, "vd_set_schedule not called");
     VD_REQUIRE(x && obs_src && obs && lat && km && fidx, "null tensor");
-    VD_REQUIRE(obs_mode >= 0 && obs_mode <= 2, "observed_frames must be x_0 / x_t / x_t_minus_1");
+    VD_REQUIRE(obs_mode >= 0 && obs_mode <= 3, "observed_frames must be x_0 / x_t / x_t_minus_1 (2: re-noised per step, 3: the caller's tensor as it is)");
+    // 3 = 'x_t_minus_1' with the caller's tensor read as it is at every step -- what scripts/video_sample.py:149-166 does (it hands x0 as a
+    // clean placeholder); 2 = p_sample_loop's form, which re-noises the clean frames to t - 1 before each step (gaussian_diffusion.py:565-568)
+    const int net_mode = obs_mode == 3 ? 2 : obs_mode;
     VD_REQUIRE(sampler == 0 || sampler == 1, "sampler: 0 p_sample, 1 ddim_sample");
     VD_REQUIRE(t_start >= 0 && t_start < e->num_timesteps, "t_start outside the schedule");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1825,7 +1833,7 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
         Arena ar; ar.base = e->ws; ar.cap = e->ws_tail;                   // the activations end where t_model and the eps scratch begin
         if (obs_mode == 2 && (rc = launch_q_sample_prev(obs_src, reinterpret_cast<const int64_t*>(e->d_win_t), e->d_tab, e->num_timesteps, B, (long)per_w,
                                                         e->d_win_rng, (unsigned long long)B * per_w / 2, e->d_win_xtm1, st))) return rc;
-        FwdIn fi{B, T, x, net_obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), obs_mode, eps};
+        FwdIn fi{B, T, x, net_obs_src, obs, lat, km, tm, reinterpret_cast<const int64_t*>(fidx), net_mode, eps};
         if ((rc = e->forward(fi, st, ar))) return rc;
         VD_HIP(hipStreamSynchronize(st));
     }
@@ -1856,7 +1864,7 @@ int vd_window_begin(vd_engine* e, int B, int T, float* x, const float* obs_src, 
     VD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     rc = obs_mode == 2 ? launch_q_sample_prev(obs_src, reinterpret_cast<const int64_t*>(e->d_win_t), e->d_tab, e->num_timesteps, B, (long)per,
                                               e->d_win_rng, (unsigned long long)B * per / 2, e->d_win_xtm1, st) : 0;
-    if (!rc) rc = step_launches(e, sampler, B, T, x, net_obs_src, obs, lat, km, fidx, e->d_win_t, obs_mode, clip, eta, nullptr, 0, 0,
+    if (!rc) rc = step_launches(e, sampler, B, T, x, net_obs_src, obs, lat, km, fidx, e->d_win_t, net_mode, clip, eta, nullptr, 0, 0,
                                 e->d_win_rng, x, nullptr, nullptr, nullptr, st, pre_on ? &plan : nullptr, suf_on ? &splan : nullptr);
     if (!rc) {
         hipLaunchKernelGGL(win_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->d_win_t, e->d_win_rng, B,
@@ -1951,6 +1959,7 @@ int vd_posterior_update(vd_engine* e, int mode, int B, long long per, const floa
     VD_REQUIRE(x && eps && t && sample && (mode == 0 || mode == 1), "arguments");
     PosteriorArgs pa{x, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
                      mode, eta, seed, offset, sample, xstart, nullptr, nullptr};
+    pa.err = e->d_err;
     return launch_posterior(pa, static_cast<hipStream_t>(stream));
 }
 
@@ -1962,6 +1971,7 @@ int vd_posterior_from_xstart(vd_engine* e, int mode, int B, long long per, const
     PosteriorArgs pa{x, nullptr, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, (long)per, clip,
                      mode, eta, seed, offset, sample, xstart, mean, nullptr};
     pa.x0_given = xstart_in;
+    pa.err = e->d_err;
     return launch_posterior(pa, static_cast<hipStream_t>(stream));
 }
 
@@ -2083,6 +2093,7 @@ int vd_guided_step(vd_engine* e, int B, int T, const float* x, const float* obs,
     if (!rc) {
         GuidedArgs ga{x, eps, noise, x_t_minus_1, obs, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, B, T, (long)per, clip,
                       deps, dxd, mean0, xstart ? xstart : xs0};
+        ga.err = e->d_err;
         rc = launch_guided_grad(ga, st);
         if (!rc) rc = e->backward(fi, deps, dxn, st, ar);
         if (!rc) rc = launch_guided_final(ga, dxn, noise2, grad, mean, sample, st);

@@ -375,6 +375,7 @@ int launch_randn(float* out, long n, unsigned long long seed, unsigned long long
 __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
     const size_t total = (size_t)a.B * a.per;
     if (a.dstate) { a.seed = a.dstate[0]; a.offset = a.dstate[1]; }
+    bool nonfinite = false;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int b = (int)(i / a.per);
         const long long tl = a.t[b];
@@ -389,7 +390,11 @@ __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
         const float* tb = a.tab + t;
         const float x = a.x[i];
         float x0 = a.x0_given ? a.x0_given[i] : tb[TAB_SQRT_RECIP * NT] * x - tb[TAB_SQRT_RECIPM1 * NT] * a.eps[i];
-        if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        // A network output that is not finite -- in the f16x3 arithmetic: an operand beyond fp16's range (|x| > 65504) anywhere in the
+        // network -- must not leave through the clamp below as a plausible -1 (fmaxf(NaN, -1) = -1): it stays NaN and sets bit 1.
+        const bool bad = !(fabsf(x0) <= 3.4028234e38f);
+        nonfinite |= bad;
+        if (a.clip && !bad) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
         if (a.xstart) a.xstart[i] = x0;
         if (a.mean) a.mean[i] = tb[TAB_COEF1 * NT] * x0 + tb[TAB_COEF2 * NT] * x;
         if (!a.sample) continue;                 // p_mean_variance only
@@ -408,6 +413,7 @@ __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
         }
         a.sample[i] = smp;
     }
+    if (nonfinite && a.err) atomicOr(a.err, VD_ERR_NONFINITE);     // (never taken on a healthy step: no cost beside the compare above)
 }
 
 int launch_posterior(const PosteriorArgs& a, hipStream_t s) {
@@ -486,7 +492,9 @@ __global__ __launch_bounds__(256) void vb_terms_kernel(VbArgs a) {
         const size_t i = (size_t)b * a.per + j;
         const float xs = a.x_start[i], xt = a.x_t[i];
         float x0 = sr * xt - srm1 * a.eps[i];
-        if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        const bool bad = !(fabsf(x0) <= 3.4028234e38f);               // (posterior_kernel: a non-finite eps must not be clamped into range)
+        if (bad && a.err) atomicOr(a.err, VD_ERR_NONFINITE);
+        if (a.clip && !bad) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
         if (a.pred_xstart) a.pred_xstart[i] = ok ? x0 : __builtin_nanf("");
         const float mean = c1 * x0 + c2 * xt, tmean = c1 * xs + c2 * xt;
         const float m = a.mask ? a.mask[(size_t)b * a.T + j / fsz] : 1.0f;

@@ -312,7 +312,10 @@ struct PosteriorArgs {
     float* mean;                    // p_mean_variance's 'mean' (posterior mean of the clipped x0 prediction), or null
     const unsigned long long* dstate;   // window executor: {seed, offset} read from device memory instead of the arguments
     const float* x0_given = nullptr;    // denoised_fn path: the caller's x_0 prediction replaces the one derived from eps
+    int* err = nullptr;                 // the engine's sticky error word: bit 1 is set when the network output (eps, or the x_0 handed in)
+                                        // is not finite -- the clamp of clip_denoised would otherwise turn a NaN into a plausible -1 silently
 };
+enum { VD_ERR_TIMESTEP = 1, VD_ERR_NONFINITE = 2 };
 int launch_posterior(const PosteriorArgs& a, hipStream_t s);
 int launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab, int num_timesteps, int B,
                     long per, float* out, hipStream_t s);
@@ -361,6 +364,7 @@ struct GuidedArgs {
     int B, T; long per; int clip;
     float* deps; float* dxd;            // d loss / d eps, and the direct part of d loss / d x
     float* mean; float* xstart;         // the unguided posterior mean and the x_0 prediction
+    int* err = nullptr;                 // sticky error word (bit 1: eps not finite)
 };
 int launch_guided_grad(const GuidedArgs& a, hipStream_t s);
 int launch_guided_final(const GuidedArgs& a, const float* dx_net, const float* noise2, float* grad, float* mean_out, float* sample,
@@ -379,6 +383,7 @@ struct VbArgs {
     double* part;                // [B][nblk][3] partial sums
     int nblk;
     float* vb; float* xstart_mse; float* mse;      // [B] outputs (the last two may be null)
+    int* err = nullptr;          // sticky error word (bit 1: eps not finite)
 };
 int launch_vb_terms(const VbArgs& a, hipStream_t s);
 int vb_terms_blocks(long per);

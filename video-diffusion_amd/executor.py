@@ -11,9 +11,12 @@ same graph: CARLA's 47 windows need two graphs (Tw = 20 and Tw = 14).
 
 Noise: the engine's counter-based generator (Philox4x32-10 + Box-Muller inside the posterior kernel) with a seed drawn
 from torch's global generator, so `torch.manual_seed` still makes a run reproducible; the draws are N(0, 1) like the
-reference's `th.randn_like`, not the same stream.  `observed_frames` in {'x_0', 'x_t', 'x_t_minus_1'}; with 'x_t_minus_1' every
-step first re-noises the clean observed frames to t - 1 inside the graph (q_sample from the same Philox stream), which is what
-p_sample_loop does on the host before each step (gaussian_diffusion.py:565-568).
+reference's `th.randn_like`, not the same stream.  `observed_frames` in {'x_0', 'x_t', 'x_t_minus_1'}.  'x_t_minus_1' has two
+callers in the reference and they differ: `p_sample_loop` re-noises the clean observed frames to t - 1 before each step
+(gaussian_diffusion.py:565-568) -- `renoise=True`, the default here: q_sample inside the graph from the same Philox stream --
+while scripts/video_sample.py:149-166 calls `p_sample` directly with `x_t_minus_1 = x0`, a clean placeholder that is read as it
+is at every step -- `renoise=False`, what `infer_video` passes, so that its graph and eager executors sample the same
+conditional distribution.
 """
 import torch as th
 
@@ -46,8 +49,10 @@ class WindowExecutor:
                                    kinda_marg_mask=f(B * T), frame_indices=th.zeros(B, T, dtype=th.int64, device=dev))
         return self._bufs[key]
 
-    def begin(self, x_init, model_kwargs, t_start=None, seed=None, sampler="p_sample", eta=0.0, clip_denoised=True):
-        """Arm a window: copy its tensors into the executor's buffers, set the device counters, capture if new."""
+    def begin(self, x_init, model_kwargs, t_start=None, seed=None, sampler="p_sample", eta=0.0, clip_denoised=True, renoise=True):
+        """Arm a window: copy its tensors into the executor's buffers, set the device counters, capture if new.
+        renoise ('x_t_minus_1' only): True = p_sample_loop's form, the clean model_kwargs['x0'] frames re-noised to t - 1 inside
+        every step; False = model_kwargs['x_t_minus_1'] read as it is at every step (a direct p_sample caller)."""
         mode = model_kwargs.get("observed_frames", "x_0")
         if mode not in _OBS_MODES:
             raise NotImplementedError(f"observed_frames={mode!r}: the window executor handles 'x_0', 'x_t' and 'x_t_minus_1'")
@@ -71,8 +76,10 @@ class WindowExecutor:
                 bufs[k].copy_(kw[k].view(bufs[k].shape))
             if mode == "x_0":
                 bufs["obs_src"].copy_(kw["obs_src"])
-            elif mode == "x_t_minus_1":                                # the CLEAN frames: the graph draws q_sample(x0, t - 1) from them
+            elif mode == "x_t_minus_1" and renoise:                    # the CLEAN frames: the graph draws q_sample(x0, t - 1) from them
                 bufs["obs_src"].copy_(model_kwargs["x0"].to(device=bufs["obs_src"].device, dtype=th.float32))
+            elif mode == "x_t_minus_1":                                # the caller's tensor, read as it is by every step
+                bufs["obs_src"].copy_(kw["obs_src"])
             if seed is None:
                 seed = int(th.randint(0, 2 ** 62, (1,)).item())        # torch.manual_seed governs the run
             if t_start is None:
@@ -83,7 +90,7 @@ class WindowExecutor:
             _lib.check(_lib.lib().vd_window_begin(
                 self.model._handle, B, T, _lib.ptr(bufs["x"]), _lib.ptr(obs_src), _lib.ptr(bufs["obs_mask"]),
                 _lib.ptr(bufs["latent_mask"]), _lib.ptr(bufs["kinda_marg_mask"]), _lib.ptr(bufs["frame_indices"]),
-                _OBS_MODES[mode], 0 if sampler == "p_sample" else 1, 1 if clip_denoised else 0, float(eta), seed, 0,
+                3 if (mode == "x_t_minus_1" and not renoise) else _OBS_MODES[mode], 0 if sampler == "p_sample" else 1, 1 if clip_denoised else 0, float(eta), seed, 0,
                 int(t_start), self.stream.cuda_stream))
         self.x = bufs["x"]
         self.seed = seed
@@ -104,9 +111,9 @@ class WindowExecutor:
         th.cuda.current_stream(self.model.device).wait_stream(self.stream)
         return self.x
 
-    def sample_window(self, x_init, model_kwargs, sampler="p_sample", eta=0.0, seed=None):
+    def sample_window(self, x_init, model_kwargs, sampler="p_sample", eta=0.0, seed=None, renoise=True):
         """All num_timesteps steps of one window; returns a fresh tensor."""
-        self.begin(x_init, model_kwargs, seed=seed, sampler=sampler, eta=eta)
+        self.begin(x_init, model_kwargs, seed=seed, sampler=sampler, eta=eta, renoise=renoise)
         return self.run(self.diffusion.num_timesteps).clone()
 
     @property

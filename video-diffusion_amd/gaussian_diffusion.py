@@ -459,6 +459,7 @@ class GaussianDiffusion:
                         per_item = r / r.mean() * per_item.mean()
                     acc = acc + per_item / (self.num_timesteps / 4)
                 attns[tag] = acc
+        getattr(model, "check_device_errors", lambda: None)()       # the loop's end synchronises anyway: a non-finite network output / bad index of ANY step surfaces here
         return final["sample"], attns
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
@@ -496,6 +497,7 @@ class GaussianDiffusion:
                                                         denoised_fn=denoised_fn, model_kwargs=model_kwargs,
                                                         device=device, progress=progress, eta=eta):
             final = sample
+        getattr(model, "check_device_errors", lambda: None)()
         return final["sample"]
 
     def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,

@@ -108,7 +108,9 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
         if t_tensors is None:          # the reference re-creates this tensor every step (video_sample.py:154-155)
             t_tensors = [torch.tensor([ts] * B, device=device) for ts in range(diffusion.num_timesteps)]
         if use_graph:
-            write_back(wex.sample_window(x0, model_kwargs, sampler=sampler, eta=eta))
+            # renoise=False: like the eager loop below (and scripts/video_sample.py:149-166), every step reads x_t_minus_1 = x0 as it is
+            write_back(wex.sample_window(x0, model_kwargs, sampler=sampler, eta=eta, renoise=False))
+            model.check_device_errors()
             continue
         local_samples = x0.clone()
         for timestep in timesteps:
@@ -120,6 +122,7 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
                 local_samples = diffusion.ddim_sample(model, local_samples, t=t_tensors[timestep], clip_denoised=True,
                                                       model_kwargs=model_kwargs, eta=eta)["sample"]
         write_back(local_samples)
+        model.check_device_errors()    # once per window (write_back has synchronised): a non-finite network output of any of its steps raises here
     return samples.numpy(), None
 
 

@@ -115,6 +115,7 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
             horizontal.append(samples.clone())
     if save_all_timesteps and horizontal:
         all_timestep_samples[:, vertical_steps:] = torch.stack(horizontal, dim=1)
+    model.check_device_errors()        # a non-finite network output of any step (vd_device_errors bit 1) raises instead of ending up in the .npy
     return samples.cpu().numpy(), all_timestep_samples.cpu().numpy()
 
 
