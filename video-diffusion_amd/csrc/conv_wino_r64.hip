@@ -73,6 +73,9 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #ifndef VD_R64_B2REG
 #define VD_R64_B2REG 1     // f16x3: the third weight piece 2^-12 b0 formed in registers (conv_wino_z128.hip) instead of loaded (A/B: 0)
 #endif
+#ifndef VD_R64_MIXHI
+#define VD_R64_MIXHI 0     // 1: the a1 piece by v_fma_mixlo/hi_f16 (scale + round in one instruction per value instead of v_ldexp_f32 x 2 +
+#endif                     // v_cvt_pk_f16_f32: 10.31 instead of 10.98 instructions per MFMA, same bits) -- measured 0 .. 5 % SLOWER per layer (r05b), off
 #ifndef VD_R64_ABL
 #define VD_R64_ABL 0       // timing-only builds of the main loop (results WRONG; tools/build_variant.sh): bit 0 no weight reloads, 1 no
 #endif                     // transform / split, 2 no patch requests, 3 no patch reads, 4 no MFMA -- never set in the product library
@@ -236,6 +239,32 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     // r * 2^12, round -- and channels 2k, 2k+1 of the NEXT position's V (column combination X -/+ Y).  `early`: the piece is read
     // by the MFMA of the next slot, and a VALU write needs two wait states before an MFMA reads it as A / B: the combination
     // goes behind the conversion.
+#if VD_R64_MIXHI
+    // a1 = f16((x - a0) * 2^12) with the scale and the rounding in ONE instruction per value: v_fma_mixlo_f16 / v_fma_mixhi_f16 write one half of
+    // the pair register each (fma(r, 4096, 0) is exact in fp32, the conversion rounds to nearest even: the bits of v_ldexp_f32 + v_cvt_pk_f16_f32).
+    // The half-register write wants a wait state before a VALU reads the register again (hipcc pads it with s_nop: round 4's first loop); here
+    // the next reader is an MFMA two or more instructions later, and the two halves are written with an independent instruction between them
+    // where the slot allows: 6 vector instructions per slot instead of 7 -- what fits beside an MFMA (LAB_NOTES R4.4).
+#define VD_R64_A1 "v_fma_mix_f32 %3, %5, -1.0, %6 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %4, %5, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+#define VD_R64_LO "v_fma_mixlo_f16 %0, %3, %12, 0 op_sel_hi:[0,0,0]\n\t"
+#define VD_R64_HI "v_fma_mixhi_f16 %0, %4, %12, 0 op_sel_hi:[0,0,0]\n\t"
+#define VD_R64_A1_OPS : "=&v"(af[cur][1][k]), "=&v"(tv[nxt][2 * k]), "=&v"(tv[nxt][2 * k + 1]), "=&v"(r0), "=&v"(r1) \
+                      : "v"(af[cur][0][k]), "v"(tv[cur][2 * k]), "v"(tv[cur][2 * k + 1]), "v"(t[cx][2 * k]), "v"(t[cy][2 * k]), "v"(t[cx][2 * k + 1]), "v"(t[cy][2 * k + 1]), "s"(k4096)
+    const float k4096 = 4096.0f;
+    auto f16_slot_a = [&](int cur, int nxt, int k, int jn, bool early) {
+        const int cx = jn == 0 ? 0 : jn == 2 ? 2 : 1, cy = jn == 0 ? 2 : jn == 1 ? 2 : jn == 2 ? 1 : 3;      // V[jn] = t[cx] - t[cy] (jn = 1: +)
+        float r0, r1;
+        if (jn == 1) {
+            if (early) asm(VD_R64_A1 VD_R64_LO VD_R64_HI "v_add_f32 %1, %8, %9\n\tv_add_f32 %2, %10, %11" VD_R64_A1_OPS);
+            else asm(VD_R64_A1 "v_add_f32 %1, %8, %9\n\t" VD_R64_LO "v_add_f32 %2, %10, %11\n\t" VD_R64_HI VD_R64_A1_OPS);
+        } else {
+            if (early) asm(VD_R64_A1 VD_R64_LO VD_R64_HI "v_sub_f32 %1, %8, %9\n\tv_sub_f32 %2, %10, %11" VD_R64_A1_OPS);
+            else asm(VD_R64_A1 "v_sub_f32 %1, %8, %9\n\t" VD_R64_LO "v_sub_f32 %2, %10, %11\n\t" VD_R64_HI VD_R64_A1_OPS);
+        }
+    };
+#undef VD_R64_LO
+#undef VD_R64_HI
+#else
 #define VD_R64_A1 "v_fma_mix_f32 %3, %5, -1.0, %6 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %4, %5, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
                   "v_ldexp_f32 %3, %3, 12\n\tv_ldexp_f32 %4, %4, 12\n\t"
 #define VD_R64_A1_OPS : "=&v"(af[cur][1][k]), "=&v"(tv[nxt][2 * k]), "=&v"(tv[nxt][2 * k + 1]), "=&v"(r0), "=&v"(r1) \
@@ -251,6 +280,7 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
             else asm(VD_R64_A1 "v_sub_f32 %1, %8, %9\n\tv_sub_f32 %2, %10, %11\n\tv_cvt_pk_f16_f32 %0, %3, %4" VD_R64_A1_OPS);
         }
     };
+#endif
 #undef VD_R64_A1
 #undef VD_R64_A1_OPS
     // Slot 4: the a0 piece of the next position's fragment (four conversions) + channels 0, 1 of the next group's t column c

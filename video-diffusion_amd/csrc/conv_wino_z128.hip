@@ -36,6 +36,9 @@ constexpr int P = 18, SPP = 10, PLB = SPP * 64, RSB = 2 * PLB, NX = 6, XBUF = NX
 constexpr int LDS_BYTES = (NB + 1) * XBUF;                     // + the spare buffer for requests past the last chunk
 }  // namespace z128
 
+#ifndef VD_Z128_MIXHI
+#define VD_Z128_MIXHI 0     // 1: v_fma_mixlo/hi_f16 for the a1 piece (conv_wino_r64.hip: one instruction fewer per pair, measured no faster; r05b)
+#endif
 #ifdef VD_WINO_TIMING
 __device__ unsigned long long g_z128_stamp[16];
 #define Z128_STAMP(i)                                                                                 \
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     // Each part is ONE asm statement: hipcc pads every asm output that the next instruction reads with an s_nop, and an s_nop is
     // an issue slot like any other (conv_wino_r64.hip).
     float pa0, pa1, pb0, pb1, pv0, pv1;                              // in flight between the parts of one block
+    const float k4096 = 4096.0f;
     auto frag_part = [&](int nxt, int jn, int b, int part) {         // block b of 8: m = b >> 2, pair b & 3
         const int m = b >> 2, pr = b & 3, h = pr >> 1, e0 = 2 * (pr & 1);
         if (part == 0) {
@@ -154,9 +158,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
 #undef VD_Z128_P01
         } else {
             float r0, r1;
+#if VD_Z128_MIXHI
+            // scale + round in one instruction per value (conv_wino_r64.hip: v_fma_mixlo/hi_f16; the register is next read by an MFMA of the
+            // following position): 4 instructions instead of 5
+            asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mixlo_f16 %0, %1, %6, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %2, %6, 0 op_sel_hi:[0,0,0]"
+                : "=&v"(af[nxt][m][1][pr]), "=&v"(r0), "=&v"(r1) : "v"(af[nxt][m][0][pr]), "v"(pv0), "v"(pv1), "s"(k4096));
+#else
             asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
                 "v_ldexp_f32 %1, %1, 12\n\tv_ldexp_f32 %2, %2, 12\n\tv_cvt_pk_f16_f32 %0, %1, %2"
                 : "=&v"(af[nxt][m][1][pr]), "=&v"(r0), "=&v"(r1) : "v"(af[nxt][m][0][pr]), "v"(pv0), "v"(pv1));
+#endif
         }
     };
     // The 24 parts of a position run in its steps 3 .. 23 (reads: two per step in steps 0 .. 7, the four of blocks 2g, 2g + 1 in
