@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--image-size", type=int, default=64)
     ap.add_argument("--respacing", default="ddim250")
     ap.add_argument("--num-res-blocks", type=int, default=2)
+    ap.add_argument("--sampler", choices=["p_sample", "ddim"], default="p_sample",
+                    help="ddim: ddim_sample with eta = 0 (SURVEY 8d config 2 asks for it beside the p_sample headline; the default run reports it as `ddim_sample_eta0`)")
     ap.add_argument("--executor", choices=["eager", "graph"], default="eager",
                     help="graph: the window executor (one captured hipGraph per window shape, device-resident step counter)")
     ap.add_argument("--prefix-cache", action="store_true",
@@ -69,6 +71,9 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32-ref", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--parity-margin", action="store_true",
+                    help="also report max |eps - reference eps| of the headline window against tests/golden/unet_full64_b8.npz (the default run "
+                         "does, for its own arithmetic and, through its VD_MATH children, for the other two)")
     ap.add_argument("--no-full-window", action="store_true",
                     help="skip the whole-window leg (one 250-step window through video_sample.infer_video, ~6 s)")
     return ap.parse_args()
@@ -139,10 +144,11 @@ def make_window(B, T, S, n_obs, seed, device):
 class Stepper:
     """The hot loop of video_sample.py:150-168 on the C ABI with every per-step host allocation hoisted out."""
 
-    def __init__(self, model, diff, kw, seed):
+    def __init__(self, model, diff, kw, seed, sampler="p_sample", eta=0.0):
         import torch
         from video_diffusion_amd import _lib
         self._lib = _lib
+        self.sampler, self.eta = sampler, float(eta)
         self.model, self.diff, self.seed = diff._bind(model), diff, seed
         x = kw["x0"].clone().float().contiguous()
         self.B, self.T = x.shape[:2]
@@ -157,10 +163,13 @@ class Stepper:
         _lib = self._lib
         src, dst = self.bufs[self.count & 1], self.bufs[(self.count + 1) & 1]
         k = self.k
-        rc = _lib.lib().vd_p_sample(self.model._handle, self.B, self.T, _lib.ptr(src), _lib.ptr(k["obs_src"]),
-                                    _lib.ptr(k["obs_mask"]), _lib.ptr(k["latent_mask"]), _lib.ptr(k["kinda_marg_mask"]),
-                                    _lib.ptr(k["frame_indices"]), _lib.ptr(self.ts[t_index]), k["obs_mode"], 1, None,
-                                    self.seed, self.count * self.B * self.per, _lib.ptr(dst), None, None, self.stream)
+        args = (self.model._handle, self.B, self.T, _lib.ptr(src), _lib.ptr(k["obs_src"]), _lib.ptr(k["obs_mask"]), _lib.ptr(k["latent_mask"]),
+                _lib.ptr(k["kinda_marg_mask"]), _lib.ptr(k["frame_indices"]), _lib.ptr(self.ts[t_index]), k["obs_mode"], 1)
+        tail = (None, self.seed, self.count * self.B * self.per, _lib.ptr(dst), None, None, self.stream)
+        if self.sampler == "p_sample":
+            rc = _lib.lib().vd_p_sample(*args, *tail)
+        else:                                                # ddim_sample (gaussian_diffusion.py:597-634)
+            rc = _lib.lib().vd_ddim_sample(*args, self.eta, *tail)
         _lib.check(rc)
         self.count += 1
         return dst
@@ -251,6 +260,38 @@ def profile_step(stepper, t_index):
     return rows
 
 
+def parity_margin(vda, model, diff, cfg):
+    """max |eps - eps_reference| of the HEADLINE window (B = 8 x T = 16 x 64 x 64, default 116 M model) against the fixture the imported
+    reference produced for it (tests/golden/unet_full64_b8.npz, tools/gen_golden_r4.py: every 4th pixel of every frame), in the process'
+    arithmetic -- the end-to-end accuracy beside the speed.  `tol_used` = max |d| / (1e-4 + 1e-4 |ref|): the share of the tier's tolerance."""
+    import numpy as np
+    import torch
+    path = os.path.join(ROOT, "tests", "golden", "unet_full64_b8.npz")
+    if not os.path.exists(path):
+        return None
+    rec = dict(np.load(path, allow_pickle=False))
+    gcfg = json.loads(str(rec["cfg_json"]))
+    if any(gcfg.get(k) != cfg.get(k) for k in gcfg if k in cfg):
+        return {"skipped": "the bench configuration is not the fixture's"}
+    B, T, n_obs, seed, S = int(rec["B"][0]), int(rec["T"][0]), int(rec["n_obs"][0]), int(rec["seed"][0]), gcfg["image_size"]
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.rand(B, T, 3, S, S, generator=g) * 2 - 1
+    x0[:, n_obs:] = 0
+    obs = torch.zeros(B, T, 1, 1, 1)
+    obs[:, :n_obs] = 1
+    x = torch.randn(B, T, 3, S, S, generator=torch.Generator().manual_seed(seed + 1))
+    dev = model.device
+    kw = dict(frame_indices=torch.arange(T).view(1, T).repeat(B, 1).to(dev), x0=x0.to(dev), obs_mask=obs.to(dev), latent_mask=(1 - obs).to(dev),
+              kinda_marg_mask=torch.zeros(B, T, 1, 1, 1).to(dev), x_t_minus_1=x0.to(dev), observed_frames="x_0")
+    t = torch.tensor([int(rec["t"][0])] * B, device=dev)
+    got, _ = diff._wrap_model(model)(x.to(dev), t, **kw)
+    got = got.cpu().double().numpy()[:, :, :, ::4, ::4]
+    ref = rec["eps_sub"].astype(np.float64)
+    d = np.abs(got - ref)
+    return {"max_abs_deps": float(d.max()), "mean_abs_deps": float(d.mean()), "tol_used": float((d / (1e-4 + 1e-4 * np.abs(ref))).max()),
+            "eps_absmax": float(rec["eps_absmax"][0]), "values": int(d.size)}
+
+
 def host_cores():
     """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota
     (a GPU box advertises every core of the host but grants a share of them)."""
@@ -272,7 +313,7 @@ def host_cores():
 
 def cpu_baseline(cfg, sd, B, T, n_obs, t_index, nts):
     """The oracle (a torch-CPU fp32 restatement of the reference; kind 'port') on the node's host cores:
-    1 warm-up + the median of 3 timed steps, bounded to ~1 minute by VD_CPU_BASELINE_BUDGET_S."""
+    1 warm-up + the median of VD_CPU_BASELINE_STEPS (2) timed steps, ~40 s of CPU work, bounded by VD_CPU_BASELINE_BUDGET_S."""
     import torch
     from oracle.sampler_ref import SamplerRef
     from oracle.schedule_ref import ScheduleRef
@@ -288,7 +329,7 @@ def cpu_baseline(cfg, sd, B, T, n_obs, t_index, nts):
     budget = float(os.environ.get("VD_CPU_BASELINE_BUDGET_S", "75"))
     t_all = time.perf_counter()
     times = []
-    for i in range(4):                                            # step 0 = warm-up (allocator, thread pool, oneDNN primitives)
+    for i in range(1 + int(os.environ.get("VD_CPU_BASELINE_STEPS", "2"))):   # step 0 = warm-up (allocator, thread pool, oneDNN primitives)
         t0 = time.perf_counter()
         ora.p_sample(x, t, kw, noise)
         times.append(time.perf_counter() - t0)
@@ -316,70 +357,71 @@ def main():
     # the number in the EXACT-split arithmetic (bf16x6, the default of earlier rounds) or with every matrix product on the fp32
     # MFMA, the same benchmark is run first in child processes with VD_MATH set -- started before this process touches the GPU.
     math = os.environ.get("VD_MATH") or "f16x3"
-    fp32_ref = x6_ref = pc_ref = ss_ref = None
+    fp32_ref = x6_ref = pc_ref = ss_ref = shapes_ref = None
     # (never under a profiler: its preloaded library has already initialised the GPU in this process, and starting
     # another program from such a process is not allowed on the GPU boxes)
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(
         k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ)
+    SIDE_OFF = ["--no-cpu-baseline", "--no-roofline", "--no-fp32-ref", "--no-dropin", "--no-full-window"]
+
+    def child(extra, env=None):
+        """The same benchmark in a child process (started before this process touches the GPU); its JSON line, or {'error': ...}."""
+        c = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:], *SIDE_OFF, *extra], env={**os.environ, **(env or {})},
+                           capture_output=True, text=True)
+        try:
+            return json.loads([l for l in c.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception:                                            # noqa: BLE001 - the headline run must not depend on a side leg
+            return {"error": (c.stderr or c.stdout)[-300:]}
+
+    def pick(ref, note, mode=None, **more):
+        if "error" in ref:
+            return ref
+        pm = (ref.get("parity_margin") or {}).get(mode)
+        return {"value": ref["value"], "ms_per_step": ref["ms_per_step"], **({"parity_margin": pm} if pm else {}), "note": note, **more}
+
     if args.gpus == 1 and not args.no_fp32_ref and not profiled and math == "f16x3":
-        child = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--no-cpu-baseline",
-                                "--no-roofline", "--no-fp32-ref", "--no-dropin", "--no-full-window"], env={**os.environ, "VD_MATH": "fp32"},
-                               capture_output=True, text=True)
-        try:
-            ref = json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1])
-            fp32_ref = {"value": ref["value"], "ms_per_step": ref["ms_per_step"], "note": "VD_MATH=fp32: every matrix product on v_mfma_f32_32x32x2_f32"}
-        except Exception:                                            # noqa: BLE001 - the headline run must not depend on it
-            fp32_ref = {"error": (child.stderr or child.stdout)[-300:]}
-        child = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--no-cpu-baseline",
-                                "--no-roofline", "--no-fp32-ref", "--no-dropin", "--no-full-window"], env={**os.environ, "VD_MATH": "bf16x6"},
-                               capture_output=True, text=True)
-        try:
-            ref = json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1])
-            x6_ref = {"value": ref["value"], "ms_per_step": ref["ms_per_step"],
-                      "note": "VD_MATH=bf16x6: fp32 operands split EXACTLY into three bf16 pieces, six piece products (the default "
-                              "arithmetic of rounds 1-3; same kernels, twice the MFMAs)"}
-        except Exception:                                            # noqa: BLE001
-            x6_ref = {"error": (child.stderr or child.stdout)[-300:]}
-        # the window executor with the prefix cache (opt-in): work that a window really does only once is outside its timed
-        # steps, so it is an extra object too -- `value` stays the step that recomputes every frame
+        fp32_ref = pick(child(["--parity-margin"], {"VD_MATH": "fp32"}), "VD_MATH=fp32: every matrix product on v_mfma_f32_32x32x2_f32", mode="fp32")
+        x6_ref = pick(child(["--parity-margin"], {"VD_MATH": "bf16x6"}),
+                      "VD_MATH=bf16x6: fp32 operands split EXACTLY into three bf16 pieces, six piece products (the default arithmetic of rounds "
+                      "1-3; same kernels, twice the MFMAs)", mode="bf16x6")
         if args.executor == "eager":
-            child = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--executor", "graph", "--prefix-cache",
-                                    "--no-cpu-baseline", "--no-roofline", "--no-fp32-ref", "--no-dropin", "--no-full-window"], env=dict(os.environ),
-                                   capture_output=True, text=True)
+            # the window executor's opt-in modes: work that a window really does only once (prefix cache), or that its caller never reads
+            # (suffix skip), is outside `value` -- which stays the step that recomputes every frame -- and is reported beside it
+            ref = child(["--executor", "graph", "--prefix-cache"])
+            pc_ref = pick(ref, "window executor with vd_set_window_prefix_cache: the observed frames' activations before the first attention "
+                               "layer are computed once per window (250 steps), the timed steps run those blocks on the other frames only; same "
+                               "arithmetic per frame (tests/test_gpu_engine.py: within 2e-6 of the uncached window); opt-in, NOT the headline",
+                          **({} if "error" in ref else {"cached_frames_per_window": ref["config"].get("cached_frames")}))
             try:
-                ref = json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1])
-                pc_ref = {"value": ref["value"], "ms_per_step": ref["ms_per_step"], "cached_frames_per_window": ref["config"].get("cached_frames"),
-                          "note": "window executor with vd_set_window_prefix_cache: the observed frames' activations before the first "
-                                  "attention layer are computed once per window (250 steps), the timed steps run those blocks on the other "
-                                  "frames only; same arithmetic per frame (tests/test_gpu_engine.py: within 2e-6 of the uncached window); "
-                                  "opt-in, NOT the headline"}
-            except Exception:                                        # noqa: BLE001
-                pc_ref = {"error": (child.stderr or child.stdout)[-300:]}
-            # the window suffix skip (opt-in): the headline window, and the window shapes of BASELINE configs[2] (MineRL: 20 frames, 13
-            # of them observed) and configs[4] (CARLA 128x128, 20 frames, 10 observed, DDIM-50), each with and without it
-            def graph_child(extra):
-                c = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--executor", "graph", "--no-cpu-baseline",
-                                    "--no-roofline", "--no-fp32-ref", "--no-dropin", "--no-full-window", *extra], env=dict(os.environ),
-                                   capture_output=True, text=True)
-                try:
-                    return json.loads([l for l in c.stdout.splitlines() if l.startswith("{")][-1])
-                except Exception:                                    # noqa: BLE001
-                    return {"error": (c.stderr or c.stdout)[-300:]}
-            try:
-                ref = graph_child(["--suffix-skip"])
+                ref = child(["--executor", "graph", "--suffix-skip"])
+                both = child(["--executor", "graph", "--suffix-skip", "--prefix-cache"])
                 ss_ref = {"value": ref["value"], "ms_per_step": ref["ms_per_step"], "suffix_frames_per_window": ref["config"].get("suffix_frames"),
+                          "with_prefix_cache": {"value": both.get("value"), "ms_per_step": both.get("ms_per_step"),
+                                                "cached_frames_per_window": both.get("config", {}).get("cached_frames")},
                           "note": "window executor with vd_set_window_suffix_skip: behind the last attention layer (decoder blocks at 32x32 / "
                                   "64x64, both Upsample convs, the head) the captured step runs on the frames that are not pure observations; "
                                   "those frames' samples equal the full step's to the bit (tests/test_gpu_engine.py), the observed frames' "
-                                  "entries of the window are meaningless and never read (scripts/video_sample.py:170-186); opt-in, NOT the headline"}
-                for name, shape, nsteps in (("configs2_window_20f_13obs", ["--frames", "20", "--obs", "13", "--steps", "10", "--warmup", "3"], 250),
-                                            ("configs4_window_128px_20f_10obs_ddim50", ["--image-size", "128", "--frames", "20", "--obs", "10", "--respacing", "ddim50",
-                                                                                          "--steps", "5", "--warmup", "2"], 50)):
-                    a, b = graph_child(shape), graph_child(shape + ["--suffix-skip"])
-                    ss_ref[name] = {"ms_per_step": a["ms_per_step"], "ms_per_step_suffix_skip": b["ms_per_step"],
-                                    "sec_per_window": round(a["ms_per_step"] * nsteps / 1e3, 3),
-                                    "sec_per_window_suffix_skip": round(b["ms_per_step"] * nsteps / 1e3, 3),
-                                    "suffix_frames_per_window": b["config"].get("suffix_frames"), "steps_per_window": nsteps}
+                                  "entries of the window are meaningless and never read (scripts/video_sample.py:170-186); opt-in, NOT the headline; "
+                                  "with_prefix_cache: both opt-ins together"}
+                # the window shapes of BASELINE configs[2] (MineRL 64x64: 20 frames, 13 of them observed), configs[3] (UCF101 128x128: B = 4 x
+                # T = 16, the un-respaced 1000-step schedule) and configs[4] (CARLA 128x128: 20 frames, 10 observed, DDIM-50): the eager step
+                # (what `value` is at the headline shape), the graph executor, and the graph executor with the suffix skip
+                shapes_ref = {}
+                for name, shape, nsteps, graph in (
+                        ("configs2_window_20f_13obs", ["--frames", "20", "--obs", "13", "--steps", "10", "--warmup", "3"], 250, True),
+                        ("configs3_window_128px_B4_16f_ddpm1000", ["--image-size", "128", "--batch", "4", "--respacing", "", "--steps", "8", "--warmup", "2"], 1000, False),
+                        ("configs4_window_128px_20f_10obs_ddim50", ["--image-size", "128", "--frames", "20", "--obs", "10", "--respacing", "ddim50",
+                                                                      "--steps", "5", "--warmup", "2"], 50, True)):
+                    e = child(shape)
+                    shapes_ref[name] = {"eager_ms_per_step": e.get("ms_per_step"), "eager_steps_per_sec": e.get("value"), "steps_per_window": nsteps,
+                                        "sec_per_window_eager": round(e["ms_per_step"] * nsteps / 1e3, 3) if "ms_per_step" in e else None,
+                                        **({"error": e["error"]} if "error" in e else {})}
+                    if graph:
+                        a, b2 = child(["--executor", "graph", *shape]), child(["--executor", "graph", "--suffix-skip", *shape])
+                        ss_ref[name] = {"ms_per_step": a["ms_per_step"], "ms_per_step_suffix_skip": b2["ms_per_step"],
+                                        "sec_per_window": round(a["ms_per_step"] * nsteps / 1e3, 3),
+                                        "sec_per_window_suffix_skip": round(b2["ms_per_step"] * nsteps / 1e3, 3),
+                                        "suffix_frames_per_window": b2["config"].get("suffix_frames"), "steps_per_window": nsteps}
             except Exception as e:                                   # noqa: BLE001
                 ss_ref = {**(ss_ref or {}), "error": repr(e)[-300:]}
 
@@ -419,12 +461,25 @@ def main():
     assert not args.prefix_cache or args.executor == "graph", "--prefix-cache is a mode of the window executor (--executor graph)"
     assert not args.suffix_skip or args.executor == "graph", "--suffix-skip is a mode of the window executor (--executor graph)"
     stepper = GraphStepper(model, diff, kw, seed=5 + rank, prefix_cache=args.prefix_cache, suffix_skip=args.suffix_skip) if args.executor == "graph" else \
-        Stepper(model, diff, kw, seed=5 + rank)
+        Stepper(model, diff, kw, seed=5 + rank, sampler=args.sampler)
+    assert args.sampler == "p_sample" or args.executor == "eager", "--sampler ddim: eager executor"
     nts = diff.num_timesteps
     order = list(range(nts))[::-1]
 
     elapsed = timed(stepper, order, args.warmup, args.steps, vdist, device)
     assert torch.isfinite(stepper.result()).all()
+    model.check_device_errors()                                    # a non-finite network output inside the timed steps (vd_device_errors bit 1) fails the run
+
+    # SURVEY 8d config 2 asks for the p_sample number AND, separately, ddim_sample with eta = 0 (gaussian_diffusion.py:597-634): the same
+    # window, the same network forward, the deterministic update -- timed here in the same process (never `value`)
+    ddim_leg = None
+    if world == 1 and args.executor == "eager" and args.sampler == "p_sample" and not args.no_dropin:
+        el = timed(Stepper(model, diff, kw, seed=5 + rank, sampler="ddim", eta=0.0), order, args.warmup, args.steps, vdist, device)
+        ddim_leg = {"value": round(args.steps / el, 4), "ms_per_step": round(1e3 * el / args.steps, 3),
+                    "what": "vd_ddim_sample (eta = 0) on the same window: UNet forward + the DDIM update of gaussian_diffusion.py:597-634"}
+    margin = None
+    if rank == 0 and (args.parity_margin or (world == 1 and not args.no_roofline and args.executor == "eager")):
+        margin = parity_margin(vda, model, diff, cfg)
 
     full_window = None
     if world == 1 and not args.no_full_window and args.executor == "eager" and rank == 0:
@@ -463,20 +518,24 @@ def main():
             traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
             headline = (S, args.batch, T, args.num_res_blocks) == (64, 8, 16, 2) and B == 8
+            pmc_kernels = {}
             if os.path.exists(pmc) and headline:
-                rec = json.load(open(pmc))
                 # the counters belong to the kernel source they were collected on: a kernel edited since then carries no
                 # traffic figure until tools/profile_bench.sh + tools/make_pmc_dominant.py have been re-run
                 import hashlib
-                srcs = rec.get("kernel_sources", {})
-                fresh = bool(srcs) and all(
-                    os.path.exists(os.path.join(ROOT, f)) and hashlib.sha1(open(os.path.join(ROOT, f), "rb").read()).hexdigest() == h
-                    for f, h in srcs.items())
-                if rec.get("kernel") == name and fresh:
+
+                def fresh(r):
+                    srcs = r.get("kernel_sources", {})
+                    return bool(srcs) and all(os.path.exists(os.path.join(ROOT, f)) and hashlib.sha1(open(os.path.join(ROOT, f), "rb").read()).hexdigest() == h
+                                              for f, h in srcs.items())
+                pmc_kernels = {k: (r if fresh(r) else None) for k, r in json.load(open(pmc)).get("kernels", {}).items()}
+                src = "profiles/pmc_dominant.json (rocprofv3 --pmc passes of this workload on this kernel source, not this run)"
+                if pmc_kernels.get(name):
+                    rec = pmc_kernels[name]
                     pmc_proof = {k: rec[k] for k in ("mfma_insts_per_launch", "mfma_insts_expected_per_launch", "mfma_insts_ratio") if k in rec}
                     traffic = round(rec["hbm_bytes_per_launch"])
-                    traffic_source = "profiles/pmc_dominant.json (rocprofv3 --pmc passes of this workload on this kernel source, not this run)"
-                elif rec.get("kernel") == name:
+                    traffic_source = src
+                elif name in pmc_kernels:
                     traffic_source = "profiles/pmc_dominant.json is stale (kernel source changed since the PMC passes): traffic withheld"
             split_conv = name in ("conv3x3_wino_r64_kernel", "conv3x3_wino_z128_kernel")
             # multiplications a direct 3x3 conv spends per one the kernel executes: F(2x2,3x3) = 36 / 16; conv_wino_z128.hip folds the
@@ -509,6 +568,24 @@ def main():
                     roofline["mfma_executed_over_sustained"] = round(ex / MFMA_BF16_SUSTAINED_RANDOM_TFLOPS, 4)
                 roofline["fp32_mfma_peak"] = PEAK_FP32_MFMA_TFLOPS          # what a plain fp32 kernel is bounded by
                 roofline["achieved_over_fp32_mfma_peak"] = round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)
+            # the next two classes by time, same figures (verdict r4 #6: `traffic` for ~75 % of the step, not for one kernel)
+            others = []
+            for k2 in sorted((k for k in classes if k != name and k.startswith(("gemm_", "igemm", "conv3x3"))), key=lambda k: -classes[k]["ms"])[:3]:
+                c2 = classes[k2]
+                pk = PEAK_BF16_MFMA_TFLOPS if (k2.startswith(("conv3x3_wino_r64", "conv3x3_wino_z128", "gemm_split")) and math != "fp32") else PEAK_FP32_MFMA_TFLOPS
+                r2 = pmc_kernels.get(k2)
+                others.append(dict(kernel=k2, bound="mfma", achieved=round(c2["gflop"] / c2["ms"], 2), peak=pk, unit="TFLOP/s",
+                                   frac=round(c2["gflop"] / c2["ms"] / pk, 4), launches_per_step=c2["launches"], ms_per_step=round(c2["ms"], 3),
+                                   alg_mb_per_launch=round(c2["mb"] / c2["launches"], 2),
+                                   traffic=round(r2["hbm_bytes_per_launch"]) if r2 else None,
+                                   traffic_over_algorithmic=round(r2["hbm_bytes_per_launch"] / (c2["mb"] / c2["launches"] * 1e6), 3) if r2 and c2["mb"] else None,
+                                   mfma_busy_frac_pmc=round(r2["mfma_busy_frac"], 4) if r2 and r2.get("mfma_busy_frac") else None,
+                                   mfma_insts_ratio=r2.get("mfma_insts_ratio") if r2 else None))
+            roofline["other_kernels"] = others
+            if pmc_kernels.get(name) and pmc_kernels[name].get("mfma_busy_frac"):
+                roofline["mfma_busy_frac_pmc"] = round(pmc_kernels[name]["mfma_busy_frac"], 4)
+            if traffic and c["mb"]:
+                roofline["traffic_over_algorithmic"] = round(traffic / (c["mb"] / c["launches"] * 1e6), 3)
     vdist.barrier()
 
     if rank != 0:
@@ -519,9 +596,9 @@ def main():
     headline = (S, args.batch, T, args.respacing, args.num_res_blocks, n_obs) == (64, 8, 16, "ddim250", 2, 4)
     nparam = sum(int(torch.tensor(s).prod()) for _, s in specs)
     workload = ("BASELINE configs[1]: BAIR-shaped 64x64, T=16 (4 obs + 12 latent), batch 8 per GPU, ddim250 respacing, "
-                "p_sample, independent mode, default 116M-param video UNet") if headline and args.scaling == "weak" else \
+                "p_sample, independent mode, default 116M-param video UNet") if headline and args.scaling == "weak" and args.sampler == "p_sample" else \
         (f"{S}x{S}, T={T} ({n_obs} obs + {T - n_obs} latent), batch {args.batch} {'per GPU' if args.scaling == 'weak' else 'in total'}, "
-         f"{args.respacing} respacing, p_sample, default video UNet (num_res_blocks={args.num_res_blocks}, {nparam / 1e6:.0f}M params)")
+         f"{args.respacing or 'no'} respacing, {args.sampler}{' (eta 0)' if args.sampler == 'ddim' else ''}, default video UNet (num_res_blocks={args.num_res_blocks}, {nparam / 1e6:.0f}M params)")
     line = {
         "metric": "denoise-steps/sec", "value": round(value, 4), "unit": "denoise-steps/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -551,6 +628,15 @@ def main():
                                   "(scripts/video_sample.py:151), torch.randn_like noise, fresh tensors per step"}
     if full_window is not None:
         line["full_window"] = full_window
+    if ddim_leg is not None:
+        line["ddim_sample_eta0"] = ddim_leg
+    if margin is not None:
+        # end-to-end accuracy of every arithmetic mode of this run beside its speed: max |eps - reference eps| on the headline window
+        line["parity_margin"] = {"fixture": "tests/golden/unet_full64_b8.npz: eps of the imported reference for the headline window (every 4th pixel "
+                                            "of all 128 frames); tolerance of the tier 1e-4 + 1e-4 |ref|", math: margin,
+                                 **{k: r["parity_margin"] for k, r in (("fp32", fp32_ref), ("bf16x6", x6_ref)) if r and r.get("parity_margin")}}
+    if shapes_ref is not None:
+        line["window_shapes"] = shapes_ref
     if fp32_ref is not None:
         line["fp32_mfma_only"] = fp32_ref
     if x6_ref is not None:

@@ -156,7 +156,9 @@ int vd_p_mean_variance(vd_engine* e, int B, int T, const float* x, const float* 
  * (:975-990), given the eps of a forward pass at x_t: vb[B] = KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) in bits per dim,
  * or the discretised decoder NLL where t == 0; xstart_mse[B] = mean((pred_xstart - x_start)^2); mse[B] =
  * mean((eps_from_xstart - noise)^2) (needs `noise`).  latent_mask: [B*T] or NULL; as in the reference's
- * mean_flat(tensor, mask) the mask multiplies and the mean still runs over all elements.  vd_prior_bpd = _prior_bpd (:909-926). */
+ * mean_flat(tensor, mask) the mask multiplies and the mean still runs over all elements.  vd_prior_bpd = _prior_bpd (:909-926).
+ * With vd_set_model_mean_type(1) (predict_xstart=True) `eps` is the network output as vd_p_mean_variance returns it, i.e. the x_0
+ * prediction itself: pred_xstart = clamp(eps) and the eps of the second MSE is derived from it (_predict_eps_from_xstart, :392-396). */
 int vd_vb_terms(vd_engine* e, int B, int T, const float* x_start, const float* x_t, const float* eps, const float* noise,
                 const long long* t, int clip_denoised, const float* latent_mask, float* vb, float* xstart_mse, float* mse,
                 float* pred_xstart, void* stream);

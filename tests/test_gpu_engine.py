@@ -315,8 +315,9 @@ def test_predict_xstart_matches_reference_golden():
     model2, diff2 = engine(cfg2)
     a = diff2._step(0, model2, x, torch.tensor([5] * B, device="cuda"), True, None, kwargs_of(c), 0.0, c["noise"])[0]
     assert torch.isfinite(a).all()
-    with pytest.raises(NotImplementedError):
-        diff._vb_terms_bpd(model, c["x0"].cuda(), x, torch.tensor([5] * B, device="cuda"), model_kwargs=kwargs_of(c))
+    # the NLL path runs with predict_xstart too since r05 (test_nll_path_with_predict_xstart_matches_reference_golden); guidance does not:
+    # the reference's own branch assumes an eps-prediction network (gaussian_diffusion.py:350-364)
+    assert torch.isfinite(diff._vb_terms_bpd(model, c["x0"].cuda(), x, torch.tensor([5] * B, device="cuda"), model_kwargs=kwargs_of(c))["output"]).all()
 
 
 def test_baseline_batch_properties():
@@ -1321,3 +1322,84 @@ def test_fp16_range_overflow_is_loud_in_the_product():
     with pytest.raises(FloatingPointError):
         video_sample.infer_video("independent", model, diff, batch, max_frames=T, obs_length=2, step_size=T - 2)
     model.check_device_errors()
+
+
+@pytest.mark.parametrize("Tw,n_obs", [(5, 4), (10, 9)])
+def test_configs0_shapes_default_model_short_windows_vs_oracle(Tw, n_obs):
+    """BASELINE configs[0] at size: the DEFAULT 64x64 model (116 M parameters), batch 1, autoreg windows of 5 .. 10 frames
+    (inference_util.py:232-245: obs_length = 4, step_size = 1, max_frames = 10), the un-respaced 1000-step DDPM schedule
+    (timestep_respacing = ''): one p_sample step at t = 999 and at t = 0 against the oracle.  What only these shapes reach on the
+    128 .. 512-channel layers: split-K of the Winograd kernel, its four-frames-per-item 8 x 8 form with a frame count that is not a
+    multiple of four (5: one full item + one quarter-full, 10: two full + one half-full), the small GEMM tiles."""
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=10, image_size=64, rp_alpha=10, rp_beta=10, rp_gamma=10, timestep_respacing="")}
+    model, diff, ora = _oracle(cfg)
+    assert diff.num_timesteps == 1000
+    c = _rand_window(1, Tw, 64, n_obs, seed=500 + Tw)
+    c["frame_indices"] = c["frame_indices"] + 3                      # a window in mid-video
+    kw = {k: v for k, v in c.items() if k not in ("x", "observed_frames")}
+    noise = torch.randn(c["x"].shape, generator=torch.Generator().manual_seed(6))
+    for tv in (999, 0):
+        t = torch.tensor([tv])
+        want = ora.p_sample(c["x"], t, kw, noise)
+        s, xs = diff._step(0, model, c["x"].cuda(), t.cuda(), True, None, kwargs_of(c), 0.0, noise)
+        gain = 1.0 + float(diff.sqrt_recipm1_alphas_cumprod[tv])
+        close(xs.cpu(), want["pred_xstart"], atol=2e-5 * gain, rtol=1e-4)
+        close(s.cpu(), want["sample"], atol=1e-4, rtol=1e-4)
+    model.check_device_errors()
+
+
+def test_nll_path_with_predict_xstart_matches_reference_golden(monkeypatch):
+    """The NLL path with predict_xstart=True (ModelMeanType.START_X; gaussian_diffusion.py:750-790 on top of :326-341): the
+    reference runs it, rounds 2-4 raised NotImplementedError.  _vb_terms_bpd at t = 4, 2, 0 (clip on / off, masked / unmasked) and
+    calc_bpd_loop_subsampled against tests/golden/nll_xstart_tiny.npz (tools/gen_golden_r5.py, imported reference)."""
+    rec = load_npz("nll_xstart_tiny.npz")
+    cfg = json.loads(str(rec["cfg_json"]))
+    assert cfg["predict_xstart"] is True
+    model, diff = engine(cfg)
+    c = {k: torch.from_numpy(rec[k]) for k in ["x0", "obs_mask", "latent_mask", "kinda_marg_mask", "frame_indices"]}
+    x0, lm = c["x0"].cuda(), c["latent_mask"].cuda()
+    B = x0.shape[0]
+    for tv in (4, 2, 0):
+        t = torch.tensor([tv] * B, device="cuda")
+        x_t = torch.from_numpy(rec[f"t{tv}_x_t"]).cuda()
+        for clip in (1, 0):
+            vb = diff._vb_terms_bpd(model, x_start=x0, x_t=x_t, t=t, clip_denoised=bool(clip), model_kwargs=kwargs_of(c), latent_mask=lm)
+            close(vb["output"].cpu(), rec[f"t{tv}_vb_clip{clip}"], atol=2e-5, rtol=1e-3)
+            close(vb["pred_xstart"].cpu(), rec[f"t{tv}_pred_xstart_clip{clip}"], atol=1e-4, rtol=1e-4)
+        vbn = diff._vb_terms_bpd(model, x_start=x0, x_t=x_t, t=t, model_kwargs=kwargs_of(c))
+        close(vbn["output"].cpu(), rec[f"t{tv}_vb_nomask"], atol=2e-5, rtol=1e-3)
+    _cpu_draws(monkeypatch)
+    torch.manual_seed(int(rec["bpd_seed"]))
+    m = diff.calc_bpd_loop_subsampled(model, x0, clip_denoised=True, model_kwargs=kwargs_of(c), latent_mask=lm)
+    for k in ("total_bpd", "prior_bpd", "vb", "xstart_mse"):
+        close(m[k].cpu(), rec[f"bpd_{k}"], atol=2e-5, rtol=1e-3)
+    # mse = mean((eps_from_xstart - noise)^2): eps is derived from x_0 with the gain 1 / sqrt(1/abar - 1) <= 153 at the last step
+    close(m["mse"].cpu(), rec["bpd_mse"], atol=1e-3, rtol=2e-3)
+    model.check_device_errors()
+
+
+def test_return_attn_weights_with_denoised_fn_matches_reference_golden():
+    """return_attn_weights TOGETHER with denoised_fn (gaussian_diffusion.py:274-324 allows it; rounds 3-4 raised): the maps of the
+    step's one forward, the sample / pred_xstart of the callback path, and p_mean_variance's dict, against
+    tests/golden/attn_denoised_tiny.npz (tools/gen_golden_r5.py)."""
+    rec = load_npz("attn_denoised_tiny.npz")
+    cfg = json.loads(str(rec["cfg_json"]))
+    model, diff = engine(cfg)
+    c = {k: torch.from_numpy(rec[k]) for k in ["x", "x0", "noise", "obs_mask", "latent_mask", "kinda_marg_mask", "frame_indices"]}
+    x = c["x"].cuda()
+    t = torch.tensor([120, 120], device="cuda")
+    sample, xs = diff._step(0, model, x, t, True, _denoised_fn, kwargs_of(c), 0.0, c["noise"], return_attn_weights=True)
+    attn = diff._last_attn
+    close(sample.cpu(), rec["psample"], atol=1e-4, rtol=1e-4)
+    close(xs.cpu(), rec["pred_xstart"], atol=1e-4, rtol=1e-4)
+    for kind in ("temporal", "spatial"):
+        assert len(attn[kind]) == int(rec[f"n_{kind}"])
+        for i, a in enumerate(attn[kind]):
+            assert tuple(a.shape) == tuple(rec[f"{kind}_{i}_shape"])
+            got = a[:, ::8] if a.shape[1] > 64 else a
+            close(got.cpu(), rec[f"{kind}_{i}"], atol=1e-5, rtol=1e-3)
+    pm = diff.p_mean_variance(model, x, t, clip_denoised=True, denoised_fn=_denoised_fn, model_kwargs=kwargs_of(c), return_attn_weights=True)
+    close(pm["mean"].cpu(), rec["pmv_mean"], atol=1e-4, rtol=1e-4)
+    assert len(pm["attn"]["temporal"]) == int(rec["n_temporal"])
+    out = diff.p_sample(model, x, t, clip_denoised=True, denoised_fn=_denoised_fn, model_kwargs=kwargs_of(c), return_attn_weights=True)
+    assert out["attn"] is not None and len(out["attn"]["spatial"]) == int(rec["n_spatial"])

@@ -154,7 +154,10 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     const double taps = (double)g.ksz * g.ksz, cin = cin_alg ? cin_alg : g.Cin;
     const double in_pix = (double)g.nfr * g.Hs * g.Ws;
     const double nz = g.zcount > 1 ? g.zcount : 1;
-    const double bytes = nz * 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout);
+    // algorithmic bytes: input once, output once (+ residual), weights once -- and, for a skip convolution that also writes the ResBlock's
+    // GroupNorm + SiLU image from the A rows it stages (IgemmArgs::side: one more tensor of the input's size written by this launch, the
+    // pass affine_act would otherwise be), that image: counted since r05 (round 4's figure omitted it and read as 2x traffic waste)
+    const double bytes = nz * 4.0 * (in_pix * cin + (double)g.M * g.Cout * (g.res ? 2 : 1) + taps * cin * g.Cout + (g.side ? in_pix * cin : 0.0));
     IgemmArgs one = g;                         // a big window goes out as several launches over frame ranges (igemm.hip)
     one.nfr = std::max(1, std::min(g.nfr, igemm_frames_per_launch(g)));
     one.M = one.nfr * g.Ho * g.Wo;
@@ -1703,6 +1706,7 @@ int vd_vb_terms(vd_engine* e, int B, int T, const float* x_start, const float* x
     VbArgs a{x_start, x_t, eps, noise, reinterpret_cast<const int64_t*>(t), e->d_tab, e->num_timesteps, latent_mask, B, T, per,
              clip, pred_xstart, e->d_part, nblk, vb, xstart_mse, mse};
     a.err = e->d_err;
+    a.start_x = e->mean_type == 1;
     return launch_vb_terms(a, static_cast<hipStream_t>(stream));
 }
 

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void vb_terms_kernel(VbArgs a) {
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < a.per; j += (long)gridDim.x * 256) {
         const size_t i = (size_t)b * a.per + j;
         const float xs = a.x_start[i], xt = a.x_t[i];
-        float x0 = sr * xt - srm1 * a.eps[i];
+        float x0 = a.start_x ? a.eps[i] : sr * xt - srm1 * a.eps[i];  // START_X: pred_xstart = process_xstart(model_output) (gaussian_diffusion.py:326-341)
         const bool bad = !(fabsf(x0) <= 3.4028234e38f);               // (posterior_kernel: a non-finite eps must not be clamped into range)
         if (bad && a.err) atomicOr(a.err, VD_ERR_NONFINITE);
         if (a.clip && !bad) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);

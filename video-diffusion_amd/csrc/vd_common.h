@@ -384,6 +384,7 @@ struct VbArgs {
     int nblk;
     float* vb; float* xstart_mse; float* mse;      // [B] outputs (the last two may be null)
     int* err = nullptr;          // sticky error word (bit 1: eps not finite)
+    int start_x = 0;             // ModelMeanType.START_X (predict_xstart=True): `eps` holds the network's x_0 prediction itself
 };
 int launch_vb_terms(const VbArgs& a, hipStream_t s);
 int vb_terms_blocks(long per);

@@ -154,8 +154,8 @@ class GaussianDiffusion:
         if model_kwargs is None:
             model_kwargs = {}
         self._refuse_learned(x)
-        if return_attn_weights and (use_gradient_method or denoised_fn is not None):
-            raise NotImplementedError("return_attn_weights together with use_gradient_method / denoised_fn")
+        if return_attn_weights and use_gradient_method:
+            raise NotImplementedError("return_attn_weights together with use_gradient_method")
         if use_gradient_method:
             if mode != 0 or denoised_fn is not None:
                 raise NotImplementedError("use_gradient_method: p_sample without denoised_fn (the reference's ddim_sample "
@@ -163,7 +163,7 @@ class GaussianDiffusion:
             out = self._guided(model, x, t, clip_denoised, model_kwargs, noise2=noise, want_sample=True)
             return out["sample"], out["pred_xstart"]
         if denoised_fn is not None:
-            return self._step_denoised_fn(mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise)
+            return self._step_denoised_fn(mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise, return_attn_weights)
         model = self._bind(model)
         B = x.shape[0]
         assert t.shape == (B,)                                   # gaussian_diffusion.py:273
@@ -229,11 +229,12 @@ class GaussianDiffusion:
             _lib.ptr(sample) if want_sample else None, _lib.current_stream()))
         return {"mean": mean, "pred_xstart": xstart, "grad": grad, "sample": sample}
 
-    def _step_denoised_fn(self, mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise):
+    def _step_denoised_fn(self, mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta, noise, return_attn_weights=False):
         """process_xstart with a caller's function (gaussian_diffusion.py:319-324): `denoised_fn` sees the UNCLIPPED x_0
         prediction, the clamp and the posterior run on what it returns.  Two launches around a host callback instead of
         the fused step: forward + x_0 (vd_p_mean_variance, clip off), then vd_posterior_from_xstart."""
-        out = self.p_mean_variance(model, x, t, clip_denoised=False, model_kwargs=model_kwargs)
+        out = self.p_mean_variance(model, x, t, clip_denoised=False, model_kwargs=model_kwargs, return_attn_weights=return_attn_weights)
+        self._last_attn = out["attn"]                              # the maps of the one forward this step makes (gaussian_diffusion.py:274-324)
         base = self._bind(model)
         dev = base.device
         xs = _f32(x, dev)
@@ -261,8 +262,8 @@ class GaussianDiffusion:
         """gaussian_diffusion.py:229-372 -> {'mean', 'variance', 'log_variance', 'pred_xstart', 'attn'} (+ 'eps', the raw
         model output, which the NLL loop reuses)."""
         self._refuse_learned(x)
-        if return_attn_weights and (use_gradient_method or denoised_fn is not None):
-            raise NotImplementedError("return_attn_weights together with use_gradient_method / denoised_fn")
+        if return_attn_weights and use_gradient_method:
+            raise NotImplementedError("return_attn_weights together with use_gradient_method")
         if use_gradient_method:
             if denoised_fn is not None:
                 raise NotImplementedError("use_gradient_method with denoised_fn")
@@ -274,7 +275,7 @@ class GaussianDiffusion:
                     "log_variance": self._extract(self._model_log_variance(), tt, g["mean"].shape),
                     "pred_xstart": g["pred_xstart"], "attn": None, "grad": g["grad"]}
         if denoised_fn is not None:
-            out = self.p_mean_variance(model, x, t, clip_denoised=False, model_kwargs=model_kwargs)
+            out = self.p_mean_variance(model, x, t, clip_denoised=False, model_kwargs=model_kwargs, return_attn_weights=return_attn_weights)
             base = self._bind(model)
             xs = _f32(x, base.device)
             x0 = _f32(denoised_fn(out["pred_xstart"]), base.device)
@@ -328,9 +329,7 @@ class GaussianDiffusion:
     def _vb_terms_bpd(self, model, x_start, x_t, t, clip_denoised=True, model_kwargs=None, latent_mask=None, _noise=None):
         """gaussian_diffusion.py:750-790 -> {'output': [N] bits/dim, 'pred_xstart'} (+ the two MSEs of
         calc_bpd_loop_subsampled when the noise x_t was drawn with is passed)."""
-        if self.model_mean_type != ModelMeanType.EPSILON:
-            raise NotImplementedError("the NLL path with predict_xstart=True")
-        model = self._bind(model)
+        model = self._bind(model)          # (predict_xstart=True: the engine takes the network output handed to vd_vb_terms as the x_0 prediction)
         dev = model.device
         xs, xt = _f32(x_start, dev), _f32(x_t, dev)
         B, T = xs.shape[:2]
