@@ -246,6 +246,14 @@ struct vd_engine {
         VD_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
         return 0;
     }
+    // rpe_all: the relative-position nets of ALL attention blocks at the start of a forward, two launches per channel width instead of two
+    // per block (they depend on the timestep embedding and the frame indices only, unet.py:283-298).  Per width: the blocks of that width,
+    // a device table of offsets (rpe_hidden: te column, Wd, bd; output layer: weight image, bias) and where the blocks' R tensors land.
+    struct RpeGroup { int C; std::vector<int> blocks; long long* d_hid = nullptr; long long* d_out = nullptr; };
+    std::vector<RpeGroup> rpe_groups;
+    std::vector<float*> rpe_R;        // [attention block][3]: R of the running forward (k, q, v order of attn_block), or empty
+    int rpe_all(const float* te, const int64_t* fidx, int B, int T, hipStream_t st, Arena& ar);
+    int rpe_tables();
     // small device tables
     float* d_freq_time = nullptr; int n_freq_time = 0;
     float* d_freq_frame = nullptr; int n_freq_frame = 0;
@@ -299,6 +307,7 @@ struct vd_engine {
     ~vd_engine() {
         if (d_freq_time) (void)hipFree(d_freq_time);
         if (d_freq_frame) (void)hipFree(d_freq_frame);
+        for (auto& g : rpe_groups) { if (g.d_hid) (void)hipFree(g.d_hid); if (g.d_out) (void)hipFree(g.d_out); }
         if (d_tab) (void)hipFree(d_tab);
         if (d_tmap) (void)hipFree(d_tmap);
         if (ws) (void)hipFree(ws);
@@ -818,8 +827,10 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
     // constant stride in the packed weights, so each of their two layers is ONE launch (blockIdx.y / .z = net)
     const RpeP* rp[3] = {&a.rq, &a.rk, &a.rv};
     const size_t rrows = (size_t)B * T * T;
-    float* Ehid = cfg.use_rpe_net ? ar.get<float>(3 * rrows * C) : nullptr;
-    float* Rall = ar.get<float>(3 * rrows * C);
+    const int blk = (int)(&a - attn.data());
+    const bool pre = !rpe_R.empty();                                        // rpe_all has produced this forward's R tensors already
+    float* Ehid = cfg.use_rpe_net && !pre ? ar.get<float>(3 * rrows * C) : nullptr;
+    float* Rall = pre ? rpe_R[3 * blk] : ar.get<float>(3 * rrows * C);     // (memory order q, k, v)
     float* R[3] = {Rall + rrows * C, Rall, Rall + 2 * rrows * C};          // k, q, v as the attention kernel takes them
     float* o = ar.get<float>(tok * C);
     float* xt = ar.get<float>(tok * C);
@@ -830,7 +841,8 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
           rc = launch_gn_temporal(x.p, W(a.tp.normw), W(a.tp.normb), B, T, HW, C, xn, st); }
         if (rc) return rc;
         if ((rc = linear(xn, (int)tok, C, 0, 0, 3 * C, W(a.tp.qkvw), W(a.tp.qkvb), 0, nullptr, qkv, st))) return rc;
-        if (cfg.use_rpe_net) {
+        if (pre) {
+        } else if (cfg.use_rpe_net) {
             const int zs_dw = (int)(W(rp[1]->dw) - W(rp[0]->dw)), zs_db = (int)(W(rp[1]->db) - W(rp[0]->db));
             const int zs_ow = (int)(W(rp[1]->ow) - W(rp[0]->ow)), zs_ob = (int)(W(rp[1]->ob) - W(rp[0]->ob));
             VD_REQUIRE(W(rp[2]->dw) - W(rp[1]->dw) == zs_dw && W(rp[2]->db) - W(rp[1]->db) == zs_db &&
@@ -890,6 +902,82 @@ int vd_engine::attn_block(const AttnP& a, Tens x, int B, int T, const float* te_
     return 0;
 }
 
+// The relative-position nets of every attention block (RPENet, unet.py:283-298: silu(Linear(feat(d)) + Linear(emb)) -> Linear) read the
+// timestep embedding and the frame indices only -- nothing a block computes.  Per block they were two small dependent launches (the three
+// nets of a block batched): 22 of the ~210 launches of a step, each paying the ~5 us of a dependent dispatch on top of 5 - 15 us of work
+// that leaves most CUs idle.  Here: per channel width ONE hidden-layer launch and ONE output-layer GEMM over all nets of that width (the
+// 3 x 5 nets of 384 channels, the 3 x 6 of 512), at the start of the forward.  Same kernels, same arithmetic per net: bit-identical R.
+// the attention blocks by channel width, and per width the device tables of offsets the two launches read (never inside a stream capture:
+// ensure_ws calls this)
+static bool rpe_all_on() { static const bool on = getenv("VD_NO_RPE_ALL") == nullptr; return on; }     // (A/B switch: the per-block launches of rounds 1-4)
+
+int vd_engine::rpe_tables() {
+    if (!cfg.use_rpe_net || !split_math() || attn.empty() || !te_total || !rpe_all_on()) return 0;
+    if (rpe_groups.empty()) {
+        for (size_t b = 0; b < attn.size(); ++b) {
+            size_t gi = 0;
+            while (gi < rpe_groups.size() && rpe_groups[gi].C != attn[b].C) ++gi;
+            if (gi == rpe_groups.size()) rpe_groups.push_back(RpeGroup{attn[b].C, {}});
+            rpe_groups[gi].blocks.push_back((int)b);
+        }
+    }
+    for (auto& g : rpe_groups) {
+        if (g.d_hid) continue;
+        const int nn = 3 * (int)g.blocks.size();
+        std::vector<long long> th(3 * nn), to(2 * nn);
+        for (size_t i = 0; i < g.blocks.size(); ++i) {
+            const AttnP& a = attn[g.blocks[i]];
+            const RpeP* rp[3] = {&a.rq, &a.rk, &a.rv};
+            for (int k = 0; k < 3; ++k) {
+                const int z = 3 * (int)i + k;
+                th[3 * z] = rp[k]->te_off; th[3 * z + 1] = (long long)params[rp[k]->dw].off; th[3 * z + 2] = (long long)params[rp[k]->db].off;
+                to[2 * z] = (long long)params[rp[k]->ow].off; to[2 * z + 1] = (long long)params[rp[k]->ob].off;
+            }
+        }
+        VD_HIP(hipMalloc(reinterpret_cast<void**>(&g.d_hid), th.size() * sizeof(long long)));
+        VD_HIP(hipMalloc(reinterpret_cast<void**>(&g.d_out), to.size() * sizeof(long long)));
+        VD_HIP(hipMemcpy(g.d_hid, th.data(), th.size() * sizeof(long long), hipMemcpyHostToDevice));
+        VD_HIP(hipMemcpy(g.d_out, to.data(), to.size() * sizeof(long long), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int vd_engine::rpe_all(const float* te, const int64_t* fidx, int B, int T, hipStream_t st, Arena& ar) {
+    rpe_R.clear();
+    if (!cfg.use_rpe_net || !split_math() || attn.empty() || !te_total || !rpe_all_on()) return 0;
+    if (ar.dry && rpe_groups.empty()) {                                // (the dry run sizes the arena before any table exists: widths only)
+        for (size_t b = 0; b < attn.size(); ++b) {
+            size_t gi = 0;
+            while (gi < rpe_groups.size() && rpe_groups[gi].C != attn[b].C) ++gi;
+            if (gi == rpe_groups.size()) rpe_groups.push_back(RpeGroup{attn[b].C, {}});
+            rpe_groups[gi].blocks.push_back((int)b);
+        }
+    }
+    VD_REQUIRE(!rpe_groups.empty(), "rpe_all: ensure_ws has not run");
+    const size_t rrows = (size_t)B * T * T;
+    rpe_R.assign(3 * attn.size(), nullptr);
+    int rc = 0;
+    for (auto& g : rpe_groups) {
+        const int nn = 3 * (int)g.blocks.size(), C = g.C;
+        float* Rg = ar.get<float>((size_t)nn * rrows * C);
+        for (size_t i = 0; i < g.blocks.size(); ++i)
+            for (int k = 0; k < 3; ++k) rpe_R[3 * g.blocks[i] + k] = Rg + (3 * i + k) * rrows * C;
+        const size_t mk = ar.mark();
+        float* Eh = ar.get<float>((size_t)nn * rrows * C);
+        ar.release(mk);                                                // a transient: the two launches are stream-ordered
+        if (ar.dry) continue;
+        VD_REQUIRE(g.d_hid && g.d_out, "rpe_all: offset tables missing (ensure_ws builds them)");
+        if ((rc = launch_rpe_hidden_tab(te, te_total, wbuf, g.d_hid, fidx, B, T, C, Eh, nn, rrows * C, st))) return rc;
+        IgemmArgs q{};
+        q.src0 = Eh; q.C0 = C; q.Cin = C; q.nfr = (int)rrows; q.Hs = q.Ws = q.Ho = q.Wo = 1; q.stride = 1; q.ksz = 1;
+        q.wfrag = wbuf + params[attn[g.blocks[0]].rq.ow].off; q.bias = wbuf + params[attn[g.blocks[0]].rq.ob].off;   // (problem 0's: the shape checks read them)
+        q.wsplit = split_math(); q.out = Rg; q.ldo = C; q.Cout = C; q.M = (int)rrows;
+        q.zcount = nn; q.zs_a = q.zs_out = (int)(rrows * C); q.ztab = g.d_out; q.zbase = wbuf;
+        if ((rc = igemm_p(q, st))) return rc;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ forward
 int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixPlan* pp, const SuffixPlan* sp) {
     const int B = in.B, T = in.T, N = B * T, S = cfg.image_size, mc = cfg.num_channels;
@@ -930,6 +1018,8 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
             if ((rc = launch_sinus_embed(ftv, N, pos_ch, d_freq_frame, femb, st))) return rc;
         }
     }
+    rpe_R.clear();
+    if (!(pp && pp->build_only) && (rc = rpe_all(te, in.fidx, B, T, st, ar))) return rc;      // every block's relative-position tensors, up front
     attn_seq = 0;
     std::vector<Tens> hs;
     Tens h{x8, STEM_KPAD, S};
@@ -1102,6 +1192,7 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
 
 int vd_engine::ensure_ws(int B, int T) {
     if (B == ws_B && T == ws_T && ws && ws_suf == suffix_skip_on) return 0;      // the common case: every step of a window
+    { const int trc = rpe_tables(); if (trc) return trc; }
     // with the window suffix skip enabled the arena also holds the gathered skip tensors: sized for the worst list (every frame)
     const long long key = ((long long)B << 32) | (unsigned)T | (suffix_skip_on ? 1ll << 61 : 0);
     auto it = ws_peaks.find(key);
@@ -1309,6 +1400,7 @@ int vd_engine::backward(const FwdIn& in, const float* deps, float* dx, hipStream
 
 // workspace of a guided step: forward (taped, nothing released that the backward reads) + backward + the step's own buffers
 int vd_engine::ensure_ws_guided(int B, int T) {
+    { const int trc = rpe_tables(); if (trc) return trc; }
     const long long key = ((long long)B << 32) | (unsigned)T | (1ll << 62);
     auto it = ws_peaks.find(key);
     if (it == ws_peaks.end()) {

@@ -121,8 +121,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     const int C1 = a.Cin - a.C0;
     if (a.zcount > 1) {                          // batched problems of one shape
         const int z = blockIdx.z;
-        a.src0 += (size_t)z * a.zs_a; a.wfrag += (size_t)z * a.zs_w; a.out += (size_t)z * a.zs_out;
-        if (a.bias) a.bias += (size_t)z * a.zs_bias;
+        a.src0 += (size_t)z * a.zs_a; a.out += (size_t)z * a.zs_out;
+        if (a.ztab) {                            // weights / bias of problem z from a table of offsets (IgemmArgs::ztab)
+            a.wfrag = a.zbase + a.ztab[2 * z];
+            a.bias = a.zbase + a.ztab[2 * z + 1];
+        } else {
+            a.wfrag += (size_t)z * a.zs_w;
+            if (a.bias) a.bias += (size_t)z * a.zs_bias;
+        }
     }
 
     const auto asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0,

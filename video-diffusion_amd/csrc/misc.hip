@@ -167,6 +167,31 @@ __global__ __launch_bounds__(256) void rpe_hidden_kernel(const float* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void rpe_hidden_tab_kernel(const float* __restrict__ te, int te_ld, const float* __restrict__ wbase,
+                                                             const long long* __restrict__ tab, const int64_t* __restrict__ fidx, int T, int C,
+                                                             float* __restrict__ E, size_t zs_e) {
+    const long long* tz = tab + 3 * blockIdx.y;
+    te += tz[0];
+    const float* Wd = wbase + tz[1];
+    const float* bd = wbase + tz[2];
+    E += blockIdx.y * zs_e;
+    const int row = blockIdx.x;                 // (b*T + t)*T + s
+    const int s_ = row % T, bt = row / T, b = bt / T;
+    const float d = (float)(fidx[bt] - fidx[b * T + s_]);
+    const float f0 = logf(1.0f + fmaxf(d, 0.f)), f1 = logf(1.0f + fmaxf(-d, 0.f)), f2 = d == 0.f ? 1.f : 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float lin = bd[c] + f0 * Wd[c * 3] + f1 * Wd[c * 3 + 1] + f2 * Wd[c * 3 + 2];
+        E[(size_t)row * C + c] = silu_f(te[(size_t)bt * te_ld + c] + lin);
+    }
+}
+
+int launch_rpe_hidden_tab(const float* te, int te_ld, const float* wbase, const long long* tab, const int64_t* fidx, int B, int T, int C,
+                          float* E, int nz, size_t zs_e, hipStream_t s) {
+    hipLaunchKernelGGL(rpe_hidden_tab_kernel, dim3(B * T * T, nz), dim3(256), 0, s, te, te_ld, wbase, tab, fidx, T, C, E, zs_e);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_rpe_hidden(const float* te, int te_ld, const float* Wd, const float* bd, const int64_t* fidx, int B, int T,
                       int C, float* E, int nz, int zs_te, int zs_w, int zs_b, size_t zs_e, hipStream_t s) {
     hipLaunchKernelGGL(rpe_hidden_kernel, dim3(B * T * T, nz), dim3(256), 0, s, te, te_ld, Wd, bd, fidx, T, C, E, zs_te, zs_w,

@@ -75,6 +75,9 @@ struct IgemmArgs {
     // problem z reads src0 + z*zs_a, wfrag + z*zs_w, bias + z*zs_bias and writes out + z*zs_out (element strides).
     // The three RPE-net output layers of an attention block (unet.py:283-298) go out this way.
     int zcount, zs_a, zs_w, zs_bias, zs_out;
+    // gemm_split.hip: problems whose weights do not sit at a constant stride (the RPE nets of ALL attention blocks of one width in one
+    // launch, engine.hip: rpe_all): problem z takes wfrag = zbase + ztab[2z], bias = zbase + ztab[2z + 1] (float offsets, device table)
+    const long long* ztab = nullptr; const float* zbase = nullptr;
     // wsplit == 2: wwino is the image of pack_conv3_wino_split (conv_wino_r64.hip).  Otherwise:
     // wfrag is the bf16-split image of the weights (gemm_split.hip: fp32 accuracy from six bf16 piece products);
     // zs_w then counts floats of that image as well
@@ -281,6 +284,9 @@ int launch_sinus_embed(const float* t, int n, int dim, const float* freqs, float
 // nz nets at once (blockIdx.y): net z reads te + z*zs_te, Wd + z*zs_w, bd + z*zs_b and writes E + z*zs_e
 int launch_rpe_hidden(const float* te, int te_ld, const float* Wd, const float* bd, const int64_t* fidx, int B, int T,
                       int C, float* E, int nz, int zs_te, int zs_w, int zs_b, size_t zs_e, hipStream_t s);
+// the same for nets at arbitrary places: net z reads te + tab[3z], wbase + tab[3z + 1] (Wd), wbase + tab[3z + 2] (bd)
+int launch_rpe_hidden_tab(const float* te, int te_ld, const float* wbase, const long long* tab, const int64_t* fidx, int B, int T, int C,
+                          float* E, int nz, size_t zs_e, hipStream_t s);
 // bucket-table path (unet.py:330-347): R[b,t,s,:] = table[bucket(d)]
 int launch_rpe_table(const float* table, const int64_t* fidx, int B, int T, int C, float alpha, float beta,
                      float gamma, float* R, hipStream_t s);
