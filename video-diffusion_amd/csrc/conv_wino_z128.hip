@@ -56,6 +56,16 @@ extern "C" int vd_debug_z128_stamps(unsigned long long* host_out) {
 #define Z128_STAMP(i)
 #endif
 
+// ACT: the input is NOT an activated image: the kernel reads the raw tensor and applies the folded GroupNorm(+FiLM) affine and the SiLU
+// itself -- x -> silu(x * A[frame][c] + B[frame][c]), zero outside the picture -- while it stages the patch (through registers instead of
+// LDS-DMA).  What it replaces is a whole pass over the tensor (norm.hip: affine_act, read + write at ~4.6 TB/s: 117 us for 128 channels at
+// 64 x 64 x 128 frames) per convolution; what it costs was measured beforehand with a timing-only build carrying the same vector work
+// and LDS stores in the same slots (r05j): +6 % of the kernel (423 -> 451 us at 128 -> 128, 709 -> 748 at 256 -> 128).  It pays only where
+// ONE or two cout blocks share a patch (every block that stages a patch activates it): Cout <= 256.  Per chunk and thread: 6 loads (one
+// patch of 16 channels = 6 x 16 bytes per thread), 24 elements x (fma, select, mul, exp, add, rcp, mul) in the 24 slots of position 2 that
+// carry nothing else, 6 ds_write_b128; the patch of chunk c + 2 is activated during chunk c from registers loaded at the end of chunk
+// c - 1, published by the barrier that stands in front of its first reader anyway.
+template <bool ACT>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, WinoZ128Geom g) {
     using namespace z128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -84,13 +94,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     // ---- patch staging (conv_wino_r64.hip): thread -> 16-byte LDS slots e*256 + tid; the slot at quad position lq of patch row py
     // holds the pixel's quad lq ^ ((py >> 1) & 3)
     unsigned xo[NX];
+    unsigned ldo[ACT ? NX : 1];                                       // ACT: byte offset of the thread's slot e inside a patch buffer
+    unsigned long long inm[ACT ? NX : 1];                             // ACT: lanes whose slot e lies inside the picture
 #pragma unroll
     for (int e = 0; e < NX; ++e) {
         const int gs = e * 256 + tid, lq = gs & 3, ps = gs >> 2;
         const int py = ps / (2 * SPP), r = ps % (2 * SPP), pxh = r % SPP, px = 2 * pxh + r / SPP;
         const int ly = oy0 + py - 1, lx = ox0 + px - 1;
         const bool in = py < P && pxh < P / 2 && ly >= 0 && ly < Hl && lx >= 0 && lx < Wl;
-        xo[e] = in ? (unsigned)((f0 * a.Hs + ly) * a.Ws + lx) * (unsigned)(a.Cin * 4) + (unsigned)((lq ^ ((py >> 1) & 3)) * 16) : 0x80000000u;
+        if constexpr (ACT) {
+            // the thread keeps ONE channel quad (lq = tid & 3: its (A, B) are four registers per chunk) and writes it to the place the
+            // DMA image gives that quad: position lq ^ ((py >> 1) & 3) of the pixel's four 16-byte slots
+            xo[e] = in ? (unsigned)((f0 * a.Hs + ly) * a.Ws + lx) * (unsigned)(a.Cin * 4) + (unsigned)(lq * 16) : 0x80000000u;
+            ldo[e] = (unsigned)(((gs & ~3) | (lq ^ ((py >> 1) & 3))) * 16);
+            inm[e] = __ballot(in);
+        } else {
+            xo[e] = in ? (unsigned)((f0 * a.Hs + ly) * a.Ws + lx) * (unsigned)(a.Cin * 4) + (unsigned)((lq ^ ((py >> 1) & 3)) * 16) : 0x80000000u;
+        }
     }
     const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
     const auto xnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, 0, 0x00020000);
@@ -101,6 +121,50 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
         const int bufi = live ? (chunk & (NB - 1)) : NB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? xsrc : xnull, (lds_ptr)(lds + bufi * XBUF + e * 4096 + wi * 1024), 16, xo[e], chunk * 64, 0, 0);
 #endif
+    };
+
+    // ---- ACT: register staging.  (A, B) of the item's frame sit in LDS behind the patch buffers: [Cin] A, [Cin] B.
+    float* const sab = reinterpret_cast<float*>(lds + LDS_BYTES);
+    const int cq4 = (tid & 3) * 4;
+    f32x4 stg[ACT ? NX : 1];                                          // the patch being staged: loaded raw, activated in place
+    f32x4 Aq = {0.f, 0.f, 0.f, 0.f}, Bq = Aq;                         // (A, B) of the thread's channel quad for that patch
+    float tq[4];                                                      // in flight between the parts of one slot e
+    auto p_load = [&](int patch, int e) {                            // (a request past the last chunk always issues, through the empty descriptor)
+        if constexpr (ACT) stg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(patch < nchunk ? xsrc : xnull, xo[e], patch * 64, 0));
+    };
+    auto p_coef = [&](int patch) {
+        if constexpr (ACT) {
+            const int pc = min(patch, nchunk - 1) * 16 + cq4;
+            Aq = *reinterpret_cast<const f32x4*>(sab + pc);
+            Bq = *reinterpret_cast<const f32x4*>(sab + a.Cin + pc);
+        }
+    };
+    // slot e in four parts of 7 vector instructions (what hides beside an MFMA that carries nothing else), consecutive instructions on
+    // different elements; the arithmetic of norm.hip's pass to the bit: fma(x, A, B), silu(v) = v * rcp(1 + exp2(-log2(e) v))
+    auto p_act = [&](int e, int part) {
+        if constexpr (ACT) {
+            if (part == 0)
+                asm("v_fma_f32 %0, %0, %4, %8\n\tv_fma_f32 %1, %1, %5, %9\n\tv_fma_f32 %2, %2, %6, %10\n\tv_fma_f32 %3, %3, %7, %11\n\t"
+                    "v_cndmask_b32_e64 %0, 0, %0, %12\n\tv_cndmask_b32_e64 %1, 0, %1, %12\n\tv_cndmask_b32_e64 %2, 0, %2, %12"
+                    : "+v"(stg[e][0]), "+v"(stg[e][1]), "+v"(stg[e][2]), "+v"(stg[e][3])
+                    : "v"(Aq[0]), "v"(Aq[1]), "v"(Aq[2]), "v"(Aq[3]), "v"(Bq[0]), "v"(Bq[1]), "v"(Bq[2]), "v"(Bq[3]), "s"(inm[e]));
+            else if (part == 1)
+                asm("v_cndmask_b32_e64 %3, 0, %3, %8\n\tv_mul_f32 %4, 0xbfb8aa3b, %0\n\tv_mul_f32 %5, 0xbfb8aa3b, %1\n\tv_mul_f32 %6, 0xbfb8aa3b, %2\n\t"
+                    "v_mul_f32 %7, 0xbfb8aa3b, %3\n\tv_exp_f32 %4, %4\n\tv_exp_f32 %5, %5"
+                    : "+v"(stg[e][0]), "+v"(stg[e][1]), "+v"(stg[e][2]), "+v"(stg[e][3]), "=&v"(tq[0]), "=&v"(tq[1]), "=&v"(tq[2]), "=&v"(tq[3])
+                    : "s"(inm[e]));
+            else if (part == 2)
+                asm("v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1\n\tv_rcp_f32 %0, %0\n\t"
+                    "v_add_f32 %2, 1.0, %2\n\tv_add_f32 %3, 1.0, %3"
+                    : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]));
+            else
+                asm("v_rcp_f32 %5, %5\n\tv_rcp_f32 %6, %6\n\tv_rcp_f32 %7, %7\n\tv_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %5\n\t"
+                    "v_mul_f32 %2, %2, %6\n\tv_mul_f32 %3, %3, %7"
+                    : "+v"(stg[e][0]), "+v"(stg[e][1]), "+v"(stg[e][2]), "+v"(stg[e][3]), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]));
+        }
+    };
+    auto p_store = [&](int patch, int e) {
+        if constexpr (ACT) *reinterpret_cast<f32x4*>(lds + (patch < nchunk ? (patch & (NB - 1)) : NB) * XBUF + ldo[e]) = stg[e];
     };
 
     // ---- the lane's patch addresses: lane (tile lr of the M-tile, k-half lh): tile column lr & 7, tile row 4m + (lr >> 3); rows of
@@ -200,10 +264,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     f32x16 acc[2][2][4];                                              // [z][m][n]
     Z128_STAMP(0); Z128_STAMP(14);
     // ---- prologue: three patches and the weights of (chunk 0, position 0) requested; the 256 accumulator writes go under the wait
+    if constexpr (ACT) {
+        // the frame's (A, B) into LDS; patches 0 and 1 loaded, activated and stored whole (per item: 2 x 6 loads, 2 x 24 elements); patch 2 is
+        // left in flight in the staging registers -- the state the loop expects: chunk c activates patch c + 2 in its position 2
+        for (int c = tid; c < a.Cin; c += 256) {
+            sab[c] = a.affA[(size_t)f0 * a.Cin + c];
+            sab[a.Cin + c] = a.affB[(size_t)f0 * a.Cin + c];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int e = 0; e < NX; ++e) x_dma_one(c, e);
+            for (int e = 0; e < NX; ++e) p_load(c, e);
+            p_coef(c);
+#pragma unroll
+            for (int e = 0; e < NX; ++e) {
+#pragma unroll
+                for (int part = 0; part < 4; ++part) p_act(e, part);
+                p_store(c, e);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NX; ++e) p_load(2, e);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int e = 0; e < NX; ++e) x_dma_one(c, e);
+    }
 #pragma unroll
     for (int idx = 0; idx < 8; ++idx) b_load_one(0, 0, idx);
     __builtin_amdgcn_sched_barrier(0);
@@ -218,7 +306,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     __builtin_amdgcn_sched_barrier(0);
     // patch 0 has landed in every wave: the 2 * NX + 8 youngest requests are patches 1, 2 (first read behind the loop's first barrier,
     // which waits for them) and the weights
-    asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
+    if constexpr (ACT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // patches 0, 1 are written; the loads in flight land in registers
+    else asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
     static_assert(NX == 6, "the wait count above");
 #pragma unroll
     for (int idx = 0; idx < 16; ++idx) frag_read(0, 0, idx);
@@ -249,7 +338,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
         for (int j = 0; j < 4; ++j) {
             const int cur = j & 1, nxt = cur ^ 1, jn = (j + 1) & 3, cn = j == 3 ? chunk + 1 : chunk;
             const int NS = (j == 0 || j == 3) ? 24 : 48, sp = NS / 24;
-            if (cpar == 0 && j == 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (cpar == 0 && j == 3) {
+                if constexpr (ACT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (the patches are ds_writes here)
+                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
             int s = 0;
 #pragma unroll
             for (int zi = 0; zi < 2; ++zi) {
@@ -282,7 +374,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
                                 if (vs >= 9) frag_part(nxt, jn, 3 + (vs - 9) / 3, (vs - 9) % 3);
                                 else if (vs >= 3 && ((vs - 3) & 1)) frag_part(nxt, jn, (vs - 3) >> 1, 2);
                                 else if (vs >= 3) frag_part(nxt, jn, (vs - 3) >> 1, 3);
-                            } else if (cpar == 1 && (j == 1 || j == 2) && (s & 7) == 1) x_dma_one(chunk + 1 + j, s >> 3);
+                            } else if (!ACT && cpar == 1 && (j == 1 || j == 2) && (s & 7) == 1) x_dma_one(chunk + 1 + j, s >> 3);
+                            if constexpr (ACT) {
+                                // position 1: (A, B) of patch chunk + 2; position 2, odd slots: its 24 elements, one part of a slot e each, the store
+                                // behind the last part; position 3: the six loads of patch chunk + 3 into the registers just freed
+                                if (j == 1 && s == 1) p_coef(chunk + 2);
+                                if (j == 2 && (s & 1)) {
+                                    p_act(s >> 3, (s >> 1) & 3);
+                                    if (((s >> 1) & 3) == 3) p_store(chunk + 2, s >> 3);
+                                }
+                                if (j == 3 && s >= 17 && s < 23) p_load(chunk + 3, s - 17);
+                            }
+
                             ++s;
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -406,6 +509,23 @@ bool conv_wino_z128_supported(const IgemmArgs& a) {
     return conv_wino_r64_supported(a) && a.ups == 0 && !a.ups_phase && conv_wino_z128_shape(a.nfr_sel ? a.nfr_sel : a.nfr, a.Hs, a.Cin, a.Cout);
 }
 
+// The same kernel with the GroupNorm(+FiLM) affine + SiLU of its input applied while it stages the patch (ACT): shapes the plain kernel
+// takes, with at most two cout blocks per patch (each of them activates it).  The shape half is what the engine asks before it decides
+// not to materialise the activation image (engine.hip: res_block).
+bool conv_wino_z128_act_shape(int nfr, int H, int Cin, int Cout) {
+#ifdef VD_Z128_NO_ACT
+    return false;
+#endif
+    static const bool off = getenv("VD_NO_CONV_ACT") != nullptr;       // A/B switch: the activation pass + the plain kernel
+    return !off && Cout <= 256 && conv_wino_z128_shape(nfr, H, Cin, Cout);
+}
+
+bool conv_wino_z128_act_supported(const IgemmArgs& a) {
+    if (!(a.affA && a.affB && a.act == 1 && a.src1 == nullptr && a.C0 == a.Cin)) return false;
+    IgemmArgs b = a; b.affA = b.affB = nullptr; b.act = 0;             // the plain kernel's conditions on everything else
+    return conv_wino_z128_supported(b) && conv_wino_z128_act_shape(a.nfr_sel ? a.nfr_sel : a.nfr, a.Hs, a.Cin, a.Cout);
+}
+
 int launch_conv_wino_z128(const IgemmArgs& a, hipStream_t s) {
     const int Hl = a.Hs;
     VD_REQUIRE(a.stats == nullptr || a.stats_split == conv_wino_stats_split(Hl), "GroupNorm partial table: split");
@@ -417,10 +537,16 @@ int launch_conv_wino_z128(const IgemmArgs& a, hipStream_t s) {
     g.xcd_order = g.nbx % 8 == 0;
     static bool attr = false;
     if (!attr) {
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_z128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_z128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_z128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(conv3x3_wino_z128_kernel, dim3(g.nitems), dim3(256), z128::LDS_BYTES, s, a, g);
+    if (a.affA) {
+        VD_REQUIRE(conv_wino_z128_act_supported(a), "conv_wino_z128 with the activation in its patch staging: shape not covered");
+        hipLaunchKernelGGL(conv3x3_wino_z128_kernel<true>, dim3(g.nitems), dim3(256), z128::LDS_BYTES + 2 * a.Cin * sizeof(float), s, a, g);
+    } else {
+        hipLaunchKernelGGL(conv3x3_wino_z128_kernel<false>, dim3(g.nitems), dim3(256), z128::LDS_BYTES, s, a, g);
+    }
     VD_HIP(hipGetLastError());
     return 0;
 }

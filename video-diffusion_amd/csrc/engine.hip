@@ -161,9 +161,10 @@ static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     IgemmArgs one = g;                         // a big window goes out as several launches over frame ranges (igemm.hip)
     one.nfr = std::max(1, std::min(g.nfr, igemm_frames_per_launch(g)));
     one.M = one.nfr * g.Ho * g.Wo;
-    const bool wino = conv_wino_supported(one) || conv_wino_r64_supported(one);
+    const bool zact = conv_wino_z128_act_supported(one);              // conv_wino_z128.hip with the activation in its patch staging
+    const bool wino = zact || conv_wino_supported(one) || conv_wino_r64_supported(one);
     const bool split_gemm = gemm_split_supported(one) || conv_split_supported(one);
-    const int cls = wino ? (int)(g.ups_phase ? PC_CONV_WINO_R64_UPS : conv_wino_z128_supported(one) ? PC_CONV_WINO_Z128
+    const int cls = wino ? (int)(g.ups_phase ? PC_CONV_WINO_R64_UPS : zact || conv_wino_z128_supported(one) ? PC_CONV_WINO_Z128
                                                                : conv_wino_r64_supported(one) ? PC_CONV_WINO_R64 : PC_CONV_WINO)
                     : split_gemm && gemm_split_tile_class(igemm_sel_M(one), g.Cout) == 4 ? (int)PC_IGEMM_128x192
                     : igemm_tile_class(igemm_sel_M(one), g.Cout) + (g.ksz == 3 && !split_gemm ? (int)PC_CONV_128x128 : 0);   // 3x3 on the generic kernel
@@ -680,7 +681,20 @@ int vd_engine::gn_act(const Tens& x0, const Tens* x1, int N, int gw, int gb, con
         int rc = launch_gn_stats(src[i]->p, nullptr, src[i]->C, src[i]->C, N, HW, pt, split[i], st);
         if (rc) return rc;
     }
+    // Big tensors (the 64 x 64 and 32 x 32 levels of a full window) take the two-launch form: (A, B) per (frame, channel) by
+    // gn_final_affine, then the pass on many short blocks -- 5.95 TB/s against the 5.2 of the long blocks the in-kernel fold needs
+    // (tools/probes/stream_probe.hip); the 7 us of the extra launch are repaid from ~64 MB on.  Same formulas, same bits.
+    static const size_t big = getenv("VD_AA_BIG_MB") ? (size_t)atol(getenv("VD_AA_BIG_MB")) << 20 : (size_t)64 << 20;
+    const bool two = (size_t)N * HW * C * 4 >= big;
+    float* Aab = two ? ar.get<float>((size_t)N * C) : nullptr;
+    float* Bab = two ? ar.get<float>((size_t)N * C) : nullptr;
     if (ar.dry) return 0;
+    if (two) {
+        int rc = launch_gn_affine(part[0], split[0], x0.C, part[1], split[1], (double)HW * (C / 32), W(gw), W(gb), film, film_ld, N, C, Aab, Bab, st);
+        if (rc) return rc;
+        ProfScope ps(PC_ELEMENTWISE, 0.0, 8.0 * N * HW * C, st);
+        return launch_affine_act(x0.p, x1 ? x1->p : nullptr, x0.C, C, Aab, Bab, N, HW, act, y, st);
+    }
     GnFold f{part[0], split[0], part[1], split[1], (double)HW * (C / 32), W(gw), W(gb), film, film_ld};
     ProfScope ps(PC_ELEMENTWISE, 0.0, 8.0 * N * HW * C, st);
     return launch_affine_act_fold(x0.p, x1 ? x1->p : nullptr, x0.C, C, f, N, HW, act, y, st);
@@ -743,7 +757,13 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     // convolution that writes the image (it takes the pair as arrays), not with a tape
     const bool fold = !tape && gn_fold_fused();
     const bool fold1 = fold && !fuse_skip;
-    if (!fold1 && (rc = gn_fold(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, st, ar, &A1, &B1, &mr1))) return rc;
+    // Where conv_wino_z128.hip takes the convolution and one or two cout blocks share a patch, the GroupNorm(+FiLM) affine + SiLU runs in
+    // the kernel's patch staging and the activation image is never written (conv_wino_z128_act_shape): the pair goes in as arrays.  The
+    // dry run lays the arena out for both forms (a compact batch may decide differently).
+    const int nsel = g_sel_nfr > N ? g_sel_nfr : N;
+    const bool za1 = !tape && !fuse_skip && x1 == nullptr && params[r.c1w].kind == PK_CONV3W && f16_math() && conv_wino_z128_act_shape(nsel, H, cin, r.cout);
+    const bool za2 = !tape && params[r.c2w].kind == PK_CONV3W && f16_math() && conv_wino_z128_act_shape(nsel, H, r.cout, r.cout);
+    if ((!fold1 || za1 || ar.dry) && (rc = gn_fold(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, st, ar, &A1, &B1, &mr1))) return rc;
     float* h = ar.get<float>((size_t)N * HW * r.cout);
     Tens ht{h, r.cout, H};
     if (params[r.c1w].kind == PK_CONV3W) ht.part = stats_table(ar, N, H, r.cout, &ht.split);
@@ -755,14 +775,15 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         float* a1 = ar.get<float>((size_t)N * HW * cin);
         const size_t ksf = ksplit_scratch(ar, N, H, cin, r.cout);      // small grids: split-K scratch (conv_wino_r64.hip)
         float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
-        if (fold1 && (rc = gn_act(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, 1, a1, st, ar))) return rc;
+        if (fold1 && !za1 && (rc = gn_act(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, 1, a1, st, ar))) return rc;
         if (!ar.dry) {
             if (fuse_skip) {
                 gsk.bias = W(r.skb); gsk.out = sk_early; gsk.side = a1; gsk.sideA = A1; gsk.sideB = B1;
                 if ((rc = igemm_p(gsk, st))) return rc;
-            } else if (!fold1 && (rc = affine_act(x0.p, s1, x0.C, cin, A1, B1, N, HW, a1, st))) return rc;
+            } else if (!fold1 && !za1 && (rc = affine_act(x0.p, s1, x0.C, cin, A1, B1, N, HW, a1, st))) return rc;
             Tens at{a1, cin, H};
-            IgemmArgs g = conv_args(at, nullptr, N, 3, 1, 0);
+            IgemmArgs g = conv_args(za1 ? x0 : at, nullptr, N, 3, 1, 0);
+            if (za1) { g.affA = A1; g.affB = B1; g.act = 1; }
             set_w(g, r.c1w); g.bias = W(r.c1b);
             g.out = h; g.ldo = r.cout; g.Cout = r.cout; g.stats = ht.part; g.stats_split = ht.split;
             g.ksplit_ws = ksw; g.ksplit_ws_floats = ksf;
@@ -771,7 +792,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         }
         ar.release(mk);
     }
-    if (!fold && (rc = gn_fold(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, st, ar, &A2, &B2, &mr2)))
+    if ((!fold || za2 || ar.dry) && (rc = gn_fold(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, st, ar, &A2, &B2, &mr2)))
         return rc;
     const float* skip = x0.p;
     if (fuse_skip) skip = sk_early;
@@ -792,11 +813,12 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
         float* a2 = ar.get<float>((size_t)N * HW * r.cout);
         const size_t ksf = ksplit_scratch(ar, N, H, r.cout, r.cout);
         float* ksw = ksf ? ar.get<float>(ksf) : nullptr;
-        if (fold && (rc = gn_act(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, 1, a2, st, ar))) return rc;
+        if (fold && !za2 && (rc = gn_act(ht, nullptr, N, r.gn2w, r.gn2b, cfg.use_scale_shift_norm ? film : nullptr, film_total, 1, a2, st, ar))) return rc;
         if (!ar.dry) {
-            if (!fold && (rc = affine_act(h, nullptr, r.cout, r.cout, A2, B2, N, HW, a2, st))) return rc;
+            if (!fold && !za2 && (rc = affine_act(h, nullptr, r.cout, r.cout, A2, B2, N, HW, a2, st))) return rc;
             Tens at{a2, r.cout, H};
-            IgemmArgs g = conv_args(at, nullptr, N, 3, 1, 0);
+            IgemmArgs g = conv_args(za2 ? ht : at, nullptr, N, 3, 1, 0);
+            if (za2) { g.affA = A2; g.affB = B2; g.act = 1; }
             set_w(g, r.c2w); g.bias = W(r.c2b);
             g.res = skip; g.res_ld = r.cout; g.out = o; g.ldo = r.cout; g.Cout = r.cout;
             g.stats = ot.part; g.stats_split = ot.split;
@@ -2233,6 +2255,21 @@ int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, i
     VD_REQUIRE(conv_wino_r64_supported(g), "vd_op_conv_wino_split: shape not covered by conv_wino_r64.hip");
     return launch_igemm(g, static_cast<hipStream_t>(stream));            // cuts big windows along frames like the engine
 }
+
+int vd_op_conv_wino_act(const float* src0, int Cin, int nfr, int Hs, int Ws, const void* w_split, const float* bias, const float* affA,
+                        const float* affB, const float* res, float* out, int Cout, double* gn_part, void* stream) {
+    IgemmArgs g{};
+    g.src0 = src0; g.C0 = Cin; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws;
+    g.stride = 1; g.pad = 1; g.ksz = 3; g.Ho = Hs; g.Wo = Ws;
+    g.wwino = static_cast<const float*>(w_split); g.wsplit = 2; g.bias = bias; g.res = res; g.res_ld = Cout;
+    g.affA = affA; g.affB = affB; g.act = 1;
+    g.out = out; g.ldo = Cout; g.Cout = Cout; g.M = nfr * g.Ho * g.Wo;
+    g.stats = gn_part; g.stats_split = conv_wino_stats_split(g.Ho);
+    VD_REQUIRE(conv_wino_z128_act_supported(g), "vd_op_conv_wino_act: shape not covered by conv_wino_z128.hip's activating form (vd_conv_wino_act_ok)");
+    return launch_igemm(g, static_cast<hipStream_t>(stream));
+}
+
+int vd_conv_wino_act_ok(int nfr, int H, int Cin, int Cout) { return f16_math() && conv_wino_z128_act_shape(nfr, H, Cin, Cout) ? 1 : 0; }
 
 int vd_pack_conv3_wino_ups(const float* host_oihw, unsigned short* host_out, int O, int I) {
     VD_REQUIRE(host_oihw && host_out && O % 64 == 0 && I % 32 == 0, "vd_pack_conv3_wino_ups: O multiple of 64, I of 32");

@@ -207,7 +207,7 @@ static int launch_igemm_one(const IgemmArgs& a, hipStream_t s) {
         return launch_conv_wino_r64(a, s);
     }
     if (gemm_split_supported(a) || conv_split_supported(a)) return launch_gemm_split(a, igemm_tile_class(igemm_sel_M(a), a.Cout), s);
-    if (conv_wino_z128_supported(a)) return launch_conv_wino_z128(a, s);
+    if (conv_wino_z128_act_supported(a) || conv_wino_z128_supported(a)) return launch_conv_wino_z128(a, s);
     if (conv_wino_r64_supported(a)) return launch_conv_wino_r64(a, s);
     VD_REQUIRE(!a.wsplit, "split weight image given for a shape the split kernels do not cover");
     if (gemm_frag_supported(a)) return launch_gemm_frag(a, igemm_tile_class(igemm_sel_M(a), a.Cout), s);

@@ -5,6 +5,8 @@
 // B=8.  Here only the *statistics* pass reads the tensor; the normalise/scale/shift/
 // activation is folded into a per-(frame, channel) affine pair consumed by the next convolution's
 // operand load (igemm.hip).  Sums are accumulated in fp64, so E[x^2]-E[x]^2 is safe.
+#include <cstdlib>
+
 #include "vd_common.h"
 
 namespace vd {
@@ -180,13 +182,20 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     for (; p < p_end; p += ppi) *reinterpret_cast<f32x4*>(dst + (size_t)p * C) = one(*reinterpret_cast<const f32x4*>(src + (size_t)p * ld));
 }
 
+// Blocks of the activation pass: pixel ranges of a frame, at least `aa_min_iters` trips of four 16-byte loads per thread, until the grid has
+// `aa_target_blocks` blocks.  tools/probes/stream_probe.hip (r05f, 128 ch x 64 x 64 x 128 frames, read + write): 2048 blocks of 8 trips
+// 5.24 TB/s, 8192 blocks of 2 trips 5.95 TB/s (a flat one-trip mapping 6.16; hipMemcpy 5.43) -- many short blocks keep more requests in
+// flight across the tail of each wave than few long ones.  (VD_AA_BLOCKS / VD_AA_ITERS: A/B knobs, read once.)
+static int aa_target_blocks() { static const int v = getenv("VD_AA_BLOCKS") ? atoi(getenv("VD_AA_BLOCKS")) : 8192; return v; }
+static int aa_min_iters() { static const int v = getenv("VD_AA_ITERS") ? atoi(getenv("VD_AA_ITERS")) : 1; return v; }
+
 int launch_affine_act(const float* src0, const float* src1, int C0, int C, const float* affA, const float* affB, int nfr,
                       int HW, int act, float* y, hipStream_t s) {
     VD_REQUIRE(C % 4 == 0 && C0 % 4 == 0 && C <= 1024 && (src1 != nullptr || C0 == C), "affine_act: channel counts");
     const int tpp = C / 4, ppi = 256 / tpp, threads = ppi * tpp;
     // pixel ranges: enough blocks to fill the chip (>= 2048), at least 4 iterations of 4 loads per block where the frame allows
     int split = 1;
-    while (nfr * split < 2048 && HW / (split * 2) >= ppi * 16) split *= 2;
+    while (nfr * split < aa_target_blocks() && HW / (split * 2) >= ppi * aa_min_iters() * 4) split *= 2;
     const int per = (HW + split - 1) / split;
     hipLaunchKernelGGL(affine_act_kernel, dim3(split, nfr), dim3(threads), 0, s, src0, src1, C0, C, affA, affB, HW, per, act, y);
     VD_HIP(hipGetLastError());
@@ -292,7 +301,7 @@ int launch_affine_act_fold(const float* src0, const float* src1, int C0, int C, 
     VD_REQUIRE(C % 32 == 0 && C0 % 4 == 0 && C <= 1024 && (src1 != nullptr || C0 == C), "affine_act_fold: channel counts");
     VD_REQUIRE(f.part0 && (C0 == C || f.part1), "affine_act_fold: GroupNorm partial tables");
     const int tpp = C / 4, ppi = 256 / tpp, threads = ppi * tpp;
-    int split = 1;
+    int split = 1;                                  // (coarse blocks: every block folds its frame's table first -- 8192 blocks: 1.74 -> 2.58 ms per step, r05h)
     while (nfr * split < 2048 && HW / (split * 2) >= ppi * 16) split *= 2;
     const int per = (HW + split - 1) / split;
     hipLaunchKernelGGL(affine_act_fold_kernel, dim3(split, nfr), dim3(threads), 0, s, src0, src1, C0, C, f, HW, per, act, y);

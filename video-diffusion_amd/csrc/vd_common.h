@@ -209,6 +209,9 @@ int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s);
 bool conv_wino_z128_supported(const IgemmArgs& a);
 bool conv_wino_z128_shape(int nfr, int H, int Cin, int Cout);     // the shape half of that decision (grid fill; conv_wino_z128.hip)
 int launch_conv_wino_z128(const IgemmArgs& a, hipStream_t s);
+// ... and with the GroupNorm(+FiLM) affine + SiLU of the input applied in the kernel's patch staging (a.affA / a.affB / a.act = 1): no activation image
+bool conv_wino_z128_act_shape(int nfr, int H, int Cin, int Cout);
+bool conv_wino_z128_act_supported(const IgemmArgs& a);
 // Upsample (nearest x2) + conv3x3 in its sub-pixel form (conv_wino_r64.hip): four phase kernels per real cout over the
 // LOW-resolution map, one of the four Winograd columns structurally zero and skipped.  IgemmArgs::ups_phase selects it;
 // the GroupNorm table then has conv_wino_ups_stats_split(Hs) entries per frame.
