@@ -341,10 +341,11 @@ int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, i
 /* The ResBlock's `GroupNorm -> SiLU -> conv3x3` (unet.py:138-141,185-198) with the normalisation's folded affine and the SiLU applied
  * INSIDE the convolution kernel: out = conv3x3(silu(x * affA[frame][c] + affB[frame][c])) + bias (+ res), zero padding applied to the
  * ACTIVATED tensor as in the reference.  csrc/conv_wino_z128.hip stages the patch through registers and activates it there, so the
- * activation image (one write + one read of the tensor) does not exist.  Shapes: vd_conv_wino_act_ok(nfr, H, Cin, Cout) -- the f16x3
+ * activation image (one write + one read of the tensor) does not exist.  The input may be the virtual channel concat of two tensors
+ * (src1 != NULL: C0 channels from src0, Cin - C0 from src1: th.cat([h, hs.pop()], 1), unet.py:826-828).  Shapes: vd_conv_wino_act_ok(nfr, H, Cin, Cout) -- the f16x3
  * arithmetic, maps >= 16 x 16, Cout in {128, 256}, Cin <= 320, a grid that fills the chip. */
-int vd_op_conv_wino_act(const float* src0, int Cin, int nfr, int Hs, int Ws, const void* w_split, const float* bias, const float* affA,
-                        const float* affB, const float* res, float* out, int Cout, double* gn_part, void* stream);
+int vd_op_conv_wino_act(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, const void* w_split, const float* bias,
+                        const float* affA, const float* affB, const float* res, float* out, int Cout, double* gn_part, void* stream);
 int vd_conv_wino_act_ok(int nfr, int H, int Cin, int Cout);
 /* Upsample (nearest x2, unet.py:70-77) + conv3x3 in its sub-pixel form on csrc/conv_wino_r64.hip: output pixel (2y + a, 2x + b) sees
  * only a 2 x 2 neighbourhood of the SOURCE map, i.e. four 3x3 "phase" kernels with one zero row and one zero column each

@@ -831,30 +831,34 @@ def test_every_arithmetic_mode_end_to_end(mode):
         assert abs(k["signed_mean_err"]) <= 0.05 * k["mean_err"] + 1e-9, ("fp32 kernel bias", k)
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H", [(41, 32, 128, 32), (64, 64, 128, 32), (16, 128, 128, 64), (128, 64, 256, 16), (43, 96, 128, 32),
-                                          (16, 320, 128, 64), (32, 256, 256, 32), (17, 160, 128, 64)])
-def test_conv3x3_winograd_with_the_activation_in_its_patch_staging(N, Cin, Cout, H):
+@pytest.mark.parametrize("N,Cin,Cout,H,C1", [(41, 32, 128, 32, 0), (64, 64, 128, 32, 0), (16, 128, 128, 64, 0), (128, 64, 256, 16, 0), (43, 96, 128, 32, 0),
+                                             (16, 320, 128, 64, 0), (32, 256, 256, 32, 0), (17, 160, 128, 64, 0),
+                                             (16, 256, 128, 64, 128), (24, 128, 256, 32, 32), (16, 192, 128, 64, 160), (33, 64, 128, 32, 32)])
+def test_conv3x3_winograd_with_the_activation_in_its_patch_staging(N, Cin, Cout, H, C1):
     """csrc/conv_wino_z128.hip, ACT form (r05): out = conv3x3(silu(x * A[n][c] + B[n][c])) + bias + res with the GroupNorm(+FiLM) affine and
     the SiLU applied while the kernel stages its patch -- the ResBlock's `GroupNorm -> SiLU -> conv` (unet.py:138-141,185-198) without the
-    activation image.  Against torch fp32 at the op tolerance; against the materialising form (vd_op_affine_act + vd_op_conv_wino_split,
-    the same arithmetic element for element: the zero padding must be zeros of the ACTIVATED tensor, silu(B) would be wrong) to the bit;
-    GroupNorm partial sums of the output as in the plain kernel; odd chunk-pair counts, one and two cout blocks, both item orders."""
+    activation image; C1 > 0: over the virtual concat of two tensors (the decoder's th.cat([h, hs.pop()], 1), unet.py:826-828; source widths
+    that are and are not a multiple of 32).  Against torch fp32 at the op tolerance; against the materialising form (vd_op_affine_act +
+    vd_op_conv_wino_split, the same arithmetic element for element: the zero padding must be zeros of the ACTIVATED tensor, silu(B) would be
+    wrong) to the bit; GroupNorm partial sums of the output as in the plain kernel; odd chunk-pair counts, one and two cout blocks, both item orders."""
     L = _lib.lib()
     if math_mode() != "f16x3" or not L.vd_conv_wino_act_ok(N, H, Cin, Cout):
         pytest.skip("the activating form serves the f16x3 arithmetic on conv_wino_z128.hip's shapes")
+    C0 = Cin - C1
     x, w, b = rnd(N, Cin, H, H, scale=2.0), rnd(Cout, Cin, 3, 3, scale=(3.0 / (9 * Cin)) ** 0.5), rnd(Cout, scale=0.1)
     A, B = rnd(N, Cin, seed=2) + 1.3, rnd(N, Cin, seed=3) * 0.7
     res = rnd(N, Cout, H, H, seed=4)
-    xd, bd, rd, Ad, Bd = dev(nhwc(x)), dev(b), dev(nhwc(res)), dev(A), dev(B)
+    x0d, x1d = dev(nhwc(x[:, :C0])), (dev(nhwc(x[:, C0:])) if C1 else None)
+    bd, rd, Ad, Bd = dev(b), dev(nhwc(res)), dev(A), dev(B)
     ws = dev(pack_wino_split(w))
     split = L.vd_conv_stats_split(H)
     out_a, out_m = torch.empty(N, H, H, Cout, device="cuda"), torch.empty(N, H, H, Cout, device="cuda")
     part_a = torch.full((N, split, Cout, 2), float("nan"), dtype=torch.float64, device="cuda")
     part_m = torch.full((N, split, Cout, 2), float("nan"), dtype=torch.float64, device="cuda")
-    _lib.check(L.vd_op_conv_wino_act(_lib.ptr(xd), Cin, N, H, H, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(Ad), _lib.ptr(Bd), _lib.ptr(rd),
+    _lib.check(L.vd_op_conv_wino_act(_lib.ptr(x0d), _lib.ptr(x1d), C0, Cin, N, H, H, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(Ad), _lib.ptr(Bd), _lib.ptr(rd),
                                      _lib.ptr(out_a), Cout, _lib.ptr(part_a), _lib.current_stream()))
     act = torch.empty(N, H, H, Cin, device="cuda")
-    _lib.check(L.vd_op_affine_act(_lib.ptr(xd), None, Cin, Cin, _lib.ptr(Ad), _lib.ptr(Bd), N, H * H, 1, _lib.ptr(act), _lib.current_stream()))
+    _lib.check(L.vd_op_affine_act(_lib.ptr(x0d), _lib.ptr(x1d), C0, Cin, _lib.ptr(Ad), _lib.ptr(Bd), N, H * H, 1, _lib.ptr(act), _lib.current_stream()))
     _lib.check(L.vd_op_conv_wino_split(_lib.ptr(act), Cin, N, H, H, 0, _lib.ptr(ws), _lib.ptr(bd), _lib.ptr(rd), None, 0, _lib.ptr(out_m), Cout,
                                        _lib.ptr(part_m), _lib.current_stream()))
     torch.cuda.synchronize()

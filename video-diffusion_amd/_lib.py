@@ -204,7 +204,7 @@ SIGNATURES = {
     "vd_conv_ups_stats_split": (_I, [_I]),
     "vd_op_conv_wino_ups": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "vd_op_conv_wino_split": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
-    "vd_op_conv_wino_act": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "vd_op_conv_wino_act": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "vd_conv_wino_act_ok": (_I, [_I, _I, _I, _I]),
     "vd_pack_conv3_split": (_I, [_P, _P, _I, _I]),
     "vd_op_conv_split": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),

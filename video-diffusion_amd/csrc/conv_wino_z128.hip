@@ -104,15 +104,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
         const bool in = py < P && pxh < P / 2 && ly >= 0 && ly < Hl && lx >= 0 && lx < Wl;
         if constexpr (ACT) {
             // the thread keeps ONE channel quad (lq = tid & 3: its (A, B) are four registers per chunk) and writes it to the place the
-            // DMA image gives that quad: position lq ^ ((py >> 1) & 3) of the pixel's four 16-byte slots
-            xo[e] = in ? (unsigned)((f0 * a.Hs + ly) * a.Ws + lx) * (unsigned)(a.Cin * 4) + (unsigned)(lq * 16) : 0x80000000u;
+            // DMA image gives that quad: position lq ^ ((py >> 1) & 3) of the pixel's four 16-byte slots.  xo = the PIXEL index: the
+            // input may be a virtual concat of two tensors of different widths (unet.py:826-828), the byte offset is formed per source
+            xo[e] = in ? (unsigned)((f0 * a.Hs + ly) * a.Ws + lx) : 0x80000000u;
             ldo[e] = (unsigned)(((gs & ~3) | (lq ^ ((py >> 1) & 3))) * 16);
             inm[e] = __ballot(in);
         } else {
             xo[e] = in ? (unsigned)((f0 * a.Hs + ly) * a.Ws + lx) * (unsigned)(a.Cin * 4) + (unsigned)((lq ^ ((py >> 1) & 3)) * 16) : 0x80000000u;
         }
     }
-    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * a.Cin * 4, 0x00020000);
+    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, a.nfr * a.Hs * a.Ws * (ACT ? a.C0 : a.Cin) * 4, 0x00020000);
     const auto xnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, 0, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto x_dma_one = [&](int chunk, int e) {                          // (a request past the last chunk always issues: conv_wino_r64.hip)
@@ -129,8 +130,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     f32x4 stg[ACT ? NX : 1];                                          // the patch being staged: loaded raw, activated in place
     f32x4 Aq = {0.f, 0.f, 0.f, 0.f}, Bq = Aq;                         // (A, B) of the thread's channel quad for that patch
     float tq[4];                                                      // in flight between the parts of one slot e
-    auto p_load = [&](int patch, int e) {                            // (a request past the last chunk always issues, through the empty descriptor)
-        if constexpr (ACT) stg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(patch < nchunk ? xsrc : xnull, xo[e], patch * 64, 0));
+    // The input may be a virtual concat of two tensors (unet.py:826-828): chunks [0, nch0) come from src0 (C0 channels per pixel), the rest
+    // from src1.  Byte offsets of the thread's six slots for either source; the descriptor of a patch is formed from SCALAR selects (a
+    // select between two descriptor VALUES goes through vector registers and hipcc wraps every load in a waterfall loop)
+    const int nch0 = a.C0 >> 4;
+    unsigned xo1[ACT ? NX : 1];
+    if constexpr (ACT) {
+#pragma unroll
+        for (int e = 0; e < NX; ++e) {
+            const unsigned pix = xo[e];
+            xo[e] = pix == 0x80000000u ? pix : pix * (unsigned)(a.C0 * 4) + (unsigned)((tid & 3) * 16);
+            xo1[e] = pix == 0x80000000u ? pix : pix * (unsigned)((a.Cin - a.C0) * 4) + (unsigned)((tid & 3) * 16);
+        }
+    }
+    auto p_load = [&](int patch, int e) {                            // (a request past the last chunk always issues, through an empty descriptor)
+        if constexpr (ACT) {
+            const bool first = patch < nch0;
+            const float* base = first ? a.src0 : a.src1;
+            const int bytes = patch >= nchunk ? 0 : a.nfr * a.Hs * a.Ws * (first ? a.C0 : a.Cin - a.C0) * 4;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base ? base : a.src0), 0, bytes, 0x00020000);
+            stg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, first ? xo[e] : xo1[e], (first ? patch : patch - nch0) * 64, 0));
+        }
     };
     auto p_coef = [&](int patch) {
         if constexpr (ACT) {
@@ -521,8 +541,8 @@ bool conv_wino_z128_act_shape(int nfr, int H, int Cin, int Cout) {
 }
 
 bool conv_wino_z128_act_supported(const IgemmArgs& a) {
-    if (!(a.affA && a.affB && a.act == 1 && a.src1 == nullptr && a.C0 == a.Cin)) return false;
-    IgemmArgs b = a; b.affA = b.affB = nullptr; b.act = 0;             // the plain kernel's conditions on everything else
+    if (!(a.affA && a.affB && a.act == 1 && (a.src1 != nullptr || a.C0 == a.Cin) && a.C0 % 16 == 0 && a.C0 > 0)) return false;
+    IgemmArgs b = a; b.affA = b.affB = nullptr; b.act = 0; b.src1 = nullptr; b.C0 = a.Cin;     // the plain kernel's conditions on everything else
     return conv_wino_z128_supported(b) && conv_wino_z128_act_shape(a.nfr_sel ? a.nfr_sel : a.nfr, a.Hs, a.Cin, a.Cout);
 }
 

@@ -756,12 +756,14 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
     // the statistics folded by the activation pass itself (gn_act) wherever nothing else reads (A, B): not for the skip
     // convolution that writes the image (it takes the pair as arrays), not with a tape
     const bool fold = !tape && gn_fold_fused();
-    const bool fold1 = fold && !fuse_skip;
     // Where conv_wino_z128.hip takes the convolution and one or two cout blocks share a patch, the GroupNorm(+FiLM) affine + SiLU runs in
     // the kernel's patch staging and the activation image is never written (conv_wino_z128_act_shape): the pair goes in as arrays.  The
     // dry run lays the arena out for both forms (a compact batch may decide differently).
     const int nsel = g_sel_nfr > N ? g_sel_nfr : N;
-    const bool za1 = !tape && !fuse_skip && x1 == nullptr && params[r.c1w].kind == PK_CONV3W && f16_math() && conv_wino_z128_act_shape(nsel, H, cin, r.cout);
+    const bool za1 = !tape && params[r.c1w].kind == PK_CONV3W && f16_math() && x0.C % 16 == 0 && conv_wino_z128_act_shape(nsel, H, cin, r.cout);
+    // ... and then the skip convolution has no image to write: it runs as a plain 1x1 (the dry run keeps the larger layout: sk_early under the transient)
+    if (za1 && !ar.dry) fuse_skip = false;
+    const bool fold1 = fold && !fuse_skip;
     const bool za2 = !tape && params[r.c2w].kind == PK_CONV3W && f16_math() && conv_wino_z128_act_shape(nsel, H, r.cout, r.cout);
     if ((!fold1 || za1 || ar.dry) && (rc = gn_fold(x0, x1, N, r.gn1w, r.gn1b, nullptr, 0, st, ar, &A1, &B1, &mr1))) return rc;
     float* h = ar.get<float>((size_t)N * HW * r.cout);
@@ -782,7 +784,7 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
                 if ((rc = igemm_p(gsk, st))) return rc;
             } else if (!fold1 && !za1 && (rc = affine_act(x0.p, s1, x0.C, cin, A1, B1, N, HW, a1, st))) return rc;
             Tens at{a1, cin, H};
-            IgemmArgs g = conv_args(za1 ? x0 : at, nullptr, N, 3, 1, 0);
+            IgemmArgs g = conv_args(za1 ? x0 : at, za1 ? x1 : nullptr, N, 3, 1, 0);
             if (za1) { g.affA = A1; g.affB = B1; g.act = 1; }
             set_w(g, r.c1w); g.bias = W(r.c1b);
             g.out = h; g.ldo = r.cout; g.Cout = r.cout; g.stats = ht.part; g.stats_split = ht.split;
@@ -2256,10 +2258,11 @@ int vd_op_conv_wino_split(const float* src0, int Cin, int nfr, int Hs, int Ws, i
     return launch_igemm(g, static_cast<hipStream_t>(stream));            // cuts big windows along frames like the engine
 }
 
-int vd_op_conv_wino_act(const float* src0, int Cin, int nfr, int Hs, int Ws, const void* w_split, const float* bias, const float* affA,
-                        const float* affB, const float* res, float* out, int Cout, double* gn_part, void* stream) {
+int vd_op_conv_wino_act(const float* src0, const float* src1, int C0, int Cin, int nfr, int Hs, int Ws, const void* w_split, const float* bias,
+                        const float* affA, const float* affB, const float* res, float* out, int Cout, double* gn_part, void* stream) {
     IgemmArgs g{};
-    g.src0 = src0; g.C0 = Cin; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws;
+    VD_REQUIRE(src0 && (src1 ? C0 > 0 && C0 < Cin : C0 == Cin), "vd_op_conv_wino_act: one source of Cin channels, or two of C0 and Cin - C0");
+    g.src0 = src0; g.src1 = src1; g.C0 = C0; g.Cin = Cin; g.nfr = nfr; g.Hs = Hs; g.Ws = Ws;
     g.stride = 1; g.pad = 1; g.ksz = 3; g.Ho = Hs; g.Wo = Ws;
     g.wwino = static_cast<const float*>(w_split); g.wsplit = 2; g.bias = bias; g.res = res; g.res_ld = Cout;
     g.affA = affA; g.affB = affB; g.act = 1;
