@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--only", type=int, default=0, help="only layers with this output resolution")
     ap.add_argument("--quick", action="store_true", help="six representative layers only (kernel ablations)")
+    ap.add_argument("--act", action="store_true", help="time conv_wino_z128.hip's activating form (vd_op_conv_wino_act) on the shapes it serves, next to "
+                                                       "the materialising pair it replaces (vd_op_affine_act + the plain conv)")
     args = ap.parse_args()
     L = _lib.lib()
     stamps = hasattr(L, "vd_debug_r64_stamps")
@@ -56,6 +58,34 @@ def main():
             else:
                 _lib.check(L.vd_op_conv_wino_split(_lib.ptr(x0), Cin, nfr, Hs, Hs, 0, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(res), None, 0,
                                                    _lib.ptr(out), Cout, _lib.ptr(part), _lib.current_stream()))
+        if args.act:
+            if ups or not L.vd_conv_wino_act_ok(nfr, H, Cin, Cout):
+                continue
+            A, Bc = torch.rand(nfr, Cin, device="cuda") + 0.5, torch.rand(nfr, Cin, device="cuda") - 0.5
+            img = torch.empty_like(x0)
+
+            def run_act():
+                _lib.check(L.vd_op_conv_wino_act(_lib.ptr(x0), None, Cin, Cin, nfr, Hs, Hs, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(A), _lib.ptr(Bc), _lib.ptr(res),
+                                                 _lib.ptr(out), Cout, _lib.ptr(part), _lib.current_stream()))
+
+            def run_pair():
+                _lib.check(L.vd_op_affine_act(_lib.ptr(x0), None, Cin, Cin, _lib.ptr(A), _lib.ptr(Bc), nfr, Hs * Hs, 1, _lib.ptr(img), _lib.current_stream()))
+                _lib.check(L.vd_op_conv_wino_split(_lib.ptr(img), Cin, nfr, Hs, Hs, 0, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(res), None, 0,
+                                                   _lib.ptr(out), Cout, _lib.ptr(part), _lib.current_stream()))
+            tms = []
+            for fn in (run, run_act, run_pair):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                tms.append(e0.elapsed_time(e1) / args.reps * 1e3)
+            print(f"{Cin:5d} -> {Cout:4d} @ {H:2d} x{cnt:2d}: plain conv {tms[0]:7.1f} us | activating conv {tms[1]:7.1f} us | affine_act + plain conv {tms[2]:7.1f} us", flush=True)
+            continue
         for _ in range(3):
             run()
         torch.cuda.synchronize()

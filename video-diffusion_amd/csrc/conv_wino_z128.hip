@@ -143,15 +143,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
             xo1[e] = pix == 0x80000000u ? pix : pix * (unsigned)((a.Cin - a.C0) * 4) + (unsigned)((tid & 3) * 16);
         }
     }
-    auto p_load = [&](int patch, int e) {                            // (a request past the last chunk always issues, through an empty descriptor)
+    auto p_fetch = [&](int patch, int e) -> f32x4 {                  // (a request past the last chunk always issues, through an empty descriptor)
         if constexpr (ACT) {
             const bool first = patch < nch0;
             const float* base = first ? a.src0 : a.src1;
             const int bytes = patch >= nchunk ? 0 : a.nfr * a.Hs * a.Ws * (first ? a.C0 : a.Cin - a.C0) * 4;
             const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base ? base : a.src0), 0, bytes, 0x00020000);
-            stg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, first ? xo[e] : xo1[e], (first ? patch : patch - nch0) * 64, 0));
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, first ? xo[e] : xo1[e], (first ? patch : patch - nch0) * 64, 0));
+        } else {
+            return f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
+    auto p_load = [&](int patch, int e) { if constexpr (ACT) stg[e] = p_fetch(patch, e); };
     auto p_coef = [&](int patch) {
         if constexpr (ACT) {
             const int pc = min(patch, nchunk - 1) * 16 + cq4;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     };
     // slot e in four parts of 7 vector instructions (what hides beside an MFMA that carries nothing else), consecutive instructions on
     // different elements; the arithmetic of norm.hip's pass to the bit: fma(x, A, B), silu(v) = v * rcp(1 + exp2(-log2(e) v))
-    auto p_act = [&](int e, int part) {
+    auto p_act_on = [&](f32x4 (&stg)[ACT ? NX : 1], int e, int part) {
         if constexpr (ACT) {
             if (part == 0)
                 asm("v_fma_f32 %0, %0, %4, %8\n\tv_fma_f32 %1, %1, %5, %9\n\tv_fma_f32 %2, %2, %6, %10\n\tv_fma_f32 %3, %3, %7, %11\n\t"
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
                     : "+v"(stg[e][0]), "+v"(stg[e][1]), "+v"(stg[e][2]), "+v"(stg[e][3]), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]));
         }
     };
+    auto p_act = [&](int e, int part) { p_act_on(stg, e, part); };
     auto p_store = [&](int patch, int e) {
         if constexpr (ACT) *reinterpret_cast<f32x4*>(lds + (patch < nchunk ? (patch & (NB - 1)) : NB) * XBUF + ldo[e]) = stg[e];
     };
@@ -284,25 +288,48 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     f32x16 acc[2][2][4];                                              // [z][m][n]
     Z128_STAMP(0); Z128_STAMP(14);
     // ---- prologue: three patches and the weights of (chunk 0, position 0) requested; the 256 accumulator writes go under the wait
+    auto zero_acc = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int z = 0; z < 2; ++z)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[z][m][n][r]));
+        __builtin_amdgcn_sched_barrier(0);
+    };
     if constexpr (ACT) {
-        // the frame's (A, B) into LDS; patches 0 and 1 loaded, activated and stored whole (per item: 2 x 6 loads, 2 x 24 elements); patch 2 is
-        // left in flight in the staging registers -- the state the loop expects: chunk c activates patch c + 2 in its position 2
+        // Patches 0 and 1 requested together with the weights of (chunk 0, position 0) -- one memory round trip at the head of the item --,
+        // the accumulator writes and the frame's (A, B) table (LDS) under the wait; both patches activated and stored whole; patch 2 is left
+        // in flight in the staging registers: the state the loop expects (chunk c activates patch c + 2 in its position 2)
+        f32x4 stg1[NX];
+#pragma unroll
+        for (int e = 0; e < NX; ++e) stg[e] = p_fetch(0, e);
+#pragma unroll
+        for (int e = 0; e < NX; ++e) stg1[e] = p_fetch(1, e);
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) b_load_one(0, 0, idx);
         for (int c = tid; c < a.Cin; c += 256) {
             sab[c] = a.affA[(size_t)f0 * a.Cin + c];
             sab[a.Cin + c] = a.affB[(size_t)f0 * a.Cin + c];
         }
+        zero_acc();
         __syncthreads();
+        p_coef(0);
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int e = 0; e < NX; ++e) {
 #pragma unroll
-            for (int e = 0; e < NX; ++e) p_load(c, e);
-            p_coef(c);
+            for (int part = 0; part < 4; ++part) p_act(e, part);
+            p_store(0, e);
+        }
+        p_coef(1);
 #pragma unroll
-            for (int e = 0; e < NX; ++e) {
+        for (int e = 0; e < NX; ++e) {
 #pragma unroll
-                for (int part = 0; part < 4; ++part) p_act(e, part);
-                p_store(c, e);
-            }
+            for (int part = 0; part < 4; ++part) p_act_on(stg1, e, part);
+            *reinterpret_cast<f32x4*>(lds + (1 < nchunk ? 1 : NB) * XBUF + ldo[e]) = stg1[e];
         }
 #pragma unroll
         for (int e = 0; e < NX; ++e) p_load(2, e);
@@ -311,19 +338,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int e = 0; e < NX; ++e) x_dma_one(c, e);
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) b_load_one(0, 0, idx);
+        zero_acc();
     }
-#pragma unroll
-    for (int idx = 0; idx < 8; ++idx) b_load_one(0, 0, idx);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int z = 0; z < 2; ++z)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[z][m][n][r]));
-    __builtin_amdgcn_sched_barrier(0);
     // patch 0 has landed in every wave: the 2 * NX + 8 youngest requests are patches 1, 2 (first read behind the loop's first barrier,
     // which waits for them) and the weights
     if constexpr (ACT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // patches 0, 1 are written; the loads in flight land in registers
@@ -537,7 +555,8 @@ bool conv_wino_z128_act_shape(int nfr, int H, int Cin, int Cout) {
     return false;
 #endif
     static const bool off = getenv("VD_NO_CONV_ACT") != nullptr;       // A/B switch: the activation pass + the plain kernel
-    return !off && Cout <= 256 && conv_wino_z128_shape(nfr, H, Cin, Cout);
+    static const int max_cout = getenv("VD_CONV_ACT_MAX_COUT") ? atoi(getenv("VD_CONV_ACT_MAX_COUT")) : 256;
+    return !off && Cout <= max_cout && conv_wino_z128_shape(nfr, H, Cin, Cout);
 }
 
 bool conv_wino_z128_act_supported(const IgemmArgs& a) {
