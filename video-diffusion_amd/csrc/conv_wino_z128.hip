@@ -522,7 +522,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
 // 16^2, 128 frames: 384 items = 1.5 rounds of 256 CUs against 3.0; 200 | 161 us): decided by the fill of the last round.
 static double z128_fill(int items, int cus) { return (double)items / ((double)cus * ((items + cus - 1) / cus)); }
 
+static bool z128_shape(int nfr, int H, int Cin, int Cout, int max_cin);
 bool conv_wino_z128_shape(int nfr, int H, int Cin, int Cout) {
+#ifndef VD_Z128_MAX_CIN
+#define VD_Z128_MAX_CIN 320
+#endif
+    return z128_shape(nfr, H, Cin, Cout, VD_Z128_MAX_CIN);
+}
+
+static bool z128_shape(int nfr, int H, int Cin, int Cout, int max_cin) {
 #ifdef VD_Z128_OFF                                   // kernel-experiment builds (tools/build_variant.sh): every shape on conv_wino_r64.hip
     return false;
 #endif
@@ -530,10 +538,7 @@ bool conv_wino_z128_shape(int nfr, int H, int Cin, int Cout) {
     // 1.5 x the MFMAs for half the per-item overhead and half the vector work: pays while the channel loop is short.  Same box,
     // us per launch, this kernel | conv_wino_r64.hip (r04q, after the latter stopped loading the third weight piece):
     // 128 -> 128 @ 64^2 411 - 428 | 432 - 451, 256 -> 256 @ 32^2 344 - 356 | 361 - 370, 640 -> 256 @ 32^2 805 | 758 - 774
-#ifndef VD_Z128_MAX_CIN
-#define VD_Z128_MAX_CIN 320
-#endif
-    if (Cin > VD_Z128_MAX_CIN) return false;
+    if (Cin > max_cin) return false;
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -556,13 +561,16 @@ bool conv_wino_z128_act_shape(int nfr, int H, int Cin, int Cout) {
 #endif
     static const bool off = getenv("VD_NO_CONV_ACT") != nullptr;       // A/B switch: the activation pass + the plain kernel
     static const int max_cout = getenv("VD_CONV_ACT_MAX_COUT") ? atoi(getenv("VD_CONV_ACT_MAX_COUT")) : 256;
-    return !off && Cout <= max_cout && conv_wino_z128_shape(nfr, H, Cin, Cout);
+    // (longer channel loops than the plain kernel takes -- the decoder's 384 .. 640 -> 128 | 256 convs, whose image the skip convolution writes --
+    // measured in the step, r05q: 320 | 384 | 640 -> 20.155 | 20.148 | 20.22 ms: what the image costs is what conv_wino_r64.hip's lead there is worth)
+    static const int max_cin = getenv("VD_CONV_ACT_MAX_CIN") ? atoi(getenv("VD_CONV_ACT_MAX_CIN")) : VD_Z128_MAX_CIN;
+    return !off && Cout <= max_cout && z128_shape(nfr, H, Cin, Cout, max_cin);
 }
 
 bool conv_wino_z128_act_supported(const IgemmArgs& a) {
     if (!(a.affA && a.affB && a.act == 1 && (a.src1 != nullptr || a.C0 == a.Cin) && a.C0 % 16 == 0 && a.C0 > 0)) return false;
-    IgemmArgs b = a; b.affA = b.affB = nullptr; b.act = 0; b.src1 = nullptr; b.C0 = a.Cin;     // the plain kernel's conditions on everything else
-    return conv_wino_z128_supported(b) && conv_wino_z128_act_shape(a.nfr_sel ? a.nfr_sel : a.nfr, a.Hs, a.Cin, a.Cout);
+    IgemmArgs b = a; b.affA = b.affB = nullptr; b.act = 0; b.src1 = nullptr; b.C0 = a.Cin;     // conv_wino_r64.hip's conditions on everything else
+    return conv_wino_r64_supported(b) && a.ups == 0 && !a.ups_phase && conv_wino_z128_act_shape(a.nfr_sel ? a.nfr_sel : a.nfr, a.Hs, a.Cin, a.Cout);
 }
 
 int launch_conv_wino_z128(const IgemmArgs& a, hipStream_t s) {
