@@ -1199,10 +1199,15 @@ int vd_engine::forward(const FwdIn& in, hipStream_t st, Arena& ar, const PrefixP
           // 1x1 GEMM over the 27 | 54 (cout, tap) columns (the generic kernel: GroupNorm affine + SiLU in its operand load), then
           // eps[cout][y][x] = bias + sum over the 9 taps of T at the neighbour the tap points to (out_gather_kernel)
           ProfScope ps(PC_OUT_CONV, 2.0 * Nrun * S * S * h.C * 27.0, 4.0 * Nrun * S * S * (h.C + 3.0), st);
-          IgemmArgs g = conv_args(h, nullptr, Nrun, 1, 1, 0);
-          g.w = W(p_outw) + (size_t)9 * oc * h.C; g.wsplit = 0; g.affA = A; g.affB = Bf; g.act = 1;
-          g.out = head_t; g.ldo = out_t_cols(oc); g.Cout = out_t_cols(oc);
-          rc = launch_igemm(g, st);
+          static const bool old_head = getenv("VD_HEAD_GENERIC") != nullptr;      // A/B switch: the generic fp32 kernel (rounds 4)
+          if (!old_head && head_gemm_supported(S * S, h.C, out_t_cols(oc))) {
+              rc = launch_head_gemm(h.p, A, Bf, W(p_outw) + (size_t)9 * oc * h.C, Nrun, S * S, h.C, out_t_cols(oc), head_t, st);
+          } else {
+              IgemmArgs g = conv_args(h, nullptr, Nrun, 1, 1, 0);
+              g.w = W(p_outw) + (size_t)9 * oc * h.C; g.wsplit = 0; g.affA = A; g.affB = Bf; g.act = 1;
+              g.out = head_t; g.ldo = out_t_cols(oc); g.Cout = out_t_cols(oc);
+              rc = launch_igemm(g, st);
+          }
           if (!rc) rc = launch_out_gather(head_t, W(p_outb), Nrun, S, S, out_t_cols(oc), oc, compact ? eps_c : in.eps, st); }
         if (rc) return rc;
         if (compact) {                                               // the other frames' eps: zeros (their samples stay finite; nobody reads them)

@@ -314,6 +314,79 @@ int launch_out_conv(const float* x, const float* affA, const float* affB, const 
 }
 
 // ------------------------------------------------------------------ output head as GEMM + gather (engine.hip: forward)
+// ------------------------------------------------------------------ the output head's GEMM (unet.py:744-749,838)
+// T[pixel][co * 9 + tap] = silu(h[pixel][:] * A[frame][:] + B[frame][:]) . w[co][:][tap]: the head's 3x3 conv (C -> 3 | 6 channels behind
+// GroupNorm + SiLU) as a 1x1 GEMM over its 27 | 54 (cout, tap) columns, followed by out_gather_kernel.  C is 128 and N is 32: no tile of
+// the general kernels fits (the generic fp32 kernel ran it at 1.4 TB/s, 185 us of the headline step for 268 MB).  Here: fp32 MFMA
+// 32x32x2 (exact fp32 products; the k order is free as long as A and B agree, so one float4 per lane feeds four MFMAs), the weights of a
+// column tile resident in registers, a block = 1024 pixels of one frame (its (A, B) in LDS), a wave = 8 tiles of 32 pixels with the next
+// tile's rows requested before the current one is multiplied.  Bound by the read of h.
+template <int NCT, int CMAX>
+__global__ __launch_bounds__(256, 2) void head_gemm_kernel(const float* __restrict__ h, const float* __restrict__ affA, const float* __restrict__ affB,
+                                                           const float* __restrict__ Wt, int HW, int C, float* __restrict__ T) {
+    constexpr int NI = CMAX / 8, LDT = 32 * NCT, TPW = 8;
+    __shared__ __attribute__((aligned(16))) float sab[2 * CMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 31, kh = lane >> 5;
+    const size_t pix_blk = (size_t)blockIdx.x * 1024;                 // 1024 pixels of ONE frame (HW % 1024 == 0)
+    const int n = (int)(pix_blk / HW);
+    for (int c = tid; c < C; c += 256) { sab[c] = affA[(size_t)n * C + c]; sab[CMAX + c] = affB[(size_t)n * C + c]; }
+    const int ni = C >> 3;
+    f32x4 w[NCT][NI];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            w[ct][i] = i < ni ? *reinterpret_cast<const f32x4*>(Wt + (size_t)(ct * 32 + lr) * C + 8 * i + 4 * kh) : f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const size_t pix0 = pix_blk + (size_t)wv * TPW * 32;
+    const float* src = h + (pix0 + lr) * C + 4 * kh;
+    f32x4 xa[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) xa[i] = i < ni ? *reinterpret_cast<const f32x4*>(src + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int it = 0; it < TPW; ++it) {
+        f32x4 xn[NI];
+        const float* nsrc = src + (size_t)(it + 1 < TPW ? it + 1 : it) * 32 * C;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xn[i] = i < ni ? *reinterpret_cast<const f32x4*>(nsrc + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x16 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i < ni) {
+                const f32x4 Aq = *reinterpret_cast<const f32x4*>(sab + 8 * i + 4 * kh), Bq = *reinterpret_cast<const f32x4*>(sab + CMAX + 8 * i + 4 * kh);
+                f32x4 v = xa[i] * Aq + Bq;
+                v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[e], w[ct][i][e], acc[ct], 0, 0, 0);
+            }
+        }
+        float* dst = T + (pix0 + (size_t)it * 32 + 4 * kh) * LDT + lr;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * LDT + ct * 32] = acc[ct][r];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xa[i] = xn[i];
+    }
+}
+
+// (32 columns: the 3-channel head; the 6-channel head of a learn_sigma network needs twice the weight registers and stays on the generic kernel)
+bool head_gemm_supported(int HW, int C, int ldt) { return HW % 1024 == 0 && C % 8 == 0 && C <= 128 && ldt == 32; }
+
+int launch_head_gemm(const float* h, const float* affA, const float* affB, const float* Wt, int nfr, int HW, int C, int ldt, float* T, hipStream_t s) {
+    VD_REQUIRE(head_gemm_supported(HW, C, ldt), "output head GEMM: whole 1024-pixel blocks of a frame, C <= 128, 32 columns");
+    const dim3 grid((unsigned)((size_t)nfr * HW / 1024));
+    hipLaunchKernelGGL((head_gemm_kernel<1, 128>), grid, dim3(256), 0, s, h, affA, affB, Wt, HW, C, T);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
 // T[pixel][co * 9 + tap] holds what tap `tap` of output channel co contributes FROM this pixel; output pixel (y, x) sums the entry of
 // tap (dy, dx) at pixel (y + dy - 1, x + dx - 1).  Block = 16 x 16 output pixels: the 18 x 18 halo of T rows is staged through LDS
 // with coalesced 16-byte loads (rows padded to an odd number of quads: lanes of a row walk different banks), then 9 * Cout LDS reads

@@ -302,6 +302,9 @@ int launch_frame_t(const int64_t* fidx, int B, int T, int center, float* tv, hip
 int launch_out_conv(const float* x, const float* affA, const float* affB, const float* w, const float* bias, int nfr,
                     int H, int W, int C, int Cout, float* out_nchw, hipStream_t s);
 
+// the head's first half as its own kernel: T[pixel][ldt] = silu(h * A + B) . Wt^T, Wt [ldt][C] fp32 (misc.hip)
+bool head_gemm_supported(int HW, int C, int ldt);
+int launch_head_gemm(const float* h, const float* affA, const float* affB, const float* Wt, int nfr, int HW, int C, int ldt, float* T, hipStream_t s);
 // the head's second half: out_nchw[n][co][y][x] = bias[co] + sum_tap T[n][y + dy][x + dx][co * 9 + tap] (zero outside the image); T [nfr][H][W][ldt]
 int launch_out_gather(const float* T, const float* bias, int nfr, int H, int W, int ldt, int Cout, float* out_nchw, hipStream_t s);
 
