@@ -76,6 +76,10 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #ifndef VD_R64_MIXHI
 #define VD_R64_MIXHI 0     // 1: the a1 piece by v_fma_mixlo/hi_f16 (scale + round in one instruction per value instead of v_ldexp_f32 x 2 +
 #endif                     // v_cvt_pk_f16_f32: 10.31 instead of 10.98 instructions per MFMA, same bits) -- measured 0 .. 5 % SLOWER per layer (r05b), off
+#ifndef VD_R64_REGSTAGE
+#define VD_R64_REGSTAGE 0  // 1: f16x3, the patch staged through registers (buffer_load_dwordx4 -> ds_write_b128) instead of LDS-DMA.  In conv_wino_z128.hip that
+#endif                     // is worth 8 % (r05s: 417 -> 385 us at 128 -> 128 @ 64^2); HERE it is 2 - 9 % SLOWER on every layer (r05t: class 14.42 -> 14.71 ms;
+                           // no spills, 11.02 instructions per MFMA against 10.98): this loop has no issue slots left for 12 more requests per chunk pair
 #ifndef VD_R64_ABL
 #define VD_R64_ABL 0       // timing-only builds of the main loop (results WRONG; tools/build_variant.sh): bit 0 no weight reloads, 1 no
 #endif                     // transform / split, 2 no patch requests, 3 no patch reads, 4 no MFMA -- never set in the product library
@@ -172,6 +176,21 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     auto x_dma = [&](int chunk) {
 #pragma unroll
         for (int e = 0; e < NX; ++e) x_dma_one(chunk, e);
+    };
+
+    // ---- register staging (F16 && VD_R64_REGSTAGE): patch p is requested into `stg` in group (p - 3, 1) position 0 and written to its buffer
+    // in group (p - 2, 0) before the position that may carry the barrier; same LDS image (the thread's slots e * 256 + tid, the quad swizzle on
+    // the source side), so everything that reads a patch is unchanged.  A request past the last chunk goes through an empty descriptor
+    // into the spare buffer, as the DMA does.
+    constexpr bool RS = F16 && VD_R64_REGSTAGE;
+    f32x4 stg[RS ? NX : 1];
+    auto s_fetch = [&](int chunk, int e) -> f32x4 {
+        const int bytes = chunk < nchunk ? a.nfr * a.Hs * a.Ws * a.Cin * 4 : 0;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, bytes, 0x00020000);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xo[e], chunk * 64, 0));
+    };
+    auto s_store = [&](int chunk, int e, f32x4 v) {
+        *reinterpret_cast<f32x4*>(lds + (chunk < nchunk ? (chunk & (NB - 1)) : NB) * XBUF + e * 4096 + tid * 16) = v;
     };
 
     // ---- transform in the fragment layout.  Lane (tile lr of the M-tile, k-half lh): tile column lr & 7, tile row 4m + (lr >> 3);
@@ -341,10 +360,26 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     R64_STAMP(0); R64_STAMP(14);
     // ---- prologue: three patches and the weights of chunk 0 requested; group (0, 0) transformed whole, position 0 split,
     // column 0 of group (0, 1) in flight -- the state the loop expects at the top of a group
+    if constexpr (RS) {
+        f32x4 s0[NX], s1[NX];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) x_dma(c);
+        for (int e = 0; e < NX; ++e) s0[e] = s_fetch(0, e);
 #pragma unroll
-    for (int li = 0; li < NP - 1; ++li) { b_load(0, JLa[li], 0); b_load(0, JLa[li], 1); }
+        for (int e = 0; e < NX; ++e) s1[e] = s_fetch(1, e);
+#pragma unroll
+        for (int li = 0; li < NP - 1; ++li) { b_load(0, JLa[li], 0); b_load(0, JLa[li], 1); }
+#pragma unroll
+        for (int e = 0; e < NX; ++e) s_store(0, e, s0[e]);
+#pragma unroll
+        for (int e = 0; e < NX; ++e) s_store(1, e, s1[e]);
+#pragma unroll
+        for (int e = 0; e < NX; ++e) stg[e] = s_fetch(2, e);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x_dma(c);
+#pragma unroll
+        for (int li = 0; li < NP - 1; ++li) { b_load(0, JLa[li], 0); b_load(0, JLa[li], 1); }
+    }
     // the 256 accumulator writes (1 k cycles of issue) go under the wait for the first patch instead of behind it
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -359,7 +394,8 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     __builtin_amdgcn_sched_barrier(0);
     // patch 0 has landed in every wave; patches 1, 2 (first read behind the loop's first barrier, which waits for them: 2 * NX requests)
     // and the (NP - 1) * 6 (4: two loads per fragment) weight loads may be in flight
-    {
+    if constexpr (RS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // patches 0, 1 are ds_writes; the loads in flight land in registers
+    else {
         constexpr int W = 2 * NX + (NP - 1) * (B2R ? 4 : 6);
         static_assert(W == 20 || W == 24 || W == 28 || W == 30 || W == 34, "wait count of the prologue");
         if constexpr (W == 20) asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
@@ -423,11 +459,22 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                     const int q = k >> 1, n = k & 1;
                     if (m == 0 && li == NP - 1 && k == 0 && cpar == 0) {
                         // the 18 (12: two loads per fragment) youngest requests are weight loads
-                        if constexpr (B2R) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        if constexpr (RS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        else if constexpr (B2R) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     }
                     // the patch requests of the chunk pair, one per slot
-                    if (cpar == 1 && !(VD_R64_ABL & 4)) {
+                    if constexpr (RS) {
+                        // group (chunk, 0), positions NP - 3 and NP - 2 (in front of the position that may carry the barrier): the writes of patch
+                        // chunk + 2, in slots 1, 3, 5 (and 0 for the eight slots of the 8 x 8 form); group (chunk, 1), position 0 (no weight loads
+                        // there): the requests of patch chunk + 3
+                        if (m == 0 && (li == NP - 3 || li == NP - 2)) {
+                            const int base = (li - (NP - 3)) * (NX / 2);
+                            if (NX == 6) { if (k & 1) s_store(chunk + 2, base + (k >> 1), stg[base + (k >> 1)]); }
+                            else { const int q = k == 0 ? 0 : (k & 1) ? 1 + (k >> 1) : -1; if (q >= 0) s_store(chunk + 2, base + q, stg[base + q]); }
+                        }
+                        if (m == 1 && li == 0) { stg[k] = s_fetch(chunk + 3, k); if (NX == 8 && k >= 4) stg[k + 2] = s_fetch(chunk + 3, k + 2); }
+                    } else if (cpar == 1 && !(VD_R64_ABL & 4)) {
                         if constexpr (F16) {
                             const int ord = m == 0 ? (li - 1) * 6 + k : (li == 0 ? (NP - 1) * 6 + k : 99);      // slots behind position 0 of group (c, 0)
                             if ((m == 1 || li > 0) && ord < 2 * NX) x_dma_one(chunk + 2 + ord / NX, ord % NX);

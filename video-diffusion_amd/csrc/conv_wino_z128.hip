@@ -165,6 +165,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     // slot e in four parts of 7 vector instructions (what hides beside an MFMA that carries nothing else), consecutive instructions on
     // different elements; the arithmetic of norm.hip's pass to the bit: fma(x, A, B), silu(v) = v * rcp(1 + exp2(-log2(e) v))
     auto p_act_on = [&](f32x4 (&stg)[ACT ? NX : 1], int e, int part) {
+#ifdef VD_Z128_REG_PLAIN          // timing-only build: register staging WITHOUT the activation (what the staging method alone is worth)
+        return;
+#endif
         if constexpr (ACT) {
             if (part == 0)
                 asm("v_fma_f32 %0, %0, %4, %8\n\tv_fma_f32 %1, %1, %5, %9\n\tv_fma_f32 %2, %2, %6, %10\n\tv_fma_f32 %3, %3, %7, %11\n\t"
