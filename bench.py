@@ -552,6 +552,10 @@ def main():
                             alg_mb_per_launch=round(c["mb"] / c["launches"], 2),
                             frac_note="achieved = ALGORITHMIC direct-form fp32 FLOPs / time; the share of the matrix pipe "
                                       "kept busy is mfma_executed_frac")
+            if name == "conv3x3_wino_z128_kernel" and math == "f16x3":
+                roofline["also_does"] = ("since round 5 this kernel applies the GroupNorm(+FiLM) affine + SiLU of its input in its patch staging (16 of its 16 launches "
+                                         "at the headline): its launches take ~7 % longer for the same algorithmic FLOPs, and 13 activation passes + 3 skip-conv "
+                                         "images of the step are gone (DESIGN.md 4; kernel_classes: affine_act_kernel)")
             if name.startswith("conv3x3_wino"):
                 # `achieved` counts the ALGORITHMIC flops of a direct fp32 3x3 convolution (2*M*Cout*Cin*9).  Winograd
                 # F(2x2,3x3) executes 16/36 of the multiplications (24/36 with the folded column transform); the split kernel spends
@@ -609,8 +613,10 @@ def main():
                       "VD_MATH=f16x3 (default): fp32 tensors and fp32 accumulation throughout; in the matrix products (3x3 convs as "
                       "Winograd F(2x2,3x3), linear layers, 1x1 and stride-2 convs) every fp32 operand is carried as two fp16 pieces "
                       "(22 significand bits, exact power-of-two scaling) and a product is three piece products on the f16 MFMA; error "
-                      "against fp64 held to the fp32-MFMA kernel's (max <= 1.5x, mean <= 1.25x asserted in tests/test_gpu_ops.py; measured <= 1.06x / 1.02x, "
-                      "profiles/r04_split_accuracy.json); the exact-split and fp32-MFMA numbers of the same run: bf16x6_exact_split, fp32_mfma_only",
+                      "against fp64 held to the fp32-MFMA kernel's (max <= 1.5x, mean <= 1.25x asserted in tests/test_gpu_ops.py and, on hostile operands, "
+                      "tests/test_gpu_hostile.py; measured <= 1.06x / 1.02x, profiles/r04_split_accuracy.json, r05_hostile_accuracy.json); usable operand range "
+                      "|x| < 2^15, beyond it NaN + vd_device_errors bit 1 (FloatingPointError); the exact-split and fp32-MFMA numbers of the same run: "
+                      "bf16x6_exact_split, fp32_mfma_only; end-to-end margins: parity_margin",
         "sec_per_clip_batch": round(nts * elapsed / args.steps, 2),
         "lib_source_sha": __import__("video_diffusion_amd")._lib.lib().vd_source_sha().decode(),
         "config": {"workload": workload, "batch_per_gpu": B, "frames": T, "image_size": S, "respaced_steps": nts,
