@@ -85,6 +85,17 @@ def main():
                 torch.cuda.synchronize()
                 tms.append(e0.elapsed_time(e1) / args.reps * 1e3)
             print(f"{Cin:5d} -> {Cout:4d} @ {H:2d} x{cnt:2d}: plain conv {tms[0]:7.1f} us | activating conv {tms[1]:7.1f} us | affine_act + plain conv {tms[2]:7.1f} us", flush=True)
+            if hasattr(L, "vd_debug_z128_stamps"):
+                for nm, fn in (("plain", run), ("activating", run_act)):
+                    fn(); torch.cuda.synchronize()
+                    st = (ctypes.c_ulonglong * 16)()
+                    L.vd_debug_z128_stamps.restype = ctypes.c_int
+                    L.vd_debug_z128_stamps.argtypes = [ctypes.c_void_p]
+                    assert L.vd_debug_z128_stamps(st) == 0
+                    t = list(st)
+                    ep = " | ".join(f"n{n}: Z {t[3+2*n]-(t[2] if n == 0 else t[2+2*n])}, rest {t[4+2*n]-t[3+2*n]}" for n in range(4))
+                    print(f"      {nm}: item of block 7 (cycles): prologue {t[1]-t[0]}, loop {t[2]-t[1]} = {(t[2]-t[1]) / (Cin // 16):.0f}/chunk, output transform "
+                          f"{t[10]-t[2]} [{ep}]; {(t[10]-t[0]) / max(t[15]-t[14], 1) * 0.1:.2f} GHz", flush=True)
             continue
         for _ in range(3):
             run()

@@ -19,6 +19,11 @@
 
 #include "vd_common.h"
 
+#ifndef VD_WINO_RES_BRANCH
+#define VD_WINO_RES_BRANCH 0   // 1: no residual requests where there is no residual (a uniform branch).  Measured r05u: step 20.01 -> 20.14 ms: the conditional requests
+                               // make hipcc wait for everything in flight behind them; the 32 requests through an empty descriptor are cheaper
+#endif
+
 namespace vd {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -529,6 +534,7 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     const int Ho = PH ? 2 * Hl : Hl, Wo = PH ? 2 * Wl : Wl;
     const int obytes = a.nfr * Ho * Wo * a.ldo * 4;
     const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)ks * (obytes >> 2), 0, obytes, 0x00020000);
+    const bool has_res = a.res != nullptr;                            // (uniform: a convolution without a residual issues none of the 32 requests per cout tile)
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
     const float sgn = p ? -1.f : 1.f;
     float* Zs = smem;
@@ -562,7 +568,7 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], nso, 0));
+            for (int r = 0; r < 16; ++r) rv[m][r] = VD_WINO_RES_BRANCH && !has_res ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], nso, 0));
             // Z = M A: columns (1, 1, 1, 0) and (0, 1, -1, -1); the column the sub-pixel form never computed is zero
             const f32x16 z0 = JS == 0 ? acc[m][1][n] + acc[m][2][n] : acc[m][0][n] + acc[m][1][n] + acc[m][2][n];
             const f32x16 z1 = JS == 3 ? acc[m][1][n] - acc[m][2][n] : acc[m][1][n] - acc[m][2][n] - acc[m][3][n];

@@ -24,6 +24,11 @@
 
 #include "vd_common.h"
 
+#ifndef VD_WINO_RES_BRANCH
+#define VD_WINO_RES_BRANCH 0   // 1: no residual requests where there is no residual (a uniform branch).  Measured r05u: step 20.01 -> 20.14 ms: the conditional requests
+                               // make hipcc wait for everything in flight behind them; the 32 requests through an empty descriptor are cheaper
+#endif
+
 namespace vd {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -162,31 +167,37 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
             Bq = *reinterpret_cast<const f32x4*>(sab + a.Cin + pc);
         }
     };
-    // slot e in four parts of 7 vector instructions (what hides beside an MFMA that carries nothing else), consecutive instructions on
-    // different elements; the arithmetic of norm.hip's pass to the bit: fma(x, A, B), silu(v) = v * rcp(1 + exp2(-log2(e) v))
+    // slot e in EIGHT parts of 2 - 4 vector instructions, consecutive instructions on different elements; the arithmetic of norm.hip's pass to
+    // the bit: fma(x, A, B), silu(v) = v * rcp(1 + exp2(-log2(e) v)).  v_exp_f32 / v_rcp_f32 run at a quarter of the vector rate (16 cycles
+    // per wave instruction): the first version -- four parts of 7 with two of them each -- put 52 cycles of vector work into a 32-cycle MFMA
+    // slot (cycle stamps: 7.2 k cycles per chunk against 5.7 k of the plain kernel); eight parts over the odd slots of positions 1 AND 2
+    // keep a part at <= 2 transcendental + 2 plain instructions.
     auto p_act_on = [&](f32x4 (&stg)[ACT ? NX : 1], int e, int part) {
 #ifdef VD_Z128_REG_PLAIN          // timing-only build: register staging WITHOUT the activation (what the staging method alone is worth)
         return;
 #endif
         if constexpr (ACT) {
             if (part == 0)
-                asm("v_fma_f32 %0, %0, %4, %8\n\tv_fma_f32 %1, %1, %5, %9\n\tv_fma_f32 %2, %2, %6, %10\n\tv_fma_f32 %3, %3, %7, %11\n\t"
-                    "v_cndmask_b32_e64 %0, 0, %0, %12\n\tv_cndmask_b32_e64 %1, 0, %1, %12\n\tv_cndmask_b32_e64 %2, 0, %2, %12"
+                asm("v_fma_f32 %0, %0, %4, %8\n\tv_fma_f32 %1, %1, %5, %9\n\tv_fma_f32 %2, %2, %6, %10\n\tv_fma_f32 %3, %3, %7, %11"
                     : "+v"(stg[e][0]), "+v"(stg[e][1]), "+v"(stg[e][2]), "+v"(stg[e][3])
-                    : "v"(Aq[0]), "v"(Aq[1]), "v"(Aq[2]), "v"(Aq[3]), "v"(Bq[0]), "v"(Bq[1]), "v"(Bq[2]), "v"(Bq[3]), "s"(inm[e]));
+                    : "v"(Aq[0]), "v"(Aq[1]), "v"(Aq[2]), "v"(Aq[3]), "v"(Bq[0]), "v"(Bq[1]), "v"(Bq[2]), "v"(Bq[3]));
             else if (part == 1)
-                asm("v_cndmask_b32_e64 %3, 0, %3, %8\n\tv_mul_f32 %4, 0xbfb8aa3b, %0\n\tv_mul_f32 %5, 0xbfb8aa3b, %1\n\tv_mul_f32 %6, 0xbfb8aa3b, %2\n\t"
-                    "v_mul_f32 %7, 0xbfb8aa3b, %3\n\tv_exp_f32 %4, %4\n\tv_exp_f32 %5, %5"
-                    : "+v"(stg[e][0]), "+v"(stg[e][1]), "+v"(stg[e][2]), "+v"(stg[e][3]), "=&v"(tq[0]), "=&v"(tq[1]), "=&v"(tq[2]), "=&v"(tq[3])
-                    : "s"(inm[e]));
+                asm("v_cndmask_b32_e64 %0, 0, %0, %4\n\tv_cndmask_b32_e64 %1, 0, %1, %4\n\tv_cndmask_b32_e64 %2, 0, %2, %4\n\tv_cndmask_b32_e64 %3, 0, %3, %4"
+                    : "+v"(stg[e][0]), "+v"(stg[e][1]), "+v"(stg[e][2]), "+v"(stg[e][3]) : "s"(inm[e]));
             else if (part == 2)
-                asm("v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1\n\tv_rcp_f32 %0, %0\n\t"
-                    "v_add_f32 %2, 1.0, %2\n\tv_add_f32 %3, 1.0, %3"
-                    : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]));
+                asm("v_mul_f32 %0, 0xbfb8aa3b, %4\n\tv_mul_f32 %1, 0xbfb8aa3b, %5\n\tv_mul_f32 %2, 0xbfb8aa3b, %6\n\tv_mul_f32 %3, 0xbfb8aa3b, %7"
+                    : "=&v"(tq[0]), "=&v"(tq[1]), "=&v"(tq[2]), "=&v"(tq[3]) : "v"(stg[e][0]), "v"(stg[e][1]), "v"(stg[e][2]), "v"(stg[e][3]));
+            else if (part == 3)
+                asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(tq[0]), "+v"(tq[1]));
+            else if (part == 4)
+                asm("v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]));
+            else if (part == 5)
+                asm("v_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\tv_add_f32 %2, 1.0, %2\n\tv_add_f32 %3, 1.0, %3" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]));
+            else if (part == 6)
+                asm("v_rcp_f32 %4, %4\n\tv_rcp_f32 %5, %5\n\tv_mul_f32 %0, %0, %2\n\tv_mul_f32 %1, %1, %3"
+                    : "+v"(stg[e][0]), "+v"(stg[e][1]), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]));
             else
-                asm("v_rcp_f32 %5, %5\n\tv_rcp_f32 %6, %6\n\tv_rcp_f32 %7, %7\n\tv_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %5\n\t"
-                    "v_mul_f32 %2, %2, %6\n\tv_mul_f32 %3, %3, %7"
-                    : "+v"(stg[e][0]), "+v"(stg[e][1]), "+v"(stg[e][2]), "+v"(stg[e][3]), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]));
+                asm("v_mul_f32 %0, %0, %2\n\tv_mul_f32 %1, %1, %3" : "+v"(stg[e][2]), "+v"(stg[e][3]) : "v"(tq[2]), "v"(tq[3]));
         }
     };
     auto p_act = [&](int e, int part) { p_act_on(stg, e, part); };
@@ -324,14 +335,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
 #pragma unroll
         for (int e = 0; e < NX; ++e) {
 #pragma unroll
-            for (int part = 0; part < 4; ++part) p_act(e, part);
+            for (int part = 0; part < 8; ++part) p_act(e, part);
             p_store(0, e);
         }
         p_coef(1);
 #pragma unroll
         for (int e = 0; e < NX; ++e) {
 #pragma unroll
-            for (int part = 0; part < 4; ++part) p_act_on(stg1, e, part);
+            for (int part = 0; part < 8; ++part) p_act_on(stg1, e, part);
             *reinterpret_cast<f32x4*>(lds + (1 < nchunk ? 1 : NB) * XBUF + ldo[e]) = stg1[e];
         }
 #pragma unroll
@@ -417,12 +428,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
                                 else if (vs >= 3) frag_part(nxt, jn, (vs - 3) >> 1, 3);
                             } else if (!ACT && cpar == 1 && (j == 1 || j == 2) && (s & 7) == 1) x_dma_one(chunk + 1 + j, s >> 3);
                             if constexpr (ACT) {
-                                // position 1: (A, B) of patch chunk + 2; position 2, odd slots: its 24 elements, one part of a slot e each, the store
-                                // behind the last part; position 3: the six loads of patch chunk + 3 into the registers just freed
-                                if (j == 1 && s == 1) p_coef(chunk + 2);
-                                if (j == 2 && (s & 1)) {
-                                    p_act(s >> 3, (s >> 1) & 3);
-                                    if (((s >> 1) & 3) == 3) p_store(chunk + 2, s >> 3);
+                                // end of position 0: (A, B) of patch chunk + 2; positions 1 and 2, odd slots: its 24 elements, one part of a slot e each, the
+                                // store behind the last part; position 3: the six loads of patch chunk + 3 into the registers just freed
+                                if (j == 0 && s == 23) p_coef(chunk + 2);
+                                if ((j == 1 || j == 2) && (s & 1)) {
+                                    const int u = (j - 1) * 24 + (s >> 1);             // 48 parts: slot e = u / 8, part u % 8
+                                    p_act(u >> 3, u & 7);
+                                    if ((u & 7) == 7) p_store(chunk + 2, u >> 3);
                                 }
                                 if (j == 3 && s >= 17 && s < 23) p_load(chunk + 3, s - 17);
                             }
@@ -443,6 +455,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     const int p = wi >> 1, q = wi & 1;
     const int obytes = a.nfr * Hl * Wl * a.ldo * 4;
     const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
+    const bool has_res = a.res != nullptr;                            // (uniform: a convolution without a residual issues none of the 32 requests per cout tile)
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
     const float sgn = p ? -1.f : 1.f;
     float* Zs = smem;
@@ -467,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], nso, 0));
+            for (int r = 0; r < 16; ++r) rv[m][r] = VD_WINO_RES_BRANCH && !has_res ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], nso, 0));
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 *reinterpret_cast<f32x4*>(Zs + ((((wi * 2 + 0) * 2 + m) * 4 + c4) * 64 + lane) * 4) =
