@@ -49,7 +49,16 @@ def main():
         ms = timeit(lambda: _lib.check(L.vd_op_linear_split(_lib.ptr(a), M, K, _lib.ptr(ws), _lib.ptr(b), _lib.ptr(r), 0, _lib.ptr(out), N,
                                                             _lib.current_stream())), args.reps)
         tot += ms * cnt
-        print(f"lin  M={M:7d} K={K:5d} N={N:5d}{' res' if res else '    '} x{cnt:2d} {ms * 1e3:8.1f} us {2.0 * M * K * N / ms / 1e9:7.1f} TFLOP/s", flush=True)
+        extra = ""
+        if hasattr(L, "vd_debug_gs_stamps"):
+            import ctypes
+            st = (ctypes.c_ulonglong * 8)()
+            L.vd_debug_gs_stamps.restype = ctypes.c_int
+            L.vd_debug_gs_stamps.argtypes = [ctypes.c_void_p]
+            assert L.vd_debug_gs_stamps(st) == 0
+            t = list(st)
+            extra = f"   one block (us at the 100 MHz clock): prologue {(t[1]-t[0]) / 100:.2f}, K loop {(t[2]-t[1]) / 100:.2f}, epilogue to stores acknowledged {(t[3]-t[2]) / 100:.2f}"
+        print(f"lin  M={M:7d} K={K:5d} N={N:5d}{' res' if res else '    '} x{cnt:2d} {ms * 1e3:8.1f} us {2.0 * M * K * N / ms / 1e9:7.1f} TFLOP/s{extra}", flush=True)
     for C, Co, H in CONV2:
         nfr = 128
         x = torch.rand(nfr, H, H, C, device="cuda") - 0.5

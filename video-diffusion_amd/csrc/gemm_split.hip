@@ -38,6 +38,9 @@ __device__ __forceinline__ f32x16 mfma_piece(u32x4 a, u32x4 b, f32x16 c) {
 #ifndef VD_GS_PF3
 #define VD_GS_PF3 1        // 0: the A operand one chunk ahead for every tile (A/B)
 #endif
+#ifndef VD_GS_PF3_ALL
+#define VD_GS_PF3_ALL 0    // 1: three chunks of the A operand in flight for the 128-row tiles too (A/B)
+#endif
 #ifndef VD_GS_RING6
 #define VD_GS_RING6 1      // 0: three weight slots for the 64x64 tile too (A/B)
 #endif
@@ -52,6 +55,16 @@ __device__ __forceinline__ f32x16 mfma_piece(u32x4 a, u32x4 b, f32x16 c) {
 #endif
 #ifndef VD_GS_SKIP
 #define VD_GS_SKIP 0       // kernel-experiment builds: bit 0 no weight loads, 1 no A staging, 2 no split VALU (timing only)
+#endif
+#ifdef VD_GS_TIMING
+// cycle stamps of ONE block (the middle row tile, column tile 0; with two blocks per CU the shader clock counts both: use the 100 MHz clock):
+// 0 start, 1 prologue done (first A tile in LDS), 2 K loop done, 3 stores issued; 4 / 5: the 100 MHz clock at 0 / 3
+__device__ unsigned long long g_gs_stamp[8];
+#define GS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) {                        \
+        __builtin_amdgcn_sched_barrier(0); g_gs_stamp[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+extern "C" int vd_debug_gs_stamps(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gs_stamp), sizeof(g_gs_stamp)); }
+#else
+#define GS_STAMP(i)
 #endif
 constexpr int SROW = 80;                   // bytes per LDS row of one plane: 32 bf16 + 16 bytes of padding
 
@@ -91,11 +104,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     // A-operand prefetch distance in chunks.  A chunk of a 64-row tile is 12 .. 24 MFMAs (0.2 .. 0.4 us): one chunk ahead, the
     // split + store of the next chunk waits a full memory round trip every chunk, and a small-M launch (a B = 1 shard: 60 of
     // them per step) costs ~1 us per chunk whatever its size.  The small tiles have the registers for three chunks in flight.
-    constexpr int PF = (BM == 64 && VD_GS_PF3) ? 3 : 1;      // (three chunks in flight for the HBM-bound 128x128 SIDE launches too: measured, no gain -- r04i)
+    constexpr int PF = ((BM == 64 && VD_GS_PF3) || VD_GS_PF3_ALL) ? 3 : 1;      // (three chunks in flight for the HBM-bound 128x128 SIDE launches too: measured, no gain -- r04i)
     constexpr int NPL = F16 ? 2 : 3;                                      // planes of the A tile
     constexpr int PLANE = BM * SROW, ABUF = NPL * PLANE;                  // bytes
     extern __shared__ __attribute__((aligned(16))) char smem_c[];         // [2][3 planes][BM][SROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    GS_STAMP(0);
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
     // block -> tile.  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), and each XCD has its own L2: with the
@@ -296,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
     a_store(smem_c, 0);
     __syncthreads();
     a_frags(0, smem_c, 0);
+    GS_STAMP(1);
 
     // k-steps in a ring of 3 weight slots (two steps ahead; 2 slots, one step ahead, for the 128x192 tile) and 2 fragment slots (one step ahead); the six piece
     // products of a tile go into its accumulator back to back, small terms first
@@ -396,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         }
     }
 
+    GS_STAMP(2);
     if constexpr (F16) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -442,6 +458,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), osrc, vbe + srow, 0, 0);
             }
         }
+#ifdef VD_GS_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    GS_STAMP(3);
 }
 
 
