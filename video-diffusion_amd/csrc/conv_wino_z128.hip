@@ -555,11 +555,16 @@ static bool z128_shape(int nfr, int H, int Cin, int Cout, int max_cin) {
     // us per launch, this kernel | conv_wino_r64.hip (r04q, after the latter stopped loading the third weight piece):
     // 128 -> 128 @ 64^2 411 - 428 | 432 - 451, 256 -> 256 @ 32^2 344 - 356 | 361 - 370, 640 -> 256 @ 32^2 805 | 758 - 774
     if (Cin > max_cin) return false;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    // CU count of the CURRENT device (cached per device id: a process that drives several devices must not inherit the first one's)
+    static int cu_of[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cu_of[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cu_of[dev] = n;
+    }
+    const int cus = cu_of[dev];
     const int items = (H / 16) * (H / 16) * nfr * (Cout / 128);
     return z128_fill(items, cus) >= 0.95 * z128_fill(2 * items, cus);
 }
