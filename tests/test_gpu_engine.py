@@ -1403,3 +1403,31 @@ def test_return_attn_weights_with_denoised_fn_matches_reference_golden():
     assert len(pm["attn"]["temporal"]) == int(rec["n_temporal"])
     out = diff.p_sample(model, x, t, clip_denoised=True, denoised_fn=_denoised_fn, model_kwargs=kwargs_of(c), return_attn_weights=True)
     assert out["attn"] is not None and len(out["attn"]["spatial"]) == int(rec["n_spatial"])
+
+
+@pytest.mark.parametrize("shrink", [1e-3, 1e-5])
+def test_use_gradient_method_with_tiny_gradients_vs_oracle_autograd(shrink):
+    """The guidance gradient when d loss / d eps is SMALL THROUGHOUT (the backward pass runs in the forward's f16x3 arithmetic, whose
+    operands below 2^-14 are carried to an absolute 2^-37 instead of a relative 2^-22).  A fractional observation mask scales the loss by its
+    square (gaussian_diffusion.py:350-364: ((x_{t-1} - x_t_minus_1) * obs_mask)^2; the network itself sees every frame as latent), i.e. the whole
+    gradient by 1e-6 / 1e-10.  The engine multiplies d loss / d eps by a power of two before the backward-data pass and divides behind it
+    (backward.hip: launch_grad_rescale -- the pass is linear), so the RELATIVE accuracy must be that of an ordinary gradient."""
+    B, T, n_obs, mc, S = 2, 5, 2, 64, 32
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=8, image_size=S, num_channels=mc, num_res_blocks=1, rp_alpha=8,
+                                                              rp_beta=8, rp_gamma=8, timestep_respacing="ddim50")}
+    model, diff, ora = _oracle(cfg)
+    c = _rand_window(B, T, S, n_obs, seed=700 + B * 10 + T)
+    gen = torch.Generator().manual_seed(5)
+    n1, n2 = torch.randn(c["x"].shape, generator=gen), torch.randn(c["x"].shape, generator=gen)
+    xtm1 = c["x0"] + 0.2 * torch.randn(c["x"].shape, generator=gen) * c["obs_mask"]
+    t = torch.tensor([30] * B)
+    small = dict(c, obs_mask=c["obs_mask"] * shrink)
+    kwo = dict(x0=c["x0"], obs_mask=small["obs_mask"], latent_mask=c["latent_mask"], kinda_marg_mask=c["kinda_marg_mask"],
+               frame_indices=c["frame_indices"], x_t_minus_1=xtm1)
+    want = ora.guided_p_sample(c["x"], t, kwo, n1, n2)
+    kw = dict(kwargs_of(small), x_t_minus_1=xtm1.cuda())
+    got = diff._guided(model, c["x"].cuda(), t.cuda(), True, kw, noise2=n2, want_sample=True, _noise=n1)
+    scale = float(want["grad"].abs().max())
+    assert 0 < scale < 1e-2 * shrink                                # a gradient that is tiny throughout
+    close(got["grad"].cpu(), want["grad"], atol=2e-4 * scale, rtol=1e-3)
+    assert torch.isfinite(got["sample"]).all()

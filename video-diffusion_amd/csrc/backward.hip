@@ -610,9 +610,41 @@ int launch_guided_grad(const GuidedArgs& a, hipStream_t s) {
     return 0;
 }
 
-// g = dxd + dx_net;  mean' = mean - 10 * alpha_t * g / 2  (alpha_t = 1 - beta_t);  sample = mean' + nz*sigma*z2
+// ---- the backward pass runs on a power-of-two multiple of the loss gradient.  The backward-data pass is LINEAR in d loss / d eps, and its matrix
+// products run in the forward's arithmetic (f16x3: an operand below 2^-14 is carried to an absolute 2^-37, not a relative 2^-22 -- tensors that are
+// small THROUGHOUT are the one case the split does not serve, and gradients are such tensors: d loss / d eps ~ 1e-3 .. 1e-8 by the timestep).  So
+// d eps is multiplied by s = 2^k with max |d eps * s| in [1, 2) before the pass and the result by 1 / s behind it: exact (powers of two), and every
+// operand of the pass sits where the split is at its full 22 bits.  gs[0] = s, gs[1] = 1 / s, gs[2] = the bits of max |d eps| (zeroed by the caller).
+__global__ __launch_bounds__(256) void grad_absmax_kernel(const float* __restrict__ g, size_t n, unsigned* __restrict__ mx) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(g[i]));     // (fmaxf drops a NaN: it stays in g)
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(mx, __builtin_bit_cast(unsigned, m));           // non-negative floats order like their bit patterns
+}
+__global__ __launch_bounds__(256) void grad_scale_kernel(float* __restrict__ g, size_t n, float* __restrict__ gs) {
+    const float m = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(gs)[2]);
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+        int ex;
+        (void)frexpf(m, &ex);                                           // m = f * 2^ex, f in [0.5, 1)
+        s = ldexpf(1.f, max(-100, min(100, 1 - ex)));               // max |d eps| * s in [1, 2): gradients inside the network may grow 2^14-fold before fp16's range ends
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { gs[0] = s; gs[1] = 1.f / s; }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] *= s;
+}
+int launch_grad_rescale(float* deps, size_t n, float* gs, hipStream_t st) {
+    VD_HIP(hipMemsetAsync(gs, 0, 4 * sizeof(float), st));
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(grad_absmax_kernel, dim3(grid), dim3(256), 0, st, deps, n, reinterpret_cast<unsigned*>(gs) + 2);
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(grid), dim3(256), 0, st, deps, n, gs);
+    VD_HIP(hipGetLastError());
+    return 0;
+}
+
+// g = dxd + dx_net / s;  mean' = mean - 10 * alpha_t * g / 2  (alpha_t = 1 - beta_t);  sample = mean' + nz*sigma*z2
 __global__ __launch_bounds__(256) void guided_final_kernel(GuidedArgs a, const float* __restrict__ dx_net, const float* __restrict__ noise2,
                                                            float* __restrict__ grad, float* __restrict__ mean_out, float* __restrict__ sample) {
+    const float inv_s = a.gscale ? a.gscale[1] : 1.f;
     const size_t total = (size_t)a.B * a.per;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int b = (int)(i / a.per);
@@ -620,7 +652,7 @@ __global__ __launch_bounds__(256) void guided_final_kernel(GuidedArgs a, const f
         const int NT = a.num_timesteps;
         if (tl < 0 || tl >= NT) { if (mean_out) mean_out[i] = __builtin_nanf(""); if (sample) sample[i] = __builtin_nanf(""); continue; }
         const float* tb = a.tab + (int)tl;
-        const float g = a.dxd[i] + dx_net[i];
+        const float g = a.dxd[i] + dx_net[i] * inv_s;
         const float m = a.mean[i] - 10.0f * tb[TAB_ALPHA * NT] * g / 2.0f;
         if (grad) grad[i] = g;
         if (mean_out) mean_out[i] = m;

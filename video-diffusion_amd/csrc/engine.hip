@@ -2220,6 +2220,9 @@ int vd_guided_step(vd_engine* e, int B, int T, const float* x, const float* obs,
                       deps, dxd, mean0, xstart ? xstart : xs0};
         ga.err = e->d_err;
         rc = launch_guided_grad(ga, st);
+        static const bool no_gs = getenv("VD_NO_GRAD_SCALE") != nullptr;      // (A/B switch: the un-scaled backward pass of rounds 3-4)
+        float* gs = lat_net + 256;                                            // 4 floats of the tail's spare kilobyte
+        if (!rc && !no_gs) { rc = launch_grad_rescale(deps, tot, gs, st); ga.gscale = gs; }
         if (!rc) rc = e->backward(fi, deps, dxn, st, ar);
         if (!rc) rc = launch_guided_final(ga, dxn, noise2, grad, mean, sample, st);
     }

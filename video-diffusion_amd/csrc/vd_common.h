@@ -377,7 +377,9 @@ struct GuidedArgs {
     float* deps; float* dxd;            // d loss / d eps, and the direct part of d loss / d x
     float* mean; float* xstart;         // the unguided posterior mean and the x_0 prediction
     int* err = nullptr;                 // sticky error word (bit 1: eps not finite)
+    const float* gscale = nullptr;      // {s, 1 / s}: the backward pass ran on s * d loss / d eps (backward.hip: launch_grad_rescale); null: 1
 };
+int launch_grad_rescale(float* deps, size_t n, float* gs, hipStream_t st);
 int launch_guided_grad(const GuidedArgs& a, hipStream_t s);
 int launch_guided_final(const GuidedArgs& a, const float* dx_net, const float* noise2, float* grad, float* mean_out, float* sample,
                         hipStream_t s);
