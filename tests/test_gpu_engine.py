@@ -1,6 +1,7 @@
 """GPU: the whole HIP denoise step through the reference-shaped Python boundary, against
 (1) golden vectors minted from the imported reference and (2) the CPU oracle on seeded inputs."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -1431,3 +1432,20 @@ def test_use_gradient_method_with_tiny_gradients_vs_oracle_autograd(shrink):
     assert 0 < scale < 1e-2 * shrink                                # a gradient that is tiny throughout
     close(got["grad"].cpu(), want["grad"], atol=2e-4 * scale, rtol=1e-3)
     assert torch.isfinite(got["sample"]).all()
+
+
+def test_round5_fusions_leave_the_bits_alone():
+    """The round-5 changes that claim the SAME arithmetic per element -- the relative-position nets of all blocks in two launches per width
+    (VD_NO_RPE_ALL undoes it), the GroupNorm affine + SiLU inside conv_wino_z128.hip's patch staging (VD_NO_CONV_ACT) -- against the forms they
+    replace: eps of the tiny model and of the default 116 M model (one 64 x 64 clip), byte for byte.  The switches are read once per process:
+    tools/switch_check.py runs as child processes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shas = {}
+    for name, env in (("default", {}), ("per_block_rpe", {"VD_NO_RPE_ALL": "1"}), ("materialised_activations", {"VD_NO_CONV_ACT": "1"})):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "switch_check.py")], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        shas[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    for name in ("per_block_rpe", "materialised_activations"):
+        assert shas[name]["tiny"] == shas["default"]["tiny"] and shas[name]["full64"] == shas["default"]["full64"], (name, shas)
