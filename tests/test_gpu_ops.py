@@ -323,7 +323,7 @@ def test_groupnorm_temporal(B, T, HW, C):
 
 @pytest.mark.parametrize("N,L,C,heads", [(3, 256, 64, 4), (2, 64, 128, 4), (2, 100, 384, 4), (1, 16, 32, 4), (2, 257, 512, 4),
                                          (1, 40, 96, 2), (1, 33, 80, 2), (2, 70, 112, 2), (1, 50, 160, 2), (1, 90, 224, 2),
-                                         (1, 24, 24, 1)])
+                                         (1, 24, 24, 1), (1, 1024, 384, 4), (1, 600, 256, 2), (2, 128, 192, 2)])
 def test_attention_spatial(N, L, C, heads):
     """softmax(q*s k^T) v per (frame, head) (unet.py:477-489,525-536 with no RPE, no mask); ragged L."""
     qkv = rnd(N, L, 3 * C) * 2

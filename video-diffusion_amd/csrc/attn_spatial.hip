@@ -188,6 +188,9 @@ __device__ __forceinline__ void split_b8(f32x4 v0, f32x4 v1, u32x4_t (&out)[3]) 
     out[1] = u32x4_t{a2.x, a2.y, b2.x, b2.y};
     out[2] = u32x4_t{a3.x, a3.y, b3.x, b3.y};
 }
+#ifndef VD_ATTN_ABL
+#define VD_ATTN_ABL 0      // timing-only builds (results WRONG; tools/build_variant.sh): bit 0 no K / V loads, 1 no scores / softmax / output MFMAs, 2 no split + LDS stores
+#endif
 template <bool F16>
 __device__ __forceinline__ f32x16 attn_mfma(u32x4_t a, u32x4_t b, f32x16 c) {
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -200,8 +203,12 @@ constexpr int attn_rowv(int F) {           // bytes per V row: >= 64 per 32-feat
     return b;
 }
 
-template <int F, bool F16>
-__global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kernel(AttnSpatialArgs a) {
+// NW waves x 32 queries per block.  L = 256 (16 x 16 tokens): NW = 8, ONE block per (frame, head) -- K and V are fetched and split once (with
+// 128 queries per block the two blocks of a (frame, head) were dealt to different XCDs and each fetched K / V from HBM: 300 MB per launch
+// for 201 algorithmic).  The key tiles are double buffered in LDS: tile t + 1 is split and stored behind tile t's MFMAs, ONE barrier per tile.
+template <int F, bool F16, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_spatial_split_kernel(AttnSpatialArgs a) {
+    constexpr int NT = NW * 64;
     constexpr int KS = (F + 15) / 16, FK = KS * 16;     // k-steps of the QK^T contraction (zero padded)
     constexpr int FT = (F + 31) / 32;                   // 32-wide output tiles over F
     constexpr int ROWK = FK * 2 + 16, ROWV = attn_rowv(F);
@@ -210,13 +217,13 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
     constexpr int NPP = F16 ? 3 : 6;                    // piece products
     // (a piece, b piece) per product, small terms first: f16x3 a1 b2, a0 b1, a0 b0; bf16x6 the six of gemm_split.hip
     constexpr int PA[6] = {F16 ? 1 : 0, F16 ? 0 : 1, F16 ? 0 : 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
-    __shared__ __attribute__((aligned(16))) char Ks[NPL * KPL];
-    __shared__ __attribute__((aligned(16))) char Vs[NPL * VPL];
+    constexpr int STAGE = NPL * (KPL + VPL);           // one key tile: [K planes][V planes]
+    extern __shared__ __attribute__((aligned(16))) char attn_sp_lds[];      // [2][STAGE]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int n = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
     const int C3 = 3 * a.C;
     const float* base = a.qkv + (size_t)n * a.L * C3 + h * F;
 
@@ -258,8 +265,10 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
 
     // padding that is read but never staged: K columns F..FK (they enter the contraction) and V columns F..FT*32 (they
     // only feed output rows that are not stored; zeroed so that no NaN pattern meets a zero weight)
-    for (int i = tid; i < NPL * KPL / 4; i += 256) reinterpret_cast<unsigned*>(Ks)[i] = 0u;
-    for (int i = tid; i < NPL * VPL / 4; i += 256) reinterpret_cast<unsigned*>(Vs)[i] = 0u;
+    if constexpr (FK != F || FT * 32 != F) {
+        for (int i = tid; i < 2 * STAGE / 4; i += NT) reinterpret_cast<unsigned*>(attn_sp_lds)[i] = 0u;
+        __syncthreads();
+    }
 
     // transposed-read addresses of this lane: row (lane&15)>>2 of the 4-key block, columns 16*((lane>>4)&1) + 4*(lane&3)
     const int trow = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -269,43 +278,50 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
 
     // K / V rows of a key tile: requested one tile ahead into registers (the loads fly under the previous tile's MFMAs),
     // split and stored once the tile before has been consumed
-    constexpr int NIT = (32 * (F / 4) + 255) / 256;
+    constexpr int NIT = (32 * (F / 4) + NT - 1) / NT;
     f32x4 pk[NIT], pv[NIT];
     auto prefetch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
-            const int i = tid + u * 256;
+            const int i = tid + u * NT;
             const int r = i / (F / 4), c4 = i - r * (F / 4);
             const int key = k0 + r;
             pk[u] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[u] = pk[u];
-            if (i < 32 * (F / 4) && key < a.L) {
+            if (!(VD_ATTN_ABL & 1) && i < 32 * (F / 4) && key < a.L) {
                 const float* p = base + (size_t)key * C3 + c4 * 4;
                 pk[u] = *reinterpret_cast<const f32x4*>(p + a.C);
                 pv[u] = *reinterpret_cast<const f32x4*>(p + 2 * a.C);
             }
         }
     };
-    prefetch(0);
-    for (int k0 = 0; k0 < a.L; k0 += 32) {
-        __syncthreads();
+    auto stage = [&](int buf) {                                    // the prefetched tile, split, into buffer buf
+        char* Kd = attn_sp_lds + buf * STAGE;
+        char* Vd = Kd + NPL * KPL;
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
-            const int i = tid + u * 256;
-            if (i < 32 * (F / 4)) {
+            const int i = tid + u * NT;
+            if (!(VD_ATTN_ABL & 4) && i < 32 * (F / 4)) {
                 const int r = i / (F / 4), c4 = i - r * (F / 4);
                 u32x2_t k1, k2, k3, v1, v2, v3;
                 if constexpr (F16) { split_a16(pk[u], k1, k2); split_a16(pv[u], v1, v2); }
                 else { split_f4(pk[u], k1, k2, k3); split_f4(pv[u], v1, v2, v3); }
-                char* kd = Ks + r * ROWK + c4 * 8;
-                char* vd = Vs + r * ROWV + c4 * 8;
+                char* kd = Kd + r * ROWK + c4 * 8;
+                char* vd = Vd + r * ROWV + c4 * 8;
                 *reinterpret_cast<u32x2_t*>(kd) = k1; *reinterpret_cast<u32x2_t*>(kd + KPL) = k2;
                 *reinterpret_cast<u32x2_t*>(vd) = v1; *reinterpret_cast<u32x2_t*>(vd + VPL) = v2;
                 if constexpr (!F16) { *reinterpret_cast<u32x2_t*>(kd + 2 * KPL) = k3; *reinterpret_cast<u32x2_t*>(vd + 2 * VPL) = v3; }
             }
         }
-        __syncthreads();
-        if (k0 + 32 < a.L) prefetch(k0 + 32);
+    };
+    prefetch(0);
+    stage(0);
+    if (32 < a.L) prefetch(32);
+    __syncthreads();
+    for (int k0 = 0, tile = 0; k0 < a.L; k0 += 32, ++tile) {
+        const char* Ks = attn_sp_lds + (tile & 1) * STAGE;
+        const char* Vs = Ks + NPL * KPL;
 
+        if (!(VD_ATTN_ABL & 2)) {
         // S^T = K . Q^T, six piece products per k-step, small terms first
         f32x16 st;
 #pragma unroll
@@ -321,12 +337,13 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
         if constexpr (F16) st *= qs_inv;                            // the query row's scale leaves (exact)
         // lane (query lr, half lh) holds keys k0 + (r&3) + 8*(r>>2) + 4*lh
         float mloc = -INFINITY;
+        if (k0 + 32 > a.L) {                                          // (uniform: only a last, partial tile has keys to mask)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (key >= a.L) st[r] = -INFINITY;
-            mloc = fmaxf(mloc, st[r]);
+            for (int r = 0; r < 16; ++r)
+                if (k0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.L) st[r] = -INFINITY;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float mnew = fmaxf(m, mloc);
         const float alpha = __expf(m - mnew);      // m = -inf on the first tile -> 0
@@ -340,30 +357,41 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
         for (int t = 0; t < FT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-        // P^T pieces of the two k-steps (keys 0..15 and 16..31 of the tile): registers 8s .. 8s+7
-        u32x4_t pp[2][3];
+        // P^T pieces of the two k-steps (keys 0..15 and 16..31 of the tile): registers 8s .. 8s+7;  O^T += V^T . P^T
         constexpr float PSC = F16 ? 16384.f : 1.f;                    // f16x3: the weights times 2^14 (undone with 1 / l)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+            u32x4_t pp[3];
             split_b8<F16>(f32x4{st[8 * s], st[8 * s + 1], st[8 * s + 2], st[8 * s + 3]} * PSC,
-                          f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]} * PSC, pp[s]);
-        // O^T += V^T . P^T
+                          f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]} * PSC, pp);
+            constexpr int TG = (FT % 2 == 0 && FT > 2) ? 2 : FT;       // feature tiles in flight together (register budget at F = 128)
 #pragma unroll
-        for (int t = 0; t < FT; ++t)
+            for (int t0 = 0; t0 < FT; t0 += TG) {
+                u32x4_t vf[TG][NPL];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                u32x4_t vf[NPL];
+                for (int t = 0; t < TG; ++t)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) {
-                    const char* vb = Vs + p * VPL + voff + (16 * s) * ROWV + t * 64;
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + 8 * ROWV));
-                    typedef short s16x8_t __attribute__((ext_vector_type(8)));
-                    vf[p] = __builtin_bit_cast(u32x4_t, s16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
-                }
+                    for (int p = 0; p < NPL; ++p) {
+                        const char* vb = Vs + p * VPL + voff + (16 * s) * ROWV + (t0 + t) * 64;
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb));
+                        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + 8 * ROWV));
+                        typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                        vf[t][p] = __builtin_bit_cast(u32x4_t, s16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
+                    }
+                // (an accumulator is touched every TG-th MFMA: a dependent one issued back to back waits for its predecessor's write-back)
 #pragma unroll
-                for (int q = 0; q < NPP; ++q) o[t] = attn_mfma<F16>(vf[PA[q]], pp[s][PB[q]], o[t]);
+                for (int q = 0; q < NPP; ++q)
+#pragma unroll
+                    for (int t = 0; t < TG; ++t) o[t0 + t] = attn_mfma<F16>(vf[t][PA[q]], pp[PB[q]], o[t0 + t]);
             }
+        }
+        }
+        // the next tile into the other buffer (last read before the barrier that ended the previous tile), the one behind it requested
+        if (k0 + 32 < a.L) {
+            stage((tile + 1) & 1);
+            if (k0 + 64 < a.L) prefetch(k0 + 64);
+        }
+        __syncthreads();
     }
     if (!qok) return;
     const float inv = (F16 ? 1.f / 16384.f : 1.f) / l;
@@ -380,6 +408,29 @@ __global__ __launch_bounds__(256, F <= 96 ? 2 : 1) void attn_spatial_split_kerne
         }
 }
 
+template <int F, bool F16, int NW>
+static int launch_attn_spatial_split(const AttnSpatialArgs& a, hipStream_t s) {
+    constexpr int KS = (F + 15) / 16, NPL = F16 ? 2 : 3;
+    constexpr int LDS = 2 * NPL * (32 * (KS * 32 + 16) + 32 * attn_rowv(F));
+    static bool attr[16] = {};                                        // per device
+    int dev = 0;
+    VD_HIP(hipGetDevice(&dev));
+    if (dev < 16 && !attr[dev]) {
+        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_spatial_split_kernel<F, F16, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr[dev] = true;
+    }
+    dim3 grid((a.L + NW * 32 - 1) / (NW * 32), a.heads, a.nfr);
+    hipLaunchKernelGGL((attn_spatial_split_kernel<F, F16, NW>), grid, dim3(NW * 64), LDS, s, a);
+    return 0;
+}
+template <int F, bool F16>
+static int launch_attn_spatial_nw(const AttnSpatialArgs& a, hipStream_t s) {
+    // tokens per block: the whole (frame, head) when it has <= 256 of them
+    if (a.L > 128) return launch_attn_spatial_split<F, F16, 8>(a, s);
+    if (a.L > 64) return launch_attn_spatial_split<F, F16, 4>(a, s);
+    return launch_attn_spatial_split<F, F16, 2>(a, s);
+}
+
 int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s) {
     VD_REQUIRE(a.C % a.heads == 0, "channels divisible by heads");
     const int F = a.C / a.heads;
@@ -387,8 +438,8 @@ int launch_attn_spatial(const AttnSpatialArgs& a, hipStream_t s) {
     const int mode = math_mode();
     switch (F) {
 #define VD_CASE(FV) case FV: if (mode == MATH_FP32) hipLaunchKernelGGL((attn_spatial_kernel<FV>), grid, dim3(256), 0, s, a); \
-                             else if (mode == MATH_F16X3) hipLaunchKernelGGL((attn_spatial_split_kernel<FV, true>), grid, dim3(256), 0, s, a); \
-                             else hipLaunchKernelGGL((attn_spatial_split_kernel<FV, false>), grid, dim3(256), 0, s, a); break;
+                             else if (mode == MATH_F16X3) { if (launch_attn_spatial_nw<FV, true>(a, s)) return -1; } \
+                             else { if (launch_attn_spatial_nw<FV, false>(a, s)) return -1; } break;
         VD_CASE(8) VD_CASE(16) VD_CASE(24) VD_CASE(32) VD_CASE(40) VD_CASE(48) VD_CASE(56) VD_CASE(64) VD_CASE(80) VD_CASE(96) VD_CASE(112) VD_CASE(128)
 #undef VD_CASE
         default:
