@@ -95,14 +95,26 @@ __global__ __launch_bounds__(256) void gn_final_affine_kernel(const double* __re
     const int n = blockIdx.x, tid = threadIdx.x;
     const int g = tid >> 3, l = tid & 7;
     const int cg = C / 32, C1 = C - C0;
-    double s = 0, ss = 0;
-    for (int ci = l; ci < cg; ci += 8) {
-        const int c = g * cg + ci;
+    // the group's cg x split (sum, sum of squares) pairs dealt to its 8 lanes, FOUR requests in flight per lane: the kernel is nothing but
+    // dependent round trips to L2 (one pair per trip and lane: 10 us per launch at 16 pixel ranges, 24 launches per step)
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const int smax = max(split0, split1), items = cg * smax;
+    auto fetch = [&](int it) -> f64x2 {
+        const int ci = it / smax, sp = it - ci * smax, c = g * cg + ci;
         const bool second = c >= C0;
         const int split = second ? split1 : split0, ld = second ? C1 : C0, cc = second ? c - C0 : c;
-        const double* p = (second ? part1 : part0) + ((size_t)n * split * ld + cc) * 2;
-        for (int sp = 0; sp < split; ++sp) { s += p[(size_t)sp * ld * 2]; ss += p[(size_t)sp * ld * 2 + 1]; }
+        if (it >= items || sp >= split) return f64x2{0.0, 0.0};
+        return *reinterpret_cast<const f64x2*>((second ? part1 : part0) + (((size_t)n * split + sp) * ld + cc) * 2);
+    };
+    f64x2 acc[4] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+    for (int it = l; it < items; it += 32) {
+        f64x2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = fetch(it + 8 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += v[u];
     }
+    double s = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), ss = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 8); ss += __shfl_xor(ss, o, 8); }
     if (l == 0) {
