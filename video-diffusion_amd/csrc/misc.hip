@@ -33,37 +33,46 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
         a.t_frames[n] = tf;
         a.amask[n] = any;
     }
-    // thread -> (pixel, tap): 16 pixels x 9 taps (+7 idle lanes' worth) per 256 threads would waste lanes; use one thread
-    // per (pixel, tap) with 9 taps in consecutive threads: blockIdx.x covers 28 pixels (252 threads active)
+    // thread -> (pixel, four consecutive columns k = tap*Cs + c of its im2col row): a row of Kpad = 64 floats leaves as sixteen 16-byte
+    // stores of neighbouring lanes (the first version -- thread = (pixel, tap), Cs scalar stores each -- wrote the 134 MB of the headline
+    // window at 1.9 TB/s: 71 us); the gathered sources are 6 MB and stay in L2
     if (a.scalars_only) return;
-    const int tp = threadIdx.x / 9, tap = threadIdx.x - tp * 9;
-    const int p = blockIdx.x * 28 + tp;
-    if (tp >= 28 || p >= HW) return;
-    const int y = p / a.W + tap / 3 - 1, x = p % a.W + tap % 3 - 1;
-    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-        const int q = y * a.W + x;
+    const int qpr = a.Kpad >> 2, ppb = 256 / qpr;                          // quads per row, pixels per block
+    const int tp = threadIdx.x / qpr, j = threadIdx.x - tp * qpr;
+    const int p = blockIdx.x * ppb + tp;
+    if (tp >= ppb || p >= HW) return;
+    const int py = p / a.W, px = p - py * a.W;
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float xv = a.x[((size_t)n * 3 + c) * HW + q];
-            const float ov = a.obs_src[((size_t)n * 3 + c) * HW + q];
-            if (a.cond_mode == 0) v[c] = xv * lm + ov * om + xv * (1.f - any);
-            else if (a.cond_mode == 1) { v[c] = xv * lm + xv * (1.f - any); v[3 + c] = ov * om; }   // obs_src = x0 (unet.py:1014-1017)
-            else v[c] = xv;
-        }
-        if (a.cond_mode == 0) { v[3] = om; v[4] = km; }
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * j + e;
+        if (k >= 9 * Cs) continue;
+        const int tap = k / Cs, c = k - tap * Cs;
+        const int y = py + tap / 3 - 1, x = px + tap % 3 - 1;
+        if (y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
+        const int q = y * a.W + x;
+        float v;
+        if (a.cond_mode == 0) {
+            if (c < 3) {
+                const float xv = a.x[((size_t)n * 3 + c) * HW + q], ov = a.obs_src[((size_t)n * 3 + c) * HW + q];
+                v = xv * lm + ov * om + xv * (1.f - any);
+            } else v = c == 3 ? om : km;
+        } else if (a.cond_mode == 1) {                                      // obs_src = x0 (unet.py:1014-1017)
+            if (c < 3) { const float xv = a.x[((size_t)n * 3 + c) * HW + q]; v = xv * lm + xv * (1.f - any); }
+            else v = a.obs_src[((size_t)n * 3 + (c - 3)) * HW + q] * om;
+        } else v = a.x[((size_t)n * 3 + c) * HW + q];
+        out[e] = v;
     }
-    float* o = a.x_cols + ((size_t)blockIdx.y * HW + p) * a.Kpad + tap * Cs;
-    for (int c = 0; c < Cs; ++c) o[c] = v[c];
-    if (tap == 8)
-        for (int k = 9 * Cs; k < a.Kpad; ++k) o[k - 8 * Cs] = 0.f;   // o + Cs = column 9*Cs
+    *reinterpret_cast<f32x4*>(a.x_cols + ((size_t)blockIdx.y * HW + p) * a.Kpad + 4 * j) = out;
 }
 
 int launch_assemble(const AssembleArgs& a, hipStream_t s) {
     VD_REQUIRE(a.Kpad % 32 == 0 && a.Kpad >= 64, "padded im2col width");
     VD_REQUIRE(!(a.frame_list && a.scalars_only), "assemble: a frame list writes im2col rows only");
     if (a.frame_list && a.n_list == 0) return 0;
-    const dim3 grid(a.scalars_only ? 1 : (a.H * a.W + 27) / 28, a.frame_list ? a.n_list : a.B * a.T);
+    VD_REQUIRE(a.Kpad <= 1024, "padded im2col width");
+    const int ppb = 256 / (a.Kpad / 4);
+    const dim3 grid(a.scalars_only ? 1 : (a.H * a.W + ppb - 1) / ppb, a.frame_list ? a.n_list : a.B * a.T);
     hipLaunchKernelGGL(assemble_kernel, grid, dim3(256), 0, s, a);
     VD_HIP(hipGetLastError());
     return 0;
@@ -167,27 +176,41 @@ __global__ __launch_bounds__(256) void rpe_hidden_kernel(const float* __restrict
     }
 }
 
+// One block per (batch item, query frame, net): the T key frames of a query frame share the timestep-embedding row, and a thread keeps its
+// channel's four constants in registers (one block per (b, t, s) row -- 30 k blocks of 1.5 KB each -- wrote its 47 / 75 MB at 1.6 TB/s: 2 x 38 us).
 __global__ __launch_bounds__(256) void rpe_hidden_tab_kernel(const float* __restrict__ te, int te_ld, const float* __restrict__ wbase,
                                                              const long long* __restrict__ tab, const int64_t* __restrict__ fidx, int T, int C,
                                                              float* __restrict__ E, size_t zs_e) {
+    __shared__ float feat[64][3];
     const long long* tz = tab + 3 * blockIdx.y;
     te += tz[0];
     const float* Wd = wbase + tz[1];
     const float* bd = wbase + tz[2];
     E += blockIdx.y * zs_e;
-    const int row = blockIdx.x;                 // (b*T + t)*T + s
-    const int s_ = row % T, bt = row / T, b = bt / T;
-    const float d = (float)(fidx[bt] - fidx[b * T + s_]);
-    const float f0 = logf(1.0f + fmaxf(d, 0.f)), f1 = logf(1.0f + fmaxf(-d, 0.f)), f2 = d == 0.f ? 1.f : 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float lin = bd[c] + f0 * Wd[c * 3] + f1 * Wd[c * 3 + 1] + f2 * Wd[c * 3 + 2];
-        E[(size_t)row * C + c] = silu_f(te[(size_t)bt * te_ld + c] + lin);
+    const int bt = blockIdx.x, b = bt / T;      // rows (b*T + t)*T + s, s = 0 .. T-1
+    for (int s0 = 0; s0 < T; s0 += 64) {
+        const int ns = min(64, T - s0);
+        __syncthreads();
+        if ((int)threadIdx.x < ns) {
+            const float d = (float)(fidx[bt] - fidx[b * T + s0 + threadIdx.x]);
+            feat[threadIdx.x][0] = logf(1.0f + fmaxf(d, 0.f));
+            feat[threadIdx.x][1] = logf(1.0f + fmaxf(-d, 0.f));
+            feat[threadIdx.x][2] = d == 0.f ? 1.f : 0.f;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float bc = bd[c], w0 = Wd[c * 3], w1 = Wd[c * 3 + 1], w2 = Wd[c * 3 + 2], tv = te[(size_t)bt * te_ld + c];
+            for (int k = 0; k < ns; ++k) {
+                const float lin = bc + feat[k][0] * w0 + feat[k][1] * w1 + feat[k][2] * w2;
+                E[((size_t)bt * T + s0 + k) * C + c] = silu_f(tv + lin);
+            }
+        }
     }
 }
 
 int launch_rpe_hidden_tab(const float* te, int te_ld, const float* wbase, const long long* tab, const int64_t* fidx, int B, int T, int C,
                           float* E, int nz, size_t zs_e, hipStream_t s) {
-    hipLaunchKernelGGL(rpe_hidden_tab_kernel, dim3(B * T * T, nz), dim3(256), 0, s, te, te_ld, wbase, tab, fidx, T, C, E, zs_e);
+    hipLaunchKernelGGL(rpe_hidden_tab_kernel, dim3(B * T, nz), dim3(256), 0, s, te, te_ld, wbase, tab, fidx, T, C, E, zs_e);
     VD_HIP(hipGetLastError());
     return 0;
 }
