@@ -33,46 +33,59 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
         a.t_frames[n] = tf;
         a.amask[n] = any;
     }
-    // thread -> (pixel, four consecutive columns k = tap*Cs + c of its im2col row): a row of Kpad = 64 floats leaves as sixteen 16-byte
-    // stores of neighbouring lanes (the first version -- thread = (pixel, tap), Cs scalar stores each -- wrote the 134 MB of the headline
-    // window at 1.9 TB/s: 71 us); the gathered sources are 6 MB and stay in L2
+    // Block = a strip of up to 64 pixels of one image row.  The three source rows of the strip (+ one column either side) are read ONCE, along
+    // x (coalesced), mixed into the Cs stem channels and kept in LDS; an im2col row of Kpad = 64 floats is nine shifted copies of those and
+    // leaves as sixteen 16-byte stores of neighbouring lanes.  (First version: thread = (pixel, tap), every tap re-reading x and x0 with
+    // scalar loads and Cs scalar stores: 71 us for the 134 MB of the headline window; 16-byte stores alone, the gathers still per lane: 79.)
     if (a.scalars_only) return;
-    const int qpr = a.Kpad >> 2, ppb = 256 / qpr;                          // quads per row, pixels per block
-    const int tp = threadIdx.x / qpr, j = threadIdx.x - tp * qpr;
-    const int p = blockIdx.x * ppb + tp;
-    if (tp >= ppb || p >= HW) return;
-    const int py = p / a.W, px = p - py * a.W;
-    f32x4 out = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int k = 4 * j + e;
-        if (k >= 9 * Cs) continue;
-        const int tap = k / Cs, c = k - tap * Cs;
-        const int y = py + tap / 3 - 1, x = px + tap % 3 - 1;
-        if (y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
-        const int q = y * a.W + x;
-        float v;
+    constexpr int SW = 64;
+    __shared__ float tile[3][SW + 2][6];
+    __shared__ int lut[256];
+    const int strips = (a.W + SW - 1) / SW;
+    const int y = blockIdx.x / strips, x0 = (blockIdx.x - y * strips) * SW;
+    for (int i = threadIdx.x; i < 9 * (SW + 2); i += 256) {
+        const int xx = i % (SW + 2), rc = i / (SW + 2), r = rc % 3, c = rc / 3;
+        const int yy = y + r - 1, gx = x0 + xx - 1;
+        const bool in = yy >= 0 && yy < a.H && gx >= 0 && gx < a.W;
+        float xv = 0.f, ov = 0.f;
+        if (in) {
+            const size_t q = ((size_t)n * 3 + c) * HW + yy * a.W + gx;
+            xv = a.x[q];
+            ov = a.obs_src[q];
+        }
         if (a.cond_mode == 0) {
-            if (c < 3) {
-                const float xv = a.x[((size_t)n * 3 + c) * HW + q], ov = a.obs_src[((size_t)n * 3 + c) * HW + q];
-                v = xv * lm + ov * om + xv * (1.f - any);
-            } else v = c == 3 ? om : km;
+            tile[r][xx][c] = in ? xv * lm + ov * om + xv * (1.f - any) : 0.f;
+            if (c == 0) { tile[r][xx][3] = in ? om : 0.f; tile[r][xx][4] = in ? km : 0.f; }
         } else if (a.cond_mode == 1) {                                      // obs_src = x0 (unet.py:1014-1017)
-            if (c < 3) { const float xv = a.x[((size_t)n * 3 + c) * HW + q]; v = xv * lm + xv * (1.f - any); }
-            else v = a.obs_src[((size_t)n * 3 + (c - 3)) * HW + q] * om;
-        } else v = a.x[((size_t)n * 3 + c) * HW + q];
-        out[e] = v;
+            tile[r][xx][c] = in ? xv * lm + xv * (1.f - any) : 0.f;
+            tile[r][xx][3 + c] = in ? ov * om : 0.f;
+        } else tile[r][xx][c] = xv;
     }
-    *reinterpret_cast<f32x4*>(a.x_cols + ((size_t)blockIdx.y * HW + p) * a.Kpad + 4 * j) = out;
+    for (int k = threadIdx.x; k < a.Kpad; k += 256) {                     // column k -> its float in the tile of pixel 0 (or none)
+        const int tap = k / Cs, c = k - tap * Cs;
+        lut[k] = k < 9 * Cs ? ((tap / 3) * (SW + 2) + tap % 3) * 6 + c : -1;
+    }
+    __syncthreads();
+    const int qpr = a.Kpad >> 2, sh = 31 - __clz(qpr);                      // (Kpad / 4 is a power of two: launch_assemble)
+    const float* tf = &tile[0][0][0];
+    for (int i = threadIdx.x; i < SW * qpr; i += 256) {
+        const int px = i >> sh, j = i & (qpr - 1);
+        if (x0 + px >= a.W) continue;
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = lut[4 * j + e];
+            out[e] = o >= 0 ? tf[o + px * 6] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(a.x_cols + ((size_t)blockIdx.y * HW + (size_t)y * a.W + x0 + px) * a.Kpad + 4 * j) = out;
+    }
 }
 
 int launch_assemble(const AssembleArgs& a, hipStream_t s) {
-    VD_REQUIRE(a.Kpad % 32 == 0 && a.Kpad >= 64, "padded im2col width");
+    VD_REQUIRE(a.Kpad >= 64 && a.Kpad <= 256 && (a.Kpad & (a.Kpad - 1)) == 0, "padded im2col width: 64, 128 or 256");
     VD_REQUIRE(!(a.frame_list && a.scalars_only), "assemble: a frame list writes im2col rows only");
     if (a.frame_list && a.n_list == 0) return 0;
-    VD_REQUIRE(a.Kpad <= 1024, "padded im2col width");
-    const int ppb = 256 / (a.Kpad / 4);
-    const dim3 grid(a.scalars_only ? 1 : (a.H * a.W + ppb - 1) / ppb, a.frame_list ? a.n_list : a.B * a.T);
+    const dim3 grid(a.scalars_only ? 1 : a.H * ((a.W + 63) / 64), a.frame_list ? a.n_list : a.B * a.T);
     hipLaunchKernelGGL(assemble_kernel, grid, dim3(256), 0, s, a);
     VD_HIP(hipGetLastError());
     return 0;
