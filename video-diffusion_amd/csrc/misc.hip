@@ -359,11 +359,11 @@ int launch_out_conv(const float* x, const float* affA, const float* affB, const 
 // tile's rows requested before the current one is multiplied.  Bound by the read of h.
 template <int NCT, int CMAX>
 __global__ __launch_bounds__(256, 2) void head_gemm_kernel(const float* __restrict__ h, const float* __restrict__ affA, const float* __restrict__ affB,
-                                                           const float* __restrict__ Wt, int HW, int C, float* __restrict__ T) {
-    constexpr int NI = CMAX / 8, LDT = 32 * NCT, TPW = 8;
+                                                           const float* __restrict__ Wt, int HW, int C, int TPW, float* __restrict__ T) {
+    constexpr int NI = CMAX / 8, LDT = 32 * NCT;
     __shared__ __attribute__((aligned(16))) float sab[2 * CMAX];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 31, kh = lane >> 5;
-    const size_t pix_blk = (size_t)blockIdx.x * 1024;                 // 1024 pixels of ONE frame (HW % 1024 == 0)
+    const size_t pix_blk = (size_t)blockIdx.x * (128 * TPW);          // 128 TPW pixels of ONE frame (HW % 1024 == 0; TPW = 8 | 2: tiles per wave)
     const int n = (int)(pix_blk / HW);
     for (int c = tid; c < C; c += 256) { sab[c] = affA[(size_t)n * C + c]; sab[CMAX + c] = affB[(size_t)n * C + c]; }
     const int ni = C >> 3;
@@ -417,8 +417,10 @@ bool head_gemm_supported(int HW, int C, int ldt) { return HW % 1024 == 0 && C % 
 
 int launch_head_gemm(const float* h, const float* affA, const float* affB, const float* Wt, int nfr, int HW, int C, int ldt, float* T, hipStream_t s) {
     VD_REQUIRE(head_gemm_supported(HW, C, ldt), "output head GEMM: whole 1024-pixel blocks of a frame, C <= 128, 32 columns");
-    const dim3 grid((unsigned)((size_t)nfr * HW / 1024));
-    hipLaunchKernelGGL((head_gemm_kernel<1, 128>), grid, dim3(256), 0, s, h, affA, affB, Wt, HW, C, T);
+    // a small window (one rank's share of a strong-scaling split: 16 frames = 64 blocks of 1024 pixels) takes 256-pixel blocks: head 58 -> 29 us there
+    const int tpw = (size_t)nfr * HW / 1024 < 512 ? 2 : 8;
+    const dim3 grid((unsigned)((size_t)nfr * HW / (128 * tpw)));
+    hipLaunchKernelGGL((head_gemm_kernel<1, 128>), grid, dim3(256), 0, s, h, affA, affB, Wt, HW, C, tpw, T);
     VD_HIP(hipGetLastError());
     return 0;
 }
