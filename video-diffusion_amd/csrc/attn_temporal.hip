@@ -177,9 +177,15 @@ __device__ __forceinline__ void rows_regs_transpose(float& x0, float& x1, float&
     x0 = f(q02[0]); x2 = f(q02[1]); x1 = f(q13[0]); x3 = f(q13[1]);
 }
 
+#ifndef VD_ATT_OCC
+#define VD_ATT_OCC 2       // waves per SIMD the compiler must leave room for (4: <= 128 registers = two resident 8-wave blocks): without / with the RPE terms (A/B)
+#endif
+#ifndef VD_ATT_OCC_RPE
+#define VD_ATT_OCC_RPE 2
+#endif
 template <int NT, int JM, bool RPE, bool EXACT>            // EXACT: F == 16*JM and T == 16*NT -- no guard around any request (a
 // conditional request makes hipcc wait for ALL outstanding loads at the next use, which voids the requests made ahead)
-__global__ __launch_bounds__(512) void attn_temporal_mfma_kernel(AttnTemporalArgs a) {
+__global__ __launch_bounds__(512, (RPE ? VD_ATT_OCC_RPE : VD_ATT_OCC)) void attn_temporal_mfma_kernel(AttnTemporalArgs a) {
     constexpr int TP = 16 * NT, RS = TP + 1, PS = TP * RS + (NT == 1 ? 1 : 17);   // pixel stride = 17 mod 32 banks
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* w = smem;                                        // [16 px][PS]: row (t) stride RS
