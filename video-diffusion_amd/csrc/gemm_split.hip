@@ -54,7 +54,7 @@ __device__ __forceinline__ f32x16 mfma_piece(u32x4 a, u32x4 b, f32x16 c) {
 #define VD_GS_XCD 1        // XCD-aware block -> tile mapping (A/B: 0)
 #endif
 #ifndef VD_GS_SKIP
-#define VD_GS_SKIP 0       // kernel-experiment builds: bit 0 no weight loads, 1 no A staging, 2 no split VALU (timing only)
+#define VD_GS_SKIP 0       // kernel-experiment builds: bit 0 no weight loads, 1 no A staging, 2 no split + LDS stores, 3 stores of unsplit bits (timing only)
 #endif
 #ifdef VD_GS_TIMING
 // cycle stamps of ONE block (the middle row tile, column tile 0; with two blocks per CU the shader clock counts both: use the 100 MHz clock):
@@ -348,7 +348,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(IgemmArgs a) {
         if (data_chunk >= 0) side_store(v, data_chunk, j);
         if constexpr (ACT) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
         u32x2 p1, p2, p3;
-        split3<F16>(v, p1, p2, p3);
+        if (VD_GS_SKIP & 8) {                    // timing only: the raw bits instead of the pieces -- what an operand that arrives split would cost
+            p1 = u32x2{__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)};
+            p2 = u32x2{__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
+            p3 = p2;
+        } else split3<F16>(v, p1, p2, p3);
         char* d = Ad + (lrow + 32 * j) * SROW + lq * 8;
         *reinterpret_cast<u32x2*>(d) = p1;
         *reinterpret_cast<u32x2*>(d + PLANE) = p2;
