@@ -39,6 +39,12 @@ def main():
         nfr, Hs = args.frames, H >> ups
         x0 = torch.rand(nfr, Hs, Hs, Cin, device="cuda") - 0.5
         w = (torch.rand(Cout, Cin, 3, 3) - 0.5) * (12.0 / (9 * Cin)) ** 0.5
+        # VD_CONV_BENCH_DATA=zero_x | zero_w | const: the same instruction stream on operands that do not toggle (a kernel that gets faster on
+        # them is limited by the board's power management, not by its schedule)
+        data = os.environ.get("VD_CONV_BENCH_DATA", "")
+        if data == "zero_x": x0.zero_()
+        if data == "zero_w": w.zero_()
+        if data == "const": x0.fill_(0.25); w.fill_(0.125)
         b, res = torch.rand(Cout, device="cuda"), torch.rand(nfr, H, H, Cout, device="cuda")
         out = torch.empty(nfr, H, H, Cout, device="cuda")
         part = torch.empty(nfr, L.vd_conv_stats_split(H), Cout, 2, dtype=torch.float64, device="cuda")
