@@ -40,6 +40,10 @@ def main():
     for M, K, N, res, cnt in LIN:
         a = torch.rand(M, K, device="cuda") - 0.5
         w = (torch.rand(N, K) - 0.5) * (12.0 / K) ** 0.5
+        data = os.environ.get("VD_GEMM_BENCH_DATA", "")       # zero_a | zero_w | const: operands that do not toggle (tools/conv_bench.py)
+        if data == "zero_a": a.zero_()
+        if data == "zero_w": w.zero_()
+        if data == "const": a.fill_(0.25); w.fill_(0.125)
         wp = torch.empty(L.vd_split_image_u16(N, K), dtype=torch.int16)
         _lib.check(L.vd_pack_linear_split(_lib.ptr(w), _lib.ptr(wp), N, K))
         ws = wp.cuda()
