@@ -259,3 +259,145 @@ def test_adaptive_schedulers_match_reference_sequences():
         it = iter(inference_strategies["adaptive-autoreg"](distance="lpips", video_length=8, num_obs=2, max_frames=4, step_size=2))
         it.set_videos(torch.zeros(1, 8, 3, 4, 4))
         next(it)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The sampling job around infer_video (scripts/video_sample.py:192-239, 570-590) and the NLL window builder
+class _CountingDiffusion:
+    """Stand-in sampler for the job tests (no GPU here): counts its p_sample calls, leaves x unchanged."""
+    num_timesteps = 3
+
+    def __init__(self):
+        self.calls = 0
+
+    def p_sample(self, model, x, t, **kw):
+        self.calls += 1
+        return {"sample": x}
+
+
+def _job_args(tmp_path, **over):
+    from argparse import Namespace
+    base = dict(checkpoint_path="", inference_mode="autoreg", T=6, max_frames=4, obs_length=2, step_size=2, batch_size=2,
+                num_videos=5, timestep_respacing="ddim5", observed_frames="x_0", image_size=32, num_channels=32,
+                num_res_blocks=1, seed=0, adaptive_distance="l2", executor="eager", eval_dir=str(tmp_path / "out"),
+                out_dir=None, use_ddim=False, sample_idx=None, num_samples=1, indices=None, task_id=None,
+                subset_size=None, optimality=None, use_gradient_method=False, save_all_timesteps=False, videos=None,
+                synthetic=True)
+    base.update(over)
+    return Namespace(**base)
+
+
+def _run_job(args):
+    import torch
+    from video_diffusion_amd import video_sample
+    diff = _CountingDiffusion()
+
+    def create(**kw):
+        model, _ = vda.create_video_model_and_diffusion(**kw)
+        return model, diff
+
+    out = video_sample.run(args, create=create, device=torch.device("cpu"))
+    return out, diff
+
+
+def test_sampling_job_decides_todo_before_sampling_and_resumes_without_a_step(tmp_path):
+    """video_sample.py:207-239: per batch and sample index the names are formed and the disk is looked at BEFORE
+    infer_video; a finished (batch, sample) costs no denoise step; a partially finished batch is sampled again but
+    only its missing files are written."""
+    args = _job_args(tmp_path, num_samples=2)
+    out, diff = _run_job(args)
+    files = sorted(os.listdir(out / "samples"))
+    assert files == [f"sample_{i:04d}-{s}.npy" for i in range(5) for s in range(2)]
+    windows = 2                                                           # autoreg: frames 2-3, 4-5 with step_size 2
+    assert diff.calls == 3 * 2 * windows * _CountingDiffusion.num_timesteps     # 3 batches x 2 samples
+    a = np.load(out / "samples" / "sample_0003-1.npy")
+    assert a.dtype == np.uint8 and a.shape == (6, 3, 32, 32)
+    out2, diff2 = _run_job(_job_args(tmp_path, num_samples=2))
+    assert out2 == out and diff2.calls == 0                              # the resumed job repeats nothing
+    stamp = os.path.getmtime(out / "samples" / "sample_0002-0.npy")
+    os.remove(out / "samples" / "sample_0003-0.npy")                     # batch (2, 3), sample 0 is now half done
+    out3, diff3 = _run_job(_job_args(tmp_path, num_samples=2))
+    assert diff3.calls == windows * _CountingDiffusion.num_timesteps
+    assert os.path.exists(out / "samples" / "sample_0003-0.npy")
+    assert os.path.getmtime(out / "samples" / "sample_0002-0.npy") == stamp        # its finished neighbour is left alone
+
+
+def test_sampling_job_indices_task_id_subset_and_sample_idx(tmp_path):
+    """video_sample.py:570-590: --indices as given; --task_id = one batch worth of consecutive items; --subset_size = the
+    first N; --sample_idx overrides --num_samples; file names carry the DATASET index (dataset_idx_translate, :202-203)."""
+    from video_diffusion_amd import video_sample as vs
+    out_a, _ = _run_job(_job_args(tmp_path / "a", indices=[4, 1, 3], sample_idx=7, num_samples=3))
+    assert sorted(os.listdir(out_a / "samples")) == ["sample_0001-7.npy", "sample_0003-7.npy", "sample_0004-7.npy"]
+    out_b, _ = _run_job(_job_args(tmp_path / "b", task_id=1))
+    assert sorted(os.listdir(out_b / "samples")) == ["sample_0002-0.npy", "sample_0003-0.npy"]
+    out, _ = _run_job(_job_args(tmp_path / "c", subset_size=3))
+    assert sorted(os.listdir(out / "samples")) == ["sample_0000-0.npy", "sample_0001-0.npy", "sample_0002-0.npy"]
+    with pytest.raises(AssertionError):
+        vs.resolve_indices(_job_args(tmp_path, task_id=0, subset_size=2), 5)
+    # a video is a function of its dataset index alone: the same item through another batch composition gives the same file
+    a = np.load(out_a / "samples" / "sample_0003-7.npy")
+    b = np.load(out_b / "samples" / "sample_0003-0.npy")
+    assert np.array_equal(a[:2], b[:2])                                  # the observed frames pass through untouched
+
+
+def test_sampling_job_reads_videos_from_a_file_and_names_the_run_from_the_options_as_given(tmp_path, monkeypatch):
+    """--videos file.npy (uint8, the format the tool writes) beside --synthetic; --T / --max_frames unset: T comes from the
+    dataset, max_frames from the model config, and the run directory says 'None' for both, as the reference's does
+    (its eval_dir is formed right after parse_args, video_sample.py:530-533)."""
+    import torch
+    vids = (np.random.RandomState(0).rand(3, 6, 3, 32, 32) * 255).astype(np.uint8)
+    np.save(tmp_path / "v.npy", vids)
+    cfg = vda.video_model_and_diffusion_defaults()
+    cfg.update(T=4, image_size=32, num_channels=32, num_res_blocks=1, rp_alpha=4, rp_beta=4, rp_gamma=4)
+    model, _ = vda.create_video_model_and_diffusion(**cfg)
+    sd = {k: torch.from_numpy(vda.weights_init.synth_param(k, s)) for k, s in model.param_specs()}
+    cfg["max_frames"] = 4                                                 # a training option the checkpoint's config records (video_train.py:126)
+    ck = tmp_path / "checkpoints" / "r" / "ema_100.pt"
+    ck.parent.mkdir(parents=True)
+    torch.save({"state_dict": sd, "config": cfg, "step": 100}, ck)
+    monkeypatch.chdir(tmp_path)
+    args = _job_args(tmp_path, checkpoint_path=str(ck), videos=str(tmp_path / "v.npy"), T=None, max_frames=None, eval_dir=None,
+                     use_ddim=True)
+    out, diff = _run_job(args)
+    assert str(out) == "results/r/ema_100_ddim_respaceddim5/autoreg_None_2_None_2"
+    assert args.T == 6 and args.max_frames == 4 and diff.calls > 0
+    got = np.load(tmp_path / out / "samples" / "sample_0002-0.npy")
+    assert np.abs(got[:2].astype(int) - vids[2, :2].astype(int)).max() <= 1        # uint8 -> [-1, 1] -> truncated uint8
+    mc = json.load(open(tmp_path / out / "model_config.json"))
+    assert mc["use_ddim"] is True and mc["timestep_respacing"] == "ddim5" and mc["max_frames"] == 4
+
+
+def test_nll_window_table_equals_the_per_item_construction():
+    """scripts/video_nll.py:150-165 builds x0 / masks / frame_indices item by item; the mirror builds them as one gather."""
+    import torch
+    from video_diffusion_amd.video_nll import _window_table, run_bpd_evaluation
+    obs = [[0, 1], [5, 2, 0], []]
+    lat = [[2, 3, 7], [3], [4, 6]]
+    batch = torch.randn(3, 8, 3, 4, 4)
+    seen = {}
+
+    class Dev:
+        device = torch.device("cpu")
+
+    class Diff:
+        def calc_bpd_loop_subsampled(self, model, x0, clip_denoised, model_kwargs, latent_mask, t_seq):
+            seen.update(model_kwargs, x_start=x0, lm=latent_mask)
+            return {"total_bpd": torch.ones(3), "vb": torch.ones(3, 5)}
+
+    out = run_bpd_evaluation(Dev(), Diff(), batch, True, obs, lat)
+    F = 5
+    x0 = torch.zeros(3, F, 3, 4, 4)
+    om, lm, fi = torch.zeros(3, F, 1, 1, 1), torch.zeros(3, F, 1, 1, 1), torch.zeros(3, F, dtype=torch.long)
+    for i, (o, l) in enumerate(zip(obs, lat)):
+        for s, f in enumerate(o + l):
+            x0[i, s] = batch[i, f]
+            fi[i, s] = f
+            (om if s < len(o) else lm)[i, s] = 1
+    assert torch.equal(seen["x0"], x0) and torch.equal(seen["x_start"], x0) and torch.equal(seen["x_t_minus_1"], x0)
+    assert torch.equal(seen["obs_mask"], om) and torch.equal(seen["latent_mask"], lm) and torch.equal(seen["lm"], lm)
+    assert torch.equal(seen["frame_indices"], fi) and seen["frame_indices"].dtype == torch.long
+    assert not seen["kinda_marg_mask"].any() and seen["observed_frames"] == "x_0"
+    assert out["total_bpd"].tolist() == [5.0] * 3 and out["vb"].tolist() == [25.0] * 3     # x window length; vb summed over t
+    t, o_, l_ = _window_table([[1]], [[2, 3]], 2)                        # a batch longer than the index lists: empty rows
+    assert t.tolist() == [[1, 2, 3], [0, 0, 0]] and o_.tolist() == [[True, False, False], [False] * 3]
+    assert l_.tolist() == [[False, True, True], [False] * 3]

@@ -43,44 +43,41 @@ else:                                  # pragma: no cover
             os.unlink(self.lock_path)
 
 
+def _checkpoint_step(checkpoint_path):
+    """The training step a checkpoint file records ('step' of the saved dict)."""
+    return torch.load(checkpoint_path, map_location="cpu")["step"]
+
+
 def get_model_results_path(args, postfix=""):
-    """results/<checkpoint path after the first '*checkpoint*' component, minus the file>/<stem>[_<step>][_ddim][_respace<X>]
-    -- or args.eval_dir untouched when it is given (test_util.py:65-108).  `args`: use_ddim, timestep_respacing,
-    eval_dir, checkpoint_path.  A checkpoint named '*latest' gets its training step appended (read from the file)."""
-    if args.use_ddim:
-        postfix += "_ddim"
-    if args.timestep_respacing != "":
-        postfix += "_" + f"respace{args.timestep_respacing}"
+    """Where the samples of a checkpoint go (contract of test_util.py:65-108, pinned by tests/golden/eval_paths.json):
+    `args.eval_dir` untouched when given; otherwise results/<dirs>/<label> with <dirs> = the directories of
+    `args.checkpoint_path` strictly between its first component containing 'checkpoint' and the file, and
+    <label> = <file stem>[_<training step> for a '*latest' file]<postfix>[_ddim][_respace<timestep_respacing>]."""
     if args.eval_dir is not None:
         return Path(args.eval_dir)
-    checkpoint_path = Path(args.checkpoint_path)
-    name = f"{checkpoint_path.stem}"
-    if name.endswith("latest"):
-        name += f"_{torch.load(args.checkpoint_path, map_location='cpu')['step']}"
-    if postfix != "":
-        name += postfix
-    path = None
-    for idx, x in enumerate(checkpoint_path.parts):
-        if "checkpoint" in x:
-            path = Path(*(checkpoint_path.parts[idx + 1:]))
-            break
-    assert path is not None
-    return Path("results") / path.parent / name
+    ckpt = Path(args.checkpoint_path)
+    marker = next((k for k, part in enumerate(ckpt.parts) if "checkpoint" in part), None)
+    if marker is None:
+        raise AssertionError(f"no '*checkpoint*' component in {ckpt}")
+    label = [ckpt.stem]
+    if ckpt.stem.endswith("latest"):
+        label.append(f"_{_checkpoint_step(args.checkpoint_path)}")
+    label.append(postfix)
+    label.append("_ddim" if args.use_ddim else "")
+    label.append(f"_respace{args.timestep_respacing}" if args.timestep_respacing != "" else "")
+    return Path("results", *ckpt.parts[marker + 1:-1], "".join(label))
 
 
 def get_eval_run_identifier(args, postfix=""):
-    """<mode>[_optimal-<o>]_<max_frames>_<step_size>_<T>_<obs_length> with the trainset_/gradientmethod_/<dataset>_
-    prefixes in the reference's order (test_util.py:111-132)."""
-    res = args.inference_mode
-    if hasattr(args, "optimality") and args.optimality is not None:
-        res += f"_optimal-{args.optimality}"
-    res += f"_{args.max_frames}_{args.step_size}_{args.T}_{args.obs_length}"
-    if hasattr(args, "dataset_partition") and args.dataset_partition == "train":
-        res = "trainset_" + res
-    if hasattr(args, "use_gradient_method") and args.use_gradient_method:
-        res = "gradientmethod_" + res
-    if hasattr(args, "override_dataset") and args.override_dataset is not None:
-        res = f"{args.override_dataset}_" + res
-    if postfix != "":
-        res += postfix
-    return res
+    """[<override_dataset>_][gradientmethod_][trainset_]<mode>[_optimal-<o>]_<max_frames>_<step_size>_<T>_<obs_length><postfix>
+    (contract of test_util.py:111-132; attributes that an `args` does not carry count as unset)."""
+    dataset = getattr(args, "override_dataset", None)
+    optimality = getattr(args, "optimality", None)
+    head = "".join([
+        f"{dataset}_" if dataset is not None else "",
+        "gradientmethod_" if getattr(args, "use_gradient_method", False) else "",
+        "trainset_" if getattr(args, "dataset_partition", None) == "train" else "",
+    ])
+    mode = args.inference_mode + (f"_optimal-{optimality}" if optimality is not None else "")
+    window = "_".join(str(v) for v in (args.max_frames, args.step_size, args.T, args.obs_length))
+    return f"{head}{mode}_{window}{postfix}"

@@ -13,8 +13,10 @@ nest:
         --step_size 2 --timestep_respacing ddim50 --vertical_steps 10 --observed_frames x_t_minus_1
 
 Results land where video_eval.py of the reference looks for them (test_util.py naming rules, samples/sample_%04d-%d.npy
-uint8, existing files skipped).  No datasets or checkpoints ship with the reference: videos are synthetic unless a
-checkpoint path is given.
+uint8); the job around the sampler -- dataset items, sample indices, the skip-before-sampling of finished batches -- is
+`video_sample.run`, shared with the windowed CLI.  `adaptive-*` modes (:78,103-113,187,223-234,306 of the reference) pick
+their observed frames per batch item from the current samples before every window; `adaptive_distance='l2'` works on the
+frames themselves, 'lpips' needs `inference_util.set_lpips_embedder`.
 """
 import argparse
 import json
@@ -26,30 +28,47 @@ import torch
 
 from . import inference_util, test_util
 from .script_util import str2bool
-from .video_sample import get_masks, load_model, save_samples
+from .video_sample import add_job_arguments, get_masks, run
 
 logger = logging.getLogger("video_sample_full")
 
 
-def _window(samples, obs_frame_indices, latent_frame_indices, B, device):
-    """video_sample_full.py:127-153 / :233-260 (non-adaptive branch): the window's tensors on the device.  `samples` stays
-    resident on the device for the whole run: the horizontal loop touches every window at every timestep, and a host copy
-    per (timestep, window) pair -- what the reference does -- is a device synchronisation per denoise step."""
-    idx = torch.tensor(list(obs_frame_indices) + list(latent_frame_indices), dtype=torch.int64, device=samples.device)
-    x0 = samples.index_select(1, idx)
-    frame_indices = idx.view(1, -1).repeat((B, 1))
-    obs_mask, latent_mask, kinda_marg_mask = get_masks(x0, len(obs_frame_indices))
-    return [v.to(device) for v in (x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices)]
+def _window(samples, obs_frame_indices, latent_frame_indices, B, device, adaptive=False):
+    """video_sample_full.py:127-153 / :233-260: the window's tensors on the device + (observed, latent) frame counts.
+    `samples` stays resident on the device for the whole run: the horizontal loop touches every window at every timestep,
+    and a host copy per (timestep, window) pair -- what the reference does -- is a device synchronisation per denoise step.
+    Adaptive schedules hand over one index row per batch item; the window is then a per-item gather."""
+    if adaptive:
+        frame_indices = torch.cat([torch.as_tensor(obs_frame_indices, dtype=torch.int64).reshape(B, -1),
+                                   torch.as_tensor(latent_frame_indices, dtype=torch.int64).reshape(B, -1)], dim=1).to(samples.device)
+        x0 = samples[torch.arange(B, device=samples.device)[:, None], frame_indices]
+        n_obs, n_latent = len(obs_frame_indices[0]), len(latent_frame_indices[0])
+    else:
+        idx = torch.tensor(list(obs_frame_indices) + list(latent_frame_indices), dtype=torch.int64, device=samples.device)
+        x0 = samples.index_select(1, idx)
+        frame_indices = idx.view(1, -1).repeat((B, 1))
+        n_obs, n_latent = len(obs_frame_indices), len(latent_frame_indices)
+    obs_mask, latent_mask, kinda_marg_mask = get_masks(x0, n_obs)
+    return [v.to(device) for v in (x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices)], n_obs, n_latent
+
+
+def _write_back(dst, latent_frame_indices, local, n_obs, n_latent, adaptive):
+    """dst[..., latent frames, ...] = the window's latent slots; `dst` / `local` are (B, T, ...) or (B, steps, T, ...)."""
+    if adaptive:
+        for i, li in enumerate(latent_frame_indices):
+            dst[i][..., li, :, :, :] = local[i][..., n_obs:, :, :, :]
+    else:
+        dst[..., latent_frame_indices, :, :, :] = local[..., -n_latent:, :, :, :]
 
 
 @torch.no_grad()
 def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size=1, optimal_schedule_path=None, *,
-                use_gradient_method=False, vertical_steps=0, observed_frames="x_0", save_all_timesteps=False):
-    """video_sample_full.py:50-323 (non-adaptive modes).  `vertical_steps`, `observed_frames` and
-    `save_all_timesteps` are the reference's `args.*` globals.  Returns (samples (B,T,C,H,W) ndarray,
-    all_timestep_samples (B,num_timesteps,T,C,H,W) ndarray or a one-element array)."""
-    if "adaptive" in mode:
-        raise NotImplementedError(f"inference mode {mode!r} needs the LPIPS network (out of scope)")
+                use_gradient_method=False, vertical_steps=0, observed_frames="x_0", save_all_timesteps=False,
+                adaptive_distance="lpips"):
+    """video_sample_full.py:50-323.  `vertical_steps`, `observed_frames` and `save_all_timesteps` are the reference's
+    `args.*` globals; `adaptive_distance` its `distance` (the reference passes 'lpips').  Returns (samples (B,T,C,H,W)
+    ndarray, all_timestep_samples (B,num_timesteps,T,C,H,W) ndarray or a one-element array)."""
+    adaptive = "adaptive" in mode
     B, T, C, H, W = batch.shape
     device = model.device
     batch = batch.to(device=device, dtype=torch.float32)
@@ -64,10 +83,19 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
     else:
         all_timestep_samples = torch.zeros([1])
 
-    def schedule():
-        return iter(inference_util.inference_strategies[mode](
+    def windows():
+        """One pass over the schedule; an adaptive strategy sees the current samples before each of its windows."""
+        it = iter(inference_util.inference_strategies[mode](
             video_length=T, num_obs=obs_length, max_frames=max_frames, step_size=step_size,
-            optimal_schedule_path=optimal_schedule_path))
+            optimal_schedule_path=optimal_schedule_path, **(dict(distance=adaptive_distance) if adaptive else {})))
+        while True:
+            if adaptive:
+                it.set_videos(samples.cpu())
+            try:
+                obs_frame_indices, latent_frame_indices = next(it)
+            except StopIteration:
+                return
+            yield obs_frame_indices, latent_frame_indices
 
     t_tensors = {}
 
@@ -78,11 +106,10 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
 
     if vertical_steps > 0:                                             # :88-200
         vertical_diff_timesteps = list(range(nts))[::-1][:vertical_steps]
-        for obs_frame_indices, latent_frame_indices in schedule():
+        for obs_frame_indices, latent_frame_indices in windows():
             logger.info(f"Conditioning on {sorted(obs_frame_indices)} frames, predicting {sorted(latent_frame_indices)}.")
-            x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices = _window(samples, obs_frame_indices,
-                                                                              latent_frame_indices, B, device)
-            n_latent = len(latent_frame_indices)
+            (x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices), n_obs, n_latent = _window(
+                samples, obs_frame_indices, latent_frame_indices, B, device, adaptive)
             model_kwargs = dict(frame_indices=frame_indices, x0=x0, obs_mask=obs_mask, latent_mask=latent_mask,
                                 kinda_marg_mask=kinda_marg_mask, x_t_minus_1=x0, observed_frames="x_0")
             local_samples = x0.clone()
@@ -93,24 +120,22 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
                                                    use_gradient_method=use_gradient_method)["sample"]
                 if save_all_timesteps:
                     all_local.append(local_samples.clone())
-            samples[:, latent_frame_indices] = local_samples[:, -n_latent:]
+            _write_back(samples, latent_frame_indices, local_samples, n_obs, n_latent, adaptive)
             if save_all_timesteps:
-                all_local = torch.stack(all_local, dim=1)
-                all_timestep_samples[:, :len(vertical_diff_timesteps), latent_frame_indices] = \
-                    all_local[:, :len(vertical_diff_timesteps), -n_latent:]
+                _write_back(all_timestep_samples[:, :len(vertical_diff_timesteps)], latent_frame_indices,
+                            torch.stack(all_local, dim=1), n_obs, n_latent, adaptive)
 
     horizontal = []
     for timestep in list(range(nts))[::-1][vertical_steps:]:           # :202-315
-        for obs_frame_indices, latent_frame_indices in schedule():
-            x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices = _window(samples, obs_frame_indices,
-                                                                              latent_frame_indices, B, device)
-            n_latent = len(latent_frame_indices)
+        for obs_frame_indices, latent_frame_indices in windows():
+            (x0, obs_mask, latent_mask, kinda_marg_mask, frame_indices), n_obs, n_latent = _window(
+                samples, obs_frame_indices, latent_frame_indices, B, device, adaptive)
             local_samples = diffusion.p_sample(
                 model, x0, t=t_of(timestep, x0.shape[0]), clip_denoised=True,
                 model_kwargs=dict(frame_indices=frame_indices, x0=x0, obs_mask=obs_mask, latent_mask=latent_mask,
                                   kinda_marg_mask=kinda_marg_mask, x_t_minus_1=x0, observed_frames=observed_frames),
                 return_attn_weights=False, use_gradient_method=use_gradient_method)["sample"]
-            samples[:, latent_frame_indices] = local_samples[:, -n_latent:]
+            _write_back(samples, latent_frame_indices, local_samples, n_obs, n_latent, adaptive)
         if save_all_timesteps:
             horizontal.append(samples.clone())
     if save_all_timesteps and horizontal:
@@ -119,59 +144,20 @@ def infer_video(mode, model, diffusion, batch, max_frames, obs_length, step_size
     return samples.cpu().numpy(), all_timestep_samples.cpu().numpy()
 
 
+def _infer(args, model, diffusion, batch, optimal_schedule_path):
+    return infer_video(args.inference_mode, model, diffusion, batch, args.max_frames, args.obs_length, args.step_size,
+                       optimal_schedule_path, use_gradient_method=args.use_gradient_method, vertical_steps=args.vertical_steps,
+                       observed_frames=args.observed_frames, save_all_timesteps=args.save_all_timesteps,
+                       adaptive_distance=args.adaptive_distance)
+
+
 def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("checkpoint_path", nargs="?", default="")
-    ap.add_argument("--eval_dir", default=None)
-    ap.add_argument("--inference_mode", default="autoreg", choices=sorted(inference_util.inference_strategies))
-    ap.add_argument("--T", type=int, default=16, help="video length")
-    ap.add_argument("--max_frames", type=int, default=10)
-    ap.add_argument("--obs_length", type=int, default=4)
-    ap.add_argument("--step_size", type=int, default=1)
+    """The reference's option surface (video_sample_full.py:560-690) = the windowed CLI's + --vertical_steps."""
+    ap = add_job_arguments(argparse.ArgumentParser())
     ap.add_argument("--vertical_steps", type=int, default=0)
-    ap.add_argument("--observed_frames", default="x_0", choices=["x_0", "x_t", "x_t_minus_1"])
-    ap.add_argument("--save_all_timesteps", type=str2bool, nargs="?", const=True, default=False)
-    ap.add_argument("--use_ddim", type=str2bool, nargs="?", const=True, default=False)
-    ap.add_argument("--timestep_respacing", default="ddim50")
-    ap.add_argument("--batch_size", type=int, default=2)
-    ap.add_argument("--num_videos", type=int, default=2)
-    ap.add_argument("--sample_idx", type=int, default=0)
-    ap.add_argument("--image_size", type=int, default=64)
-    ap.add_argument("--num_channels", type=int, default=128)
-    ap.add_argument("--num_res_blocks", type=int, default=2)
-    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--adaptive_distance", default="l2", choices=["l2", "lpips"])
     args = ap.parse_args(argv)
-    logging.basicConfig(level=logging.INFO)
-    from . import dist as vdist
-    rank, local_rank, world = vdist.init()
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
-    torch.manual_seed(args.seed + rank)
-    model, diffusion = load_model(args, device, rank, world)      # rank 0 reads the checkpoint; one broadcast of the packed image
-    # results/<...>/<run identifier>/ (test_util.py:65-132, video_sample_full.py:712-724); synthetic runs have no
-    # checkpoint.  Derived on rank 0 only (a '*latest' checkpoint is opened there for its step) and sent to the others.
-    out_dir = None
-    if rank == 0:
-        if args.eval_dir is None and not args.checkpoint_path:
-            args.eval_dir = "results/synthetic"
-        out_dir = test_util.get_model_results_path(args) / test_util.get_eval_run_identifier(args)
-        os.makedirs(out_dir / "samples", exist_ok=True)
-        json_path = out_dir / "model_config.json"
-        if not json_path.exists():
-            with test_util.Protect(json_path):
-                with open(json_path, "w") as f:
-                    json.dump(model.config, f, indent=4)
-    out_dir = vdist.broadcast_object(out_dir, src=0)
-    n_tasks = (args.num_videos + args.batch_size - 1) // args.batch_size
-    for task in vdist.task_ids(n_tasks, rank, world):
-        idx = vdist.indices_for_task(task, args.batch_size, args.num_videos)
-        g = torch.Generator().manual_seed(1234 + task)
-        batch = torch.rand(len(idx), args.T, 3, args.image_size, args.image_size, generator=g) * 2 - 1
-        recon, _ = infer_video(args.inference_mode, model, diffusion, batch, args.max_frames, args.obs_length, args.step_size,
-                               vertical_steps=args.vertical_steps, observed_frames=args.observed_frames)
-        for p in save_samples(recon, str(out_dir), first_index=idx[0], sample_idx=args.sample_idx):
-            logger.info(f"*** Saved {p} ***")
-    vdist.barrier()
+    return run(args, infer=_infer)
 
 
 if __name__ == "__main__":
