@@ -104,13 +104,16 @@ int vd_set_model_mean_type(vd_engine* e, int type);
 
 /* Timestep indices outside [0, num_timesteps) make the reference raise IndexError (_extract_into_tensor,
  * gaussian_diffusion.py:1019-1031).  The step entry points stay asynchronous: such a batch element is written as NaN
- * and a sticky device flag is set; this call copies the flags to the host (it SYNCHRONISES), clears them, and the host
+ * and a sticky device flag is set; this call waits for the whole DEVICE (steps issued on any stream, non-blocking side streams included, have finished),
+ * copies the flags to the host, clears them, and the host
  * mirror raises IndexError.  bit 0: timestep index out of range.
  * bit 1: the network output a step consumed was not finite.  The reference would carry the NaN into its sample; here the clamp
  * of clip_denoised would turn it into a plausible -1, so the posterior kernels keep such an element NaN and set this bit
  * (vd_p_sample, vd_ddim_sample, vd_p_mean_variance, vd_posterior_update, vd_posterior_from_xstart, vd_vb_terms, vd_guided_step,
  * the window executor's captured step).  In the default f16x3 arithmetic (two fp16 pieces per fp32 operand) this is how an
- * activation beyond fp16's range (|x| > 65504) anywhere in the network shows: VD_MATH=bf16x6 carries the full fp32 range.
+ * operand beyond the split's range (|x| >= 2^15 = 32768: the scaled remainder (x - a0) 2^12 then leaves fp16; for a 3x3 conv the operand
+ * is the Winograd-domain value, a signed sum of four inputs, so |input| < 2^13 is safe) anywhere in the network shows: VD_MATH=bf16x6
+ * carries the full fp32 range.
  * The host mirror raises FloatingPointError. */
 int vd_device_errors(vd_engine* e, int* flags);
 
@@ -273,8 +276,9 @@ const char* vd_profile_class_name(int i);
 
 /* ---- arithmetic of the matrix products (environment VD_MATH, read once per process) -------------
  *   0  f16x3  (default) an fp32 operand x is carried as two fp16 pieces, x ~ a0 + 2^-12 a1, a0 = f16(x), a1 = f16((x - a0) 2^12):
- *             22 significand bits (relative error <= 2^-22 for 2^-14 <= |x| <= 65504, absolute <= 2^-37 below; larger |x| -> NaN,
- *             never a silently wrong number); a product is three piece products a0 b0 + a0 b1 + a1 (2^-12 b0) on
+ *             22 significand bits (relative error <= 2^-22 for 2^-14 <= |x| < 2^15, absolute <= 2^-37 below; |x| >= 2^15 = 32768 -- not
+ *             fp16's 65504: the scaled remainder (x - a0) 2^12 reaches 65536 there -- gives NaN, never a silently wrong number; inputs of
+ *             a 3x3 conv: |x| < 2^13, its operand is a signed sum of four of them); a product is three piece products a0 b0 + a0 b1 + a1 (2^-12 b0) on
  *             v_mfma_f32_32x32x16_f16 with fp32 accumulation; weights carry a per-output power-of-two scale (image trailer).
  *   1  bf16x6 the exact split: three bf16 pieces per operand, six piece products (the default of earlier releases).
  *   2  fp32   every product on v_mfma_f32_32x32x2_f32.

@@ -1449,3 +1449,187 @@ def test_round5_fusions_leave_the_bits_alone():
         shas[name] = json.loads(r.stdout.strip().splitlines()[-1])
     for name in ("per_block_rpe", "materialised_activations"):
         assert shas[name]["tiny"] == shas["default"]["tiny"] and shas[name]["full64"] == shas["default"]["full64"], (name, shas)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 6: the sampling job end to end, the adaptive vertical / horizontal sampler
+def test_sampling_cli_from_a_checkpoint_file_writes_the_oracles_videos_and_resumes_without_a_step(tmp_path, monkeypatch):
+    """`video_sample.run()` -- the body of the CLI -- on the REAL engine: a checkpoint FILE {'state_dict','config','step'} under a
+    '*checkpoints*' directory, test videos from a .npy file, ddim5, two batches x two sample indices; the written uint8 files are
+    compared with the same job run on the CPU oracle with the identical noise draws, the directory with the reference's naming rules
+    (test_util.py:65-132); a second run finds every file and issues ZERO p_sample calls (video_sample.py:231-239)."""
+    from argparse import Namespace
+    from video_diffusion_amd import gaussian_diffusion as gdm
+    from video_diffusion_amd import inference_util as iu
+    from video_diffusion_amd import video_sample as vs
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=4, rp_beta=4, rp_gamma=4, timestep_respacing="ddim5")}
+    model, _, ora = _oracle(cfg)
+    ck = tmp_path / "my-checkpoints" / "exp7" / "ema_0.9999_latest.pt"
+    ck.parent.mkdir(parents=True)
+    saved_cfg = {k: v for k, v in cfg.items() if k != "timestep_respacing"}
+    saved_cfg.update(timestep_respacing="", max_frames=4)                 # what a training run records; the CLI overrides respacing
+    torch.save({"state_dict": synth_sd(model.param_specs()), "config": saved_cfg, "step": 1234}, ck)
+    vids = torch.rand(3, 6, 3, 32, 32, generator=torch.Generator().manual_seed(77)) * 2 - 1
+    np.save(tmp_path / "videos.npy", vids.numpy())
+    monkeypatch.chdir(tmp_path)
+
+    def args():
+        return Namespace(checkpoint_path=str(ck), videos=str(tmp_path / "videos.npy"), synthetic=False, inference_mode="autoreg",
+                         T=None, max_frames=None, obs_length=2, step_size=2, batch_size=2, num_videos=0, timestep_respacing="ddim5",
+                         observed_frames="x_0", image_size=32, num_channels=32, num_res_blocks=1, seed=0, adaptive_distance="l2",
+                         executor="eager", eval_dir=None, out_dir=None, use_ddim=False, sample_idx=None, num_samples=2, indices=None,
+                         task_id=None, subset_size=None, optimality=None, use_gradient_method=False, save_all_timesteps=False)
+
+    draws, gen, calls = [], torch.Generator().manual_seed(5), []
+
+    def fake_randn_like(x, *a, **k):
+        z = torch.randn(x.shape, generator=gen)
+        draws.append(z)
+        return z.to(x.device)
+
+    real_p_sample = gdm.GaussianDiffusion.p_sample
+
+    def counting_p_sample(self, *a, **k):
+        calls.append(1)
+        return real_p_sample(self, *a, **k)
+
+    monkeypatch.setattr(gdm.th, "randn_like", fake_randn_like)
+    monkeypatch.setattr(gdm.GaussianDiffusion, "p_sample", counting_p_sample)
+    out = vs.run(args(), device=torch.device("cuda", 0))
+    assert str(out) == "results/exp7/ema_0.9999_latest_1234_respaceddim5/autoreg_None_2_None_2"
+    files = sorted(os.listdir(tmp_path / out / "samples"))
+    assert files == [f"sample_{i:04d}-{s}.npy" for i in range(3) for s in range(2)]
+    n_windows, n_steps = 2, 5
+    assert len(calls) == 2 * 2 * n_windows * n_steps and len(draws) == len(calls)           # 2 batches x 2 sample indices
+    # the same job on the oracle: batches (0, 1), (2,); per batch sample 0 then sample 1; the noise in the order it was drawn
+    it = iter(draws)
+    worst, off = 0, 0
+    for ids in ([0, 1], [2]):
+        for s in range(2):
+            batch = vids[ids]
+            B = len(ids)
+            samples = torch.zeros_like(batch)
+            samples[:, :2] = batch[:, :2]
+            for obs_idx, lat_idx in iu.inference_strategies["autoreg"](video_length=6, num_obs=2, max_frames=4, step_size=2):
+                x0 = torch.cat([samples[:, obs_idx], samples[:, lat_idx]], dim=1).clone()
+                om, lm, km = vs.get_masks(x0, len(obs_idx))
+                kw = dict(x0=x0, obs_mask=om, latent_mask=lm, kinda_marg_mask=km, frame_indices=torch.tensor(obs_idx + lat_idx).repeat(B, 1))
+                local = x0.clone()
+                for ts in range(n_steps)[::-1]:
+                    local = ora.p_sample(local, torch.tensor([ts] * B), kw, next(it))["sample"]
+                samples[:, lat_idx] = local[:, -len(lat_idx):]
+            want = vs.to_uint8(samples.numpy())
+            for j, i in enumerate(ids):
+                got = np.load(tmp_path / out / "samples" / f"sample_{i:04d}-{s}.npy")
+                assert got.dtype == np.uint8 and got.shape == (6, 3, 32, 32)
+                d = np.abs(got.astype(int) - want[j].astype(int))
+                worst, off = max(worst, int(d.max())), off + int((d > 0).sum())
+                assert np.array_equal(got[:2], want[j][:2])              # observed frames: the same truncation of the same floats
+    # 10 chained ddim5 steps of drift (<= 3e-2 on a handful of elements, test_infer_video_autoreg_vs_oracle) = a few grey levels at most;
+    # a value within float error of a level boundary truncates either way
+    assert worst <= 4 and off < 0.01 * 6 * 6 * 3 * 32 * 32, (worst, off)
+    mc = json.load(open(tmp_path / out / "model_config.json"))
+    assert mc["timestep_respacing"] == "ddim5" and mc["num_channels"] == 32
+    # resume: everything is on disk -> not one denoise step, not one draw, no file touched
+    stamps = {f: os.path.getmtime(tmp_path / out / "samples" / f) for f in files}
+    del calls[:], draws[:]
+    out2 = vs.run(args(), device=torch.device("cuda", 0))
+    assert out2 == out and calls == [] and draws == []
+    assert stamps == {f: os.path.getmtime(tmp_path / out / "samples" / f) for f in files}
+    # --save_all_timesteps on one new sample index: the three extra files of video_sample.py:209-230,273-298
+    a = args()
+    a.sample_idx, a.save_all_timesteps, a.indices = 5, True, [1]
+    vs.run(a, device=torch.device("cuda", 0))
+    every = np.load(tmp_path / out / "samples" / "all_timestep_sample_0001-5.npy")
+    final = np.load(tmp_path / out / "samples" / "sample_0001-5.npy")
+    q_all = np.load(tmp_path / out / "samples" / "q_sample_0001-5.npy")
+    err = np.load(tmp_path / out / "samples" / "error_0001-5.npy")
+    assert every.shape == (5, 6, 3, 32, 32) and every.dtype == np.uint8 and q_all.shape == err.shape == every.shape
+    assert np.array_equal(every[-1], final) and np.array_equal(every[0, :2], final[:2])      # the last step IS the sample; observed frames in every step
+    assert np.isfinite(err).all() and np.abs(q_all[0] - vids[1].numpy()).max() < 1.0          # t = 0 of ddim5: almost the clean video
+
+
+def test_full_sampler_adaptive_autoreg_vs_oracle(monkeypatch):
+    """scripts/video_sample_full.py:78,103-113,187,223-234,306: `adaptive-*` in the vertical + horizontal sampler -- the strategy
+    sees the current samples before every window of every pass and hands back one index row per batch item.  distance='l2', 2
+    vertical + 3 horizontal ddim5 steps, against the same loop nest on the CPU oracle with identical noise draws."""
+    from video_diffusion_amd import gaussian_diffusion as gdm
+    from video_diffusion_amd import inference_util as iu
+    from video_diffusion_amd.video_sample import get_masks
+    from video_diffusion_amd.video_sample_full import infer_video
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=4, rp_beta=4, rp_gamma=4, timestep_respacing="ddim5")}
+    model, diff, ora = _oracle(cfg)
+    B, T, obs_len, max_frames, step, vertical = 2, 7, 3, 4, 2, 2
+    batch = torch.rand(B, T, 3, 32, 32, generator=torch.Generator().manual_seed(31)) * 2 - 1
+    draws, gen = [], torch.Generator().manual_seed(32)
+
+    def fake_randn_like(x, *a, **k):
+        z = torch.randn(x.shape, generator=gen)
+        draws.append(z)
+        return z.to(x.device)
+
+    monkeypatch.setattr(gdm.th, "randn_like", fake_randn_like)
+    got, every = infer_video("adaptive-autoreg", model, diff, batch.cuda(), max_frames, obs_len, step, vertical_steps=vertical,
+                             observed_frames="x_0", adaptive_distance="l2", save_all_timesteps=True)
+    monkeypatch.undo()
+
+    samples = torch.zeros_like(batch)
+    samples[:, :obs_len] = batch[:, :obs_len]
+    it = iter(draws)
+
+    def one_pass(timesteps):
+        sched = iter(iu.inference_strategies["adaptive-autoreg"](distance="l2", video_length=T, num_obs=obs_len,
+                                                                 max_frames=max_frames, step_size=step))
+        n = 0
+        while True:
+            sched.set_videos(samples)
+            try:
+                obs_idx, lat_idx = next(sched)
+            except StopIteration:
+                return n
+            fi = torch.cat([torch.tensor(obs_idx).reshape(B, -1), torch.tensor(lat_idx).reshape(B, -1)], dim=1)
+            x0 = torch.stack([samples[i, f] for i, f in enumerate(fi)]).clone()
+            om, lm, km = get_masks(x0, len(obs_idx[0]))
+            kw = dict(x0=x0, obs_mask=om, latent_mask=lm, kinda_marg_mask=km, frame_indices=fi)
+            local = x0.clone()
+            for ts in timesteps:
+                local = ora.p_sample(local, torch.tensor([ts] * B), kw, next(it))["sample"]
+            for i, li in enumerate(lat_idx):
+                samples[i, li] = local[i, len(obs_idx[0]):]
+            n += 1
+
+    steps = list(range(diff.num_timesteps))[::-1]
+    assert one_pass(steps[:vertical]) == 2
+    for ts in steps[vertical:]:
+        assert one_pass([ts]) == 2
+    assert len(draws) == 2 * vertical + 2 * (len(steps) - vertical) and next(it, None) is None
+    err = np.abs(got - samples.numpy())
+    assert err.mean() < 2e-4, err.mean()
+    close(got, samples.numpy(), atol=3e-2, rtol=1e-2)
+    assert np.array_equal(got[:, :obs_len], batch[:, :obs_len].numpy())
+    assert every.shape == (B, 5, T, 3, 32, 32) and np.array_equal(every[:, -1], got)       # the last horizontal pass is the result
+
+
+def test_bench_two_rank_launch_path_runs_on_the_box():
+    """The N > 1 path of `bench.py --gpus N` as the driver starts it on the 8-GPU node -- self-launch of one process per rank,
+    rendezvous on 127.0.0.1, the layout-id all-reduce, the ONE packed-weight broadcast, barrier + max-over-ranks timing -- executed
+    on this one-GPU box every round: two ranks over gloo, both on device 0 (RCCL refuses two ranks on one GPU; the 8-GPU run is the
+    driver's).  No scaling number is read off this.  Reference fan-out: improved_diffusion/command_launchers.py:32-62."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    err1 = os.path.join(root, "gpurun_out", "rank1.err")
+    if os.path.exists(err1):
+        os.remove(err1)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-fp32-ref", "--no-dropin", "--no-full-window", "--no-roofline"],
+                       env={**os.environ, "VD_BENCH_BACKEND": "gloo", "VD_BENCH_ALL_ON_DEVICE0": "1"}, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["scaling"] == "weak", line
+    assert line["steps"] == 2 and line["warmup"] == 1 and np.isfinite(line["value"]) and line["value"] > 0
+    assert abs(line["value"] - 2 * 1000.0 / line["ms_per_step"]) < 1e-2 * line["value"]      # whole-job steps/s = ranks x steps / slowest rank's time
+    rank1 = open(err1).read() if os.path.exists(err1) else ""
+    assert [l for l in rank1.splitlines() if l.strip() and "amdgpu.ids" not in l] == [], rank1[-2000:]

@@ -150,6 +150,17 @@ struct ProfScope {
     ~ProfScope() { if (live) (void)hipEventRecord(g_prof.recs.back().b, st); }
 };
 
+// res_block decides from the SHAPE alone (conv_wino_z128_act_shape) that a conv activates in its own patch staging and then never
+// materialises the activation image; the dispatcher takes the activating kernel only when conv_wino_z128_act_supported holds for the
+// call as built (weight image, piece count, strides, size limits).  If the two ever disagree the conv would get a raw tensor plus
+// (A, B) that no other kernel applies: say so here, by name, instead of failing later with the generic "no kernel covers" error.
+static bool act_conv_will_dispatch(const IgemmArgs& g) {
+    IgemmArgs one = g;
+    one.nfr = std::max(1, std::min(g.nfr, igemm_frames_per_launch(g)));
+    one.M = one.nfr * g.Ho * g.Wo;
+    return conv_wino_z128_act_supported(one);
+}
+
 static int igemm_p(const IgemmArgs& g, hipStream_t st, int cin_alg = 0) {
     const double taps = (double)g.ksz * g.ksz, cin = cin_alg ? cin_alg : g.Cin;
     const double in_pix = (double)g.nfr * g.Hs * g.Ws;
@@ -790,6 +801,8 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
             g.out = h; g.ldo = r.cout; g.Cout = r.cout; g.stats = ht.part; g.stats_split = ht.split;
             g.ksplit_ws = ksw; g.ksplit_ws_floats = ksf;
             if (!cfg.use_scale_shift_norm) { g.fbias = film; g.fbias_ld = film_total; }    // h + emb_out (unet.py:196)
+            VD_REQUIRE(!za1 || act_conv_will_dispatch(g), "res_block: in_layers conv was planned on conv_wino_z128's activating form (no activation image "
+                                                          "written) but the call as built is not one it takes");
             if ((rc = igemm_p(g, st))) return rc;
         }
         ar.release(mk);
@@ -825,6 +838,8 @@ int vd_engine::res_block(const ResP& r, Tens x0, const Tens* x1, int N, const fl
             g.res = skip; g.res_ld = r.cout; g.out = o; g.ldo = r.cout; g.Cout = r.cout;
             g.stats = ot.part; g.stats_split = ot.split;
             g.ksplit_ws = ksw; g.ksplit_ws_floats = ksf;
+            VD_REQUIRE(!za2 || act_conv_will_dispatch(g), "res_block: out_layers conv was planned on conv_wino_z128's activating form (no activation image "
+                                                          "written) but the call as built is not one it takes");
             if ((rc = igemm_p(g, st))) return rc;
         }
         ar.release(mk);
@@ -1692,8 +1707,12 @@ int vd_device_errors(vd_engine* e, int* flags) {
     VD_REQUIRE(e && flags, "null argument");
     *flags = 0;
     if (!e->d_err) return 0;
-    VD_HIP(hipMemcpy(flags, e->d_err, sizeof(int), hipMemcpyDeviceToHost));       // synchronises
-    if (*flags) VD_HIP(hipMemset(e->d_err, 0, sizeof(int)));
+    // The steps may have run on any stream -- torch's side streams are non-blocking, and a NULL-stream copy is not ordered behind
+    // those: wait for the whole device first, so that the word read is the word every step issued so far has left, and the clear
+    // cannot race a step still in flight (read + clear are then two operations on an idle device).
+    VD_HIP(hipDeviceSynchronize());
+    VD_HIP(hipMemcpy(flags, e->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (*flags) { VD_HIP(hipMemset(e->d_err, 0, sizeof(int))); VD_HIP(hipDeviceSynchronize()); }
     return 0;
 }
 

@@ -458,7 +458,7 @@ class GaussianDiffusion:
                         per_item = r / r.mean() * per_item.mean()
                     acc = acc + per_item / (self.num_timesteps / 4)
                 attns[tag] = acc
-        getattr(model, "check_device_errors", lambda: None)()       # the loop's end synchronises anyway: a non-finite network output / bad index of ANY step surfaces here
+        getattr(model, "check_device_errors", lambda: None)()       # waits for the device (every stream): a non-finite network output / bad index of ANY step surfaces here, not in a later loop
         return final["sample"], attns
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,

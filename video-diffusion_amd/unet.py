@@ -277,7 +277,8 @@ class CondMargVideoModel:
         return int(_lib.lib().vd_weights_layout_id(self._handle))
 
     def check_device_errors(self):
-        """Synchronise and raise what the reference would have raised eagerly: an out-of-range timestep index is an
+        """Synchronise the DEVICE (every stream: the steps may have been issued under `torch.cuda.stream(s)`) and raise what the
+        reference would have raised eagerly: an out-of-range timestep index is an
         IndexError in `_extract_into_tensor` (gaussian_diffusion.py:1019-1031); the asynchronous HIP step poisons the
         output with NaN and records it in a sticky device flag instead.  A network output that is not finite (bit 1: an
         fp16-range overflow of the f16x3 arithmetic, or NaN weights / inputs) is a FloatingPointError naming the way out."""
@@ -289,7 +290,7 @@ class CondMargVideoModel:
             raise FloatingPointError(
                 "a denoise step consumed a network output that is not finite (device flag set by an earlier step; the affected "
                 "elements of its result are NaN).  In the default arithmetic VD_MATH=f16x3 fp32 operands travel as two fp16 pieces: "
-                "an activation beyond fp16's range (|x| > 65504) overflows -- set VD_MATH=bf16x6 (exact three-piece split, full "
+                "an operand beyond the split's range (|x| >= 2^15; inputs of a 3x3 conv: 2^13) overflows -- set VD_MATH=bf16x6 (exact three-piece split, full "
                 "fp32 exponent range) on every rank and reload the weights")
 
     # -- forward ---------------------------------------------------------------------------------------
