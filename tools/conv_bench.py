@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--only", type=int, default=0, help="only layers with this output resolution")
     ap.add_argument("--quick", action="store_true", help="six representative layers only (kernel ablations)")
+    ap.add_argument("--r64", action="store_true", help="only the layers conv_wino_r64.hip's 64-cout block serves (no Upsample forms)")
     ap.add_argument("--act", action="store_true", help="time conv_wino_z128.hip's activating form (vd_op_conv_wino_act) on the shapes it serves, next to "
                                                        "the materialising pair it replaces (vd_op_affine_act + the plain conv)")
     args = ap.parse_args()
@@ -37,6 +38,8 @@ def main():
         if (args.only and H != args.only) or (args.quick and ((Cin, Cout, H) not in QUICK or ups)):
             continue
         nfr, Hs = args.frames, H >> ups
+        if args.r64 and (ups or L.vd_conv_wino_block_couts(nfr, H, Cin, Cout) != 64):
+            continue
         x0 = torch.rand(nfr, Hs, Hs, Cin, device="cuda") - 0.5
         w = (torch.rand(Cout, Cin, 3, 3) - 0.5) * (12.0 / (9 * Cin)) ** 0.5
         # VD_CONV_BENCH_DATA=zero_x | zero_w | const: the same instruction stream on operands that do not toggle (a kernel that gets faster on
@@ -45,6 +48,8 @@ def main():
         if data == "zero_x": x0.zero_()
         if data == "zero_w": w.zero_()
         if data == "const": x0.fill_(0.25); w.fill_(0.125)
+        if data == "f16pairs":   # every fp32 word = two fp16 values of N(0, 1/4): what a pre-split (a0, a1) operand would put on the wires (-DVD_R64_ABL=34 builds)
+            x0 = (torch.randn(nfr, Hs, Hs, 2 * Cin, device="cuda") * 0.5).half().view(torch.float32).contiguous()
         b, res = torch.rand(Cout, device="cuda"), torch.rand(nfr, H, H, Cout, device="cuda")
         out = torch.empty(nfr, H, H, Cout, device="cuda")
         part = torch.empty(nfr, L.vd_conv_stats_split(H), Cout, 2, dtype=torch.float64, device="cuda")

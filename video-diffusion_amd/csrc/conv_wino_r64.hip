@@ -50,11 +50,14 @@ template <bool TF4> struct R64G {
     static constexpr int XBUF = NX * 4096;
     static constexpr int MOFF = TF4 ? 2 * FSB : 8 * RSB;    // second M-tile: two frames / four tile rows further
 };
+#ifndef VD_R64_ABL
+#define VD_R64_ABL 0       // timing-only builds of the main loop, see below
+#endif
 namespace r64 {
 constexpr int NB = 4;                       // patch buffers
 // 4 patch buffers (98304 | 131072 bytes; the Z image, 64 KB, overlays them) + one more that only ever receives the requests
 // past the item's last chunk (see x_dma): 122880 | 163840
-template <bool TF4> constexpr int lds_bytes() { return (NB + 1) * R64G<TF4>::XBUF; }
+template <bool TF4> constexpr int lds_bytes() { return (VD_R64_ABL & 32) ? 163840 : (NB + 1) * R64G<TF4>::XBUF; }
 }  // namespace r64
 
 #ifdef VD_WINO_TIMING
@@ -85,9 +88,13 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #define VD_R64_REGSTAGE 0  // 1: f16x3, the patch staged through registers (buffer_load_dwordx4 -> ds_write_b128) instead of LDS-DMA.  In conv_wino_z128.hip that
 #endif                     // is worth 8 % (r05s: 417 -> 385 us at 128 -> 128 @ 64^2); HERE it is 2 - 9 % SLOWER on every layer (r05t: class 14.42 -> 14.71 ms;
                            // no spills, 11.02 instructions per MFMA against 10.98): this loop has no issue slots left for 12 more requests per chunk pair
-#ifndef VD_R64_ABL
-#define VD_R64_ABL 0       // timing-only builds of the main loop (results WRONG; tools/build_variant.sh): bit 0 no weight reloads, 1 no
-#endif                     // transform / split, 2 no patch requests, 3 no patch reads, 4 no MFMA -- never set in the product library
+// VD_R64_ABL: timing-only builds of the main loop (results WRONG; tools/build_variant.sh): bit 0 no weight reloads, 1 no
+// transform / split, 2 no patch requests, 3 no patch reads, 4 no MFMA -- never set in the product library
+// bit 5 (with bit 1): the loop as it would be if the A operand arrived ALREADY transformed and split (review r5 item 1a: V = B^T d B as
+// (a0, a1) fp16 pairs written once per layer by a pre-pass): no transform / split, HALF the LDS reads (two ds_read_b128 per position instead
+// of four), and the staging traffic of the V image -- 64 tiles x 16 positions x 16 channels x 4 B = 64 KB per chunk instead of the 24 / 32 KB
+// patch: 16 - NX more LDS-DMA requests per thread and chunk, one per slot, read from the output buffer (one 4 KB line per request, the same
+// lines for the cout blocks of a patch, as V would be shared) into LDS beyond the patch buffers.  A best case: no pre-pass is timed.
 
 // block -> (tile group, first cout tile): blocks are dealt to the 8 XCDs round-robin; inside an XCD the cout blocks of one
 // patch are neighbours
@@ -149,6 +156,9 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     const int byy = bx % g.tiles_y; bx /= g.tiles_y;
     const int f0 = TF4 ? bx * 4 : bx;                                 // first frame of the item
     const int ox0 = bxx * 16, oy0 = byy * 16;                        // TF4: the whole 8 x 8 map (tiles_x = tiles_y = 1)
+#if VD_R64_ABL & 32
+    const int patch_id = (f0 * g.tiles_y + byy) * g.tiles_x + bxx;
+#endif
 
     // ---- patch staging: thread -> 16-byte LDS slots e*256 + tid; the slot at quad position lq of patch row py holds the
     // pixel's quad lq ^ ((py >> 1) & 3)
@@ -182,6 +192,17 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
 #pragma unroll
         for (int e = 0; e < NX; ++e) x_dma_one(chunk, e);
     };
+#if VD_R64_ABL & 32
+    const unsigned xtra_bytes = (unsigned)(a.nfr * Hl * Wl * a.ldo * 4);
+    const auto xtra_src = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, xtra_bytes, 0x00020000);
+    const unsigned xtra_span = (unsigned)((nchunk + 4) * (16 - NX) * 4096);                    // the PATCH's lines (shared by its cout blocks)
+    const unsigned xtra_base = ((unsigned)patch_id * xtra_span) % (xtra_bytes - xtra_span) + (unsigned)(tid * 16);
+    auto x_extra = [&](int chunk, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xtra_src, (lds_ptr)(lds + NB * XBUF + i * 4096 + wi * 1024), 16, xtra_base, (chunk * (16 - NX) + i) * 4096, 0, 0);
+#endif
+    };
+#endif
 
     // ---- register staging (F16 && VD_R64_REGSTAGE): patch p is requested into `stg` in group (p - 3, 1) position 0 and written to its buffer
     // in group (p - 2, 0) before the position that may carry the barrier; same LDS image (the thread's slots e * 256 + tid, the quad swizzle on
@@ -220,7 +241,7 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             stx[h] = *reinterpret_cast<const f32x4*>(rb + adr[0][h]);
-            sts[h] = *reinterpret_cast<const f32x4*>(rb + adr[1][h]);
+            if (!(VD_R64_ABL & 32)) sts[h] = *reinterpret_cast<const f32x4*>(rb + adr[1][h]);
         }
     };
     auto t_fma1 = [&](int c, int e) {          // plain v_fma_f32: hipcc pairs these into v_pk_fma_f32, which does not co-issue with the MFMA
@@ -487,11 +508,19 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                             if (m == 0 && (li == 0 || li == 1) && k >= 12 - NX) x_dma_one(chunk + 2 + li, k - (12 - NX));   // the last NX slots of positions 0, 1
                         }
                     }
+#if VD_R64_ABL & 32
+                    if (cpar == 0 && F16) {                          // the V image's extra staging requests: 2 * (16 - NX) per chunk pair, one per slot
+                        const int slot = m == 0 ? (li - 1) * 6 + k : (li == 0 ? (NP - 1) * 6 + k : 99);
+                        if ((m == 1 || li > 0) && slot < 2 * (16 - NX)) x_extra(chunk + slot / (16 - NX), slot % (16 - NX));
+                    }
+#endif
                     if (VD_R64_ABL & 16) {}
                     else if constexpr (F16) acc[m][j][n] = r64_mfma<true>(af[cur][PA3[q]], bfr[j][n][PB3[q]], acc[m][j][n]);
                     else acc[m][j][n] = r64_mfma<false>(af[cur][PA6[q]], bfr[j][n][PB6[q]], acc[m][j][n]);
                     if (B2R && m == 0 && (k == 1 || k == 2)) b_third(j, k - 1);      // first read in slot 4 / 5; the M-tile group m = 1 finds it in place
-                    if (VD_R64_ABL & 2) {}
+                    if (VD_R64_ABL & 32) {                          // the two ds_read_b128 of a position ARE its fragment's pieces
+                        if (k == 4) { af[nxt][0] = __builtin_bit_cast(u32x4, stx[0]); af[nxt][1] = __builtin_bit_cast(u32x4, stx[1]); }
+                    } else if (VD_R64_ABL & 2) {}
                     else if constexpr (F16) {
                         if (k < 4) f16_slot_a(cur, nxt, k, jn, k == 3);
                         else if (k == 4) f16_slot_b(nxt, ORDa[li]);
@@ -766,7 +795,10 @@ int launch_conv_wino_r64(const IgemmArgs& a, hipStream_t s) {
     g.ncb = a.Cout / 64;
     g.nitems = g.nbx * g.ncb;
     g.xcd_order = g.nbx % 8 == 0;
-    // (the grouped cout walk of the sub-pixel form changes nothing here: 2 .. 8 cout blocks per patch, headline 27.55 ms with groups of 0 / 2 / 4)
+    // (the grouped cout walk of the sub-pixel form changes nothing here: 2 .. 8 cout blocks per patch, headline 27.55 ms with groups of 0 / 2 / 4;
+    // re-measured in round 6 on the f16x3 kernel through VD_R64_CGROUP, LAB_NOTES R6)
+    static const int env_cgroup = getenv("VD_R64_CGROUP") ? atoi(getenv("VD_R64_CGROUP")) : 0;
+    if (env_cgroup > 0 && g.xcd_order && g.ncb % env_cgroup == 0) g.cgroup = env_cgroup;
     // split-K only with scratch from the caller (the engine's arena; the single-operator entry points run one slice)
     g.ksplit = a.ksplit_ws && a.ksplit_ws_floats >= conv_wino_r64_ksplit_floats(a.nfr, Hl, a.Cin, a.Cout, a.nfr_sel)
                    ? conv_wino_r64_ksplit(a.nfr_sel ? a.nfr_sel : a.nfr, Hl, a.Cin, a.Cout) : 1;
