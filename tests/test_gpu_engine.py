@@ -1634,3 +1634,24 @@ def test_bench_two_rank_launch_path_runs_on_the_box():
     rank1 = open(err1).read() if os.path.exists(err1) else ""
     # (c10d's "[W...] hostname of the client socket cannot be retrieved" and libdrm's amdgpu.ids line are this pool's noise)
     assert not any(w in rank1 for w in ("Traceback", "Error", "error:", "FAILED", "Aborted")), rank1[-2000:]
+
+
+def test_infer_video_whole_video_is_bit_identical_with_the_suffix_skip():
+    """`infer_video(executor='graph', suffix_skip=True)` over a whole multi-window autoreg video (later windows condition on frames the
+    earlier ones generated): every frame the caller gets back equals the plain graph path's to the BIT -- the skipped frames are pure
+    observations whose step output nobody reads (scripts/video_sample.py:170-186).  Same seed = same Philox streams on both sides; the
+    prefix cache stays off (its per-window recomputation of the observed prefix is equal to rounding only, its own test above).
+    This is the user-visible form of bench.py's `window_shapes[*].speedup_of_the_opt_in`."""
+    from video_diffusion_amd.video_sample import infer_video
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=6, image_size=32, num_channels=64, num_res_blocks=1,
+                                                              rp_alpha=6, rp_beta=6, rp_gamma=6, timestep_respacing="ddim5")}
+    model, diff = engine(cfg)
+    batch = torch.rand(2, 14, 3, 32, 32, generator=torch.Generator().manual_seed(61)) * 2 - 1
+    outs = []
+    for ss in (False, True):
+        torch.manual_seed(62)
+        outs.append(infer_video("autoreg", model, diff, batch.cuda(), 6, 4, 2, executor="graph", suffix_skip=ss, prefix_cache=False)[0])
+        assert model._window_executor.suffix_skip == ss and not model._window_executor.prefix_cache
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])          # 5 windows x 5 steps, bit for bit
+    assert np.array_equal(outs[1][:, :4], batch[:, :4].numpy())
+    assert model._window_executor.suffix_frames == 2 * 2                            # 2 latent frames of 6 per clip run the suffix

@@ -433,3 +433,28 @@ def test_integration_import_block_resolves_every_name_the_script_uses(tmp_path):
             src = open(os.path.join(ref, script)).read()
             for mod in ("dist_util", "inference_util", "test_util"):
                 assert sorted(set(re.findall(rf"\b{mod}\.([A-Za-z_][A-Za-z0-9_]*)", src))) == mods.get(mod, []), (script, mod)
+
+
+def test_timing_only_kernel_builds_still_compile(tmp_path):
+    """The hot kernels carry timing-only ablation hooks (results WRONG, never in the product library; tools/build_variant.sh builds them
+    for same-box A/B runs: -DVD_R64_ABL, -DVD_GS_SKIP, -DVD_ATTN_ABL, the cycle-stamp builds).  Nothing else compiles those paths, so
+    this does: hipcc for gfx950, device code only, all variants in parallel."""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    cs = os.path.join(ROOT, "video-diffusion_amd", "csrc")
+    variants = [("conv_wino_r64.hip", ["-DVD_R64_ABL=34", "-DVD_WINO_TIMING"]),
+                ("conv_wino_r64.hip", ["-DVD_R64_ABL=29"]),
+                ("conv_wino_z128.hip", ["-DVD_WINO_TIMING", *_lib.SOURCE_FLAGS.get("conv_wino_z128.hip", [])]),
+                ("gemm_split.hip", ["-DVD_GS_SKIP=15", "-DVD_GS_TIMING"]),
+                ("attn_spatial.hip", ["-DVD_ATTN_ABL=7"]),
+                ("attn_temporal.hip", ["-DVD_ATT_TIMING"])]
+
+    def build(i):
+        src, flags = variants[i]
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *flags,
+                            "--cuda-device-only", "-c", os.path.join(cs, src), "-o", str(tmp_path / f"v{i}.o")], capture_output=True, text=True)
+        return src, flags, r.returncode, r.stderr[-1500:]
+
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        for src, flags, rc, err in pool.map(build, range(len(variants))):
+            assert rc == 0, (src, flags, err)

@@ -19,10 +19,6 @@
 
 #include "vd_common.h"
 
-#ifndef VD_WINO_RES_BRANCH
-#define VD_WINO_RES_BRANCH 0   // 1: no residual requests where there is no residual (a uniform branch).  Measured r05u: step 20.01 -> 20.14 ms: the conditional requests
-                               // make hipcc wait for everything in flight behind them; the 32 requests through an empty descriptor are cheaper
-#endif
 
 namespace vd {
 
@@ -81,13 +77,10 @@ extern "C" int vd_debug_r64_stamps(unsigned long long* host_out) {
 #ifndef VD_R64_B2REG
 #define VD_R64_B2REG 1     // f16x3: the third weight piece 2^-12 b0 formed in registers (conv_wino_z128.hip) instead of loaded (A/B: 0)
 #endif
-#ifndef VD_R64_MIXHI
-#define VD_R64_MIXHI 0     // 1: the a1 piece by v_fma_mixlo/hi_f16 (scale + round in one instruction per value instead of v_ldexp_f32 x 2 +
-#endif                     // v_cvt_pk_f16_f32: 10.31 instead of 10.98 instructions per MFMA, same bits) -- measured 0 .. 5 % SLOWER per layer (r05b), off
-#ifndef VD_R64_REGSTAGE
-#define VD_R64_REGSTAGE 0  // 1: f16x3, the patch staged through registers (buffer_load_dwordx4 -> ds_write_b128) instead of LDS-DMA.  In conv_wino_z128.hip that
-#endif                     // is worth 8 % (r05s: 417 -> 385 us at 128 -> 128 @ 64^2); HERE it is 2 - 9 % SLOWER on every layer (r05t: class 14.42 -> 14.71 ms;
-                           // no spills, 11.02 instructions per MFMA against 10.98): this loop has no issue slots left for 12 more requests per chunk pair
+// Variants that were built, measured and taken out again (the code lives in the history, commit aa1331c): the a1 piece by v_fma_mixlo/hi_f16 (10.31
+// instead of 10.98 instructions per MFMA, same bits: 0 .. 5 % slower per layer, r05b); the patch staged through registers instead of LDS-DMA (worth 8 % in
+// conv_wino_z128.hip, 2 .. 9 % SLOWER here, r05t: this loop has no issue slot left for twelve more requests per chunk pair); a uniform branch around the
+// residual requests of a conv without residual (step 20.01 -> 20.14 ms, r05u: hipcc waits for everything in flight behind a conditional request).
 // VD_R64_ABL: timing-only builds of the main loop (results WRONG; tools/build_variant.sh): bit 0 no weight reloads, 1 no
 // transform / split, 2 no patch requests, 3 no patch reads, 4 no MFMA -- never set in the product library
 // bit 5 (with bit 1): the loop as it would be if the A operand arrived ALREADY transformed and split (review r5 item 1a: V = B^T d B as
@@ -204,20 +197,6 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     };
 #endif
 
-    // ---- register staging (F16 && VD_R64_REGSTAGE): patch p is requested into `stg` in group (p - 3, 1) position 0 and written to its buffer
-    // in group (p - 2, 0) before the position that may carry the barrier; same LDS image (the thread's slots e * 256 + tid, the quad swizzle on
-    // the source side), so everything that reads a patch is unchanged.  A request past the last chunk goes through an empty descriptor
-    // into the spare buffer, as the DMA does.
-    constexpr bool RS = F16 && VD_R64_REGSTAGE;
-    f32x4 stg[RS ? NX : 1];
-    auto s_fetch = [&](int chunk, int e) -> f32x4 {
-        const int bytes = chunk < nchunk ? a.nfr * a.Hs * a.Ws * a.Cin * 4 : 0;
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, bytes, 0x00020000);
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xo[e], chunk * 64, 0));
-    };
-    auto s_store = [&](int chunk, int e, f32x4 v) {
-        *reinterpret_cast<f32x4*>(lds + (chunk < nchunk ? (chunk & (NB - 1)) : NB) * XBUF + e * 4096 + tid * 16) = v;
-    };
 
     // ---- transform in the fragment layout.  Lane (tile lr of the M-tile, k-half lh): tile column lr & 7, tile row 4m + (lr >> 3);
     // rows of B^T as d[X] + s*d[S]: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d3 - d1 (row 3 of U is negated on the host)
@@ -284,32 +263,6 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     // r * 2^12, round -- and channels 2k, 2k+1 of the NEXT position's V (column combination X -/+ Y).  `early`: the piece is read
     // by the MFMA of the next slot, and a VALU write needs two wait states before an MFMA reads it as A / B: the combination
     // goes behind the conversion.
-#if VD_R64_MIXHI
-    // a1 = f16((x - a0) * 2^12) with the scale and the rounding in ONE instruction per value: v_fma_mixlo_f16 / v_fma_mixhi_f16 write one half of
-    // the pair register each (fma(r, 4096, 0) is exact in fp32, the conversion rounds to nearest even: the bits of v_ldexp_f32 + v_cvt_pk_f16_f32).
-    // The half-register write wants a wait state before a VALU reads the register again (hipcc pads it with s_nop: round 4's first loop); here
-    // the next reader is an MFMA two or more instructions later, and the two halves are written with an independent instruction between them
-    // where the slot allows: 6 vector instructions per slot instead of 7 -- what fits beside an MFMA (LAB_NOTES R4.4).
-#define VD_R64_A1 "v_fma_mix_f32 %3, %5, -1.0, %6 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %4, %5, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-#define VD_R64_LO "v_fma_mixlo_f16 %0, %3, %12, 0 op_sel_hi:[0,0,0]\n\t"
-#define VD_R64_HI "v_fma_mixhi_f16 %0, %4, %12, 0 op_sel_hi:[0,0,0]\n\t"
-#define VD_R64_A1_OPS : "=&v"(af[cur][1][k]), "=&v"(tv[nxt][2 * k]), "=&v"(tv[nxt][2 * k + 1]), "=&v"(r0), "=&v"(r1) \
-                      : "v"(af[cur][0][k]), "v"(tv[cur][2 * k]), "v"(tv[cur][2 * k + 1]), "v"(t[cx][2 * k]), "v"(t[cy][2 * k]), "v"(t[cx][2 * k + 1]), "v"(t[cy][2 * k + 1]), "s"(k4096)
-    const float k4096 = 4096.0f;
-    auto f16_slot_a = [&](int cur, int nxt, int k, int jn, bool early) {
-        const int cx = jn == 0 ? 0 : jn == 2 ? 2 : 1, cy = jn == 0 ? 2 : jn == 1 ? 2 : jn == 2 ? 1 : 3;      // V[jn] = t[cx] - t[cy] (jn = 1: +)
-        float r0, r1;
-        if (jn == 1) {
-            if (early) asm(VD_R64_A1 VD_R64_LO VD_R64_HI "v_add_f32 %1, %8, %9\n\tv_add_f32 %2, %10, %11" VD_R64_A1_OPS);
-            else asm(VD_R64_A1 "v_add_f32 %1, %8, %9\n\t" VD_R64_LO "v_add_f32 %2, %10, %11\n\t" VD_R64_HI VD_R64_A1_OPS);
-        } else {
-            if (early) asm(VD_R64_A1 VD_R64_LO VD_R64_HI "v_sub_f32 %1, %8, %9\n\tv_sub_f32 %2, %10, %11" VD_R64_A1_OPS);
-            else asm(VD_R64_A1 "v_sub_f32 %1, %8, %9\n\t" VD_R64_LO "v_sub_f32 %2, %10, %11\n\t" VD_R64_HI VD_R64_A1_OPS);
-        }
-    };
-#undef VD_R64_LO
-#undef VD_R64_HI
-#else
 #define VD_R64_A1 "v_fma_mix_f32 %3, %5, -1.0, %6 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %4, %5, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
                   "v_ldexp_f32 %3, %3, 12\n\tv_ldexp_f32 %4, %4, 12\n\t"
 #define VD_R64_A1_OPS : "=&v"(af[cur][1][k]), "=&v"(tv[nxt][2 * k]), "=&v"(tv[nxt][2 * k + 1]), "=&v"(r0), "=&v"(r1) \
@@ -325,7 +278,6 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
             else asm(VD_R64_A1 "v_sub_f32 %1, %8, %9\n\tv_sub_f32 %2, %10, %11\n\tv_cvt_pk_f16_f32 %0, %3, %4" VD_R64_A1_OPS);
         }
     };
-#endif
 #undef VD_R64_A1
 #undef VD_R64_A1_OPS
     // Slot 4: the a0 piece of the next position's fragment (four conversions) + channels 0, 1 of the next group's t column c
@@ -386,26 +338,10 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     R64_STAMP(0); R64_STAMP(14);
     // ---- prologue: three patches and the weights of chunk 0 requested; group (0, 0) transformed whole, position 0 split,
     // column 0 of group (0, 1) in flight -- the state the loop expects at the top of a group
-    if constexpr (RS) {
-        f32x4 s0[NX], s1[NX];
 #pragma unroll
-        for (int e = 0; e < NX; ++e) s0[e] = s_fetch(0, e);
+    for (int c = 0; c < 3; ++c) x_dma(c);
 #pragma unroll
-        for (int e = 0; e < NX; ++e) s1[e] = s_fetch(1, e);
-#pragma unroll
-        for (int li = 0; li < NP - 1; ++li) { b_load(0, JLa[li], 0); b_load(0, JLa[li], 1); }
-#pragma unroll
-        for (int e = 0; e < NX; ++e) s_store(0, e, s0[e]);
-#pragma unroll
-        for (int e = 0; e < NX; ++e) s_store(1, e, s1[e]);
-#pragma unroll
-        for (int e = 0; e < NX; ++e) stg[e] = s_fetch(2, e);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) x_dma(c);
-#pragma unroll
-        for (int li = 0; li < NP - 1; ++li) { b_load(0, JLa[li], 0); b_load(0, JLa[li], 1); }
-    }
+    for (int li = 0; li < NP - 1; ++li) { b_load(0, JLa[li], 0); b_load(0, JLa[li], 1); }
     // the 256 accumulator writes (1 k cycles of issue) go under the wait for the first patch instead of behind it
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -420,8 +356,7 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     __builtin_amdgcn_sched_barrier(0);
     // patch 0 has landed in every wave; patches 1, 2 (first read behind the loop's first barrier, which waits for them: 2 * NX requests)
     // and the (NP - 1) * 6 (4: two loads per fragment) weight loads may be in flight
-    if constexpr (RS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // patches 0, 1 are ds_writes; the loads in flight land in registers
-    else {
+    {
         constexpr int W = 2 * NX + (NP - 1) * (B2R ? 4 : 6);
         static_assert(W == 20 || W == 24 || W == 28 || W == 30 || W == 34, "wait count of the prologue");
         if constexpr (W == 20) asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
@@ -485,22 +420,11 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
                     const int q = k >> 1, n = k & 1;
                     if (m == 0 && li == NP - 1 && k == 0 && cpar == 0) {
                         // the 18 (12: two loads per fragment) youngest requests are weight loads
-                        if constexpr (RS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                        else if constexpr (B2R) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        if constexpr (B2R) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     }
                     // the patch requests of the chunk pair, one per slot
-                    if constexpr (RS) {
-                        // group (chunk, 0), positions NP - 3 and NP - 2 (in front of the position that may carry the barrier): the writes of patch
-                        // chunk + 2, in slots 1, 3, 5 (and 0 for the eight slots of the 8 x 8 form); group (chunk, 1), position 0 (no weight loads
-                        // there): the requests of patch chunk + 3
-                        if (m == 0 && (li == NP - 3 || li == NP - 2)) {
-                            const int base = (li - (NP - 3)) * (NX / 2);
-                            if (NX == 6) { if (k & 1) s_store(chunk + 2, base + (k >> 1), stg[base + (k >> 1)]); }
-                            else { const int q = k == 0 ? 0 : (k & 1) ? 1 + (k >> 1) : -1; if (q >= 0) s_store(chunk + 2, base + q, stg[base + q]); }
-                        }
-                        if (m == 1 && li == 0) { stg[k] = s_fetch(chunk + 3, k); if (NX == 8 && k >= 4) stg[k + 2] = s_fetch(chunk + 3, k + 2); }
-                    } else if (cpar == 1 && !(VD_R64_ABL & 4)) {
+                    if (cpar == 1 && !(VD_R64_ABL & 4)) {
                         if constexpr (F16) {
                             const int ord = m == 0 ? (li - 1) * 6 + k : (li == 0 ? (NP - 1) * 6 + k : 99);      // slots behind position 0 of group (c, 0)
                             if ((m == 1 || li > 0) && ord < 2 * NX) x_dma_one(chunk + 2 + ord / NX, ord % NX);
@@ -563,7 +487,6 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
     const int Ho = PH ? 2 * Hl : Hl, Wo = PH ? 2 * Wl : Wl;
     const int obytes = a.nfr * Ho * Wo * a.ldo * 4;
     const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)ks * (obytes >> 2), 0, obytes, 0x00020000);
-    const bool has_res = a.res != nullptr;                            // (uniform: a convolution without a residual issues none of the 32 requests per cout tile)
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
     const float sgn = p ? -1.f : 1.f;
     float* Zs = smem;
@@ -597,7 +520,7 @@ __device__ __forceinline__ void r64_body(const IgemmArgs& a, const WinoR64Geom& 
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[m][r] = VD_WINO_RES_BRANCH && !has_res ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], nso, 0));
+            for (int r = 0; r < 16; ++r) rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], nso, 0));
             // Z = M A: columns (1, 1, 1, 0) and (0, 1, -1, -1); the column the sub-pixel form never computed is zero
             const f32x16 z0 = JS == 0 ? acc[m][1][n] + acc[m][2][n] : acc[m][0][n] + acc[m][1][n] + acc[m][2][n];
             const f32x16 z1 = JS == 3 ? acc[m][1][n] - acc[m][2][n] : acc[m][1][n] - acc[m][2][n] - acc[m][3][n];

@@ -24,11 +24,6 @@
 
 #include "vd_common.h"
 
-#ifndef VD_WINO_RES_BRANCH
-#define VD_WINO_RES_BRANCH 0   // 1: no residual requests where there is no residual (a uniform branch).  Measured r05u: step 20.01 -> 20.14 ms: the conditional requests
-                               // make hipcc wait for everything in flight behind them; the 32 requests through an empty descriptor are cheaper
-#endif
-
 namespace vd {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -41,9 +36,8 @@ constexpr int P = 18, SPP = 10, PLB = SPP * 64, RSB = 2 * PLB, NX = 6, XBUF = NX
 constexpr int LDS_BYTES = (NB + 1) * XBUF;                     // + the spare buffer for requests past the last chunk
 }  // namespace z128
 
-#ifndef VD_Z128_MIXHI
-#define VD_Z128_MIXHI 0     // 1: v_fma_mixlo/hi_f16 for the a1 piece (conv_wino_r64.hip: one instruction fewer per pair, measured no faster; r05b)
-#endif
+// Variants built, measured and taken out (history: commit aa1331c): v_fma_mixlo/hi_f16 for the a1 piece (no faster, r05b), a uniform branch around
+// the residual requests (slower, r05u), register staging without the activation as a timing build (r05s: what the staging method alone is worth).
 #ifdef VD_WINO_TIMING
 __device__ unsigned long long g_z128_stamp[16];
 #define Z128_STAMP(i)                                                                                 \
@@ -173,9 +167,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     // slot (cycle stamps: 7.2 k cycles per chunk against 5.7 k of the plain kernel); eight parts over the odd slots of positions 1 AND 2
     // keep a part at <= 2 transcendental + 2 plain instructions.
     auto p_act_on = [&](f32x4 (&stg)[ACT ? NX : 1], int e, int part) {
-#ifdef VD_Z128_REG_PLAIN          // timing-only build: register staging WITHOUT the activation (what the staging method alone is worth)
-        return;
-#endif
         if constexpr (ACT) {
             if (part == 0)
                 asm("v_fma_f32 %0, %0, %4, %8\n\tv_fma_f32 %1, %1, %5, %9\n\tv_fma_f32 %2, %2, %6, %10\n\tv_fma_f32 %3, %3, %7, %11"
@@ -233,7 +224,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     // Each part is ONE asm statement: hipcc pads every asm output that the next instruction reads with an s_nop, and an s_nop is
     // an issue slot like any other (conv_wino_r64.hip).
     float pa0, pa1, pb0, pb1, pv0, pv1;                              // in flight between the parts of one block
-    const float k4096 = 4096.0f;
     auto frag_part = [&](int nxt, int jn, int b, int part) {         // block b of 8: m = b >> 2, pair b & 3
         const int m = b >> 2, pr = b & 3, h = pr >> 1, e0 = 2 * (pr & 1);
         if (part == 0) {
@@ -260,17 +250,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
 #undef VD_Z128_P01
         } else {
             float r0, r1;
-#if VD_Z128_MIXHI
-            // scale + round in one instruction per value (conv_wino_r64.hip: v_fma_mixlo/hi_f16; the register is next read by an MFMA of the
-            // following position): 4 instructions instead of 5
-            asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-                "v_fma_mixlo_f16 %0, %1, %6, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %2, %6, 0 op_sel_hi:[0,0,0]"
-                : "=&v"(af[nxt][m][1][pr]), "=&v"(r0), "=&v"(r1) : "v"(af[nxt][m][0][pr]), "v"(pv0), "v"(pv1), "s"(k4096));
-#else
             asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
                 "v_ldexp_f32 %1, %1, 12\n\tv_ldexp_f32 %2, %2, 12\n\tv_cvt_pk_f16_f32 %0, %1, %2"
                 : "=&v"(af[nxt][m][1][pr]), "=&v"(r0), "=&v"(r1) : "v"(af[nxt][m][0][pr]), "v"(pv0), "v"(pv1));
-#endif
         }
     };
     // The 24 parts of a position run in its steps 3 .. 23 (reads: two per step in steps 0 .. 7, the four of blocks 2g, 2g + 1 in
@@ -455,7 +437,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
     const int p = wi >> 1, q = wi & 1;
     const int obytes = a.nfr * Hl * Wl * a.ldo * 4;
     const auto osrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
-    const bool has_res = a.res != nullptr;                            // (uniform: a convolution without a residual issues none of the 32 requests per cout tile)
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.out), 0, a.res ? obytes : 0, 0x00020000);
     const float sgn = p ? -1.f : 1.f;
     float* Zs = smem;
@@ -480,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_z128_kernel(IgemmArgs a, 
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[m][r] = VD_WINO_RES_BRANCH && !has_res ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], nso, 0));
+            for (int r = 0; r < 16; ++r) rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oo[m][r], nso, 0));
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 *reinterpret_cast<f32x4*>(Zs + ((((wi * 2 + 0) * 2 + m) * 4 + c4) * 64 + lane) * 4) =

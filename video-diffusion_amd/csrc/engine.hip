@@ -694,9 +694,12 @@ int vd_engine::gn_act(const Tens& x0, const Tens* x1, int N, int gw, int gb, con
     }
     // Big tensors (the 64 x 64 and 32 x 32 levels of a full window) take the two-launch form: (A, B) per (frame, channel) by
     // gn_final_affine, then the pass on many short blocks -- 5.95 TB/s against the 5.2 of the long blocks the in-kernel fold needs
-    // (tools/probes/stream_probe.hip); the 7 us of the extra launch are repaid from ~64 MB on.  Same formulas, same bits.
+    // (tools/probes/stream_probe.hip); the 7 us of the extra launch are repaid from ~64 MB on.  Same formulas and fp64 sums; the ORDER of the
+    // sums differs (gn_final_affine deals a group's pairs to eight lanes, the folding pass walks them in sequence), so (A, B) agree to fp64
+    // rounding -- after the cast to fp32 in practice to the bit (tools/switch_check.py), by construction to 1 ulp.  The 64 MB switch is by the
+    // size of the whole layer call (g_sel_nfr): a full window and the compact suffix batch of the same layer take the same form.
     static const size_t big = getenv("VD_AA_BIG_MB") ? (size_t)atol(getenv("VD_AA_BIG_MB")) << 20 : (size_t)64 << 20;
-    const bool two = (size_t)N * HW * C * 4 >= big;
+    const bool two = (size_t)(g_sel_nfr > N ? g_sel_nfr : N) * HW * C * 4 >= big;      // by the size of the whole layer call: the compact suffix batch takes the full window's form
     float* Aab = two ? ar.get<float>((size_t)N * C) : nullptr;
     float* Bab = two ? ar.get<float>((size_t)N * C) : nullptr;
     if (ar.dry) return 0;

@@ -50,13 +50,13 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const float* __restrict_
     }
     __shared__ double red[256 * 8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[tid * 8 + e] = s[e]; red[tid * 8 + 4 + e] = ss[e]; }
+    for (int e = 0; e < 4; ++e) { red[e * 256 + tid] = s[e]; red[(4 + e) * 256 + tid] = ss[e]; }      // one plane per sum: conflict-free
     __syncthreads();
     if (tid < tpp) {
         double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < ppi; ++k)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += red[(k * tpp + tid) * 8 + e];
+            for (int e = 0; e < 8; ++e) a[e] += red[e * 256 + k * tpp + tid];
         double* o = part + (((size_t)n * split + sp) * C + tid * 4) * 2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { o[e * 2] = a[e]; o[e * 2 + 1] = a[4 + e]; }
@@ -214,6 +214,9 @@ int launch_affine_act(const float* src0, const float* src1, int C0, int C, const
     return 0;
 }
 
+static int fold_target_blocks() { static const int v = getenv("VD_FOLD_BLOCKS") ? atoi(getenv("VD_FOLD_BLOCKS")) : 2048; return v; }   // A/B knobs, read once
+static int fold_min_rows() { static const int v = getenv("VD_FOLD_ROWS") ? atoi(getenv("VD_FOLD_ROWS")) : 16; return v; }
+
 // ------------------------------------------------------------------ the fold inside the pass
 // gn_final_affine_kernel is 7.5 us of dependent round trips per launch whatever the size (56 launches per step, 0.42 ms: the
 // largest item of the step that is not work).  Here every block of the activation pass folds the statistics of ITS frame
@@ -224,15 +227,28 @@ int launch_affine_act(const float* src0, const float* src1, int C0, int C, const
 __global__ __launch_bounds__(256) void affine_act_fold_kernel(const float* __restrict__ src0, const float* __restrict__ src1,
                                                               int C0, int C, GnFold f, int HW, int per, int act,
                                                               float* __restrict__ y) {
-    __shared__ double red[256 * 8];              // [pixel lane][quad][4 sums | 4 sums of squares]
-    __shared__ double gs[1024 * 2];              // [channel][sum, sum of squares] of the frame
+    // LDS (dynamic, sized by C: the blocks of a CU fold side by side, and 32 KB of static arrays allowed five of them):
+    //   red [8 sums][thread]   the threads' partial sums over the producer's pixel ranges -- one PLANE per sum, so that a wave's
+    //                          64 stores / loads of a plane are 64 consecutive doubles (round 5's [thread][8] layout put every fourth lane
+    //                          on the same bank: rocprofv3 counted bank-conflict cycles for 0.7 of this kernel's LDS cycles)
+    //   gs  [2][C]             per-channel (sum | sum of squares) of the frame, two planes
+    //   mr  [32][2] floats     per-group (mean, rstd): formed ONCE per block by one lane per group.  Round 5 had every thread fold the groups
+    //                          of its four channels itself: 8 cg conflicting ds_read_b64 and four fp64 divisions + square roots per thread,
+    //                          256 times the same 32 results -- the fold, not HBM, set the time of the small tensors (3.5 TB/s).
+    // Same sums in the same order as round 5's kernel (pixel lanes k ascending, then the group's channels ascending), same formulas: its bits.
+    // Against gn_final_affine_kernel's (A, B): same formulas, fp64 sums in another order (that kernel deals the pairs to eight lanes).
+    extern __shared__ __attribute__((aligned(16))) double fold_lds[];
+    const int NT = blockDim.x;
+    double* const red = fold_lds;                // [8][NT]
+    double* const gs = fold_lds + 8 * NT;        // [2][C]
+    float* const mr = reinterpret_cast<float*>(gs + 2 * C);
     const int n = blockIdx.y;
-    const int tpp = C >> 2, ppi = blockDim.x / tpp;
+    const int tpp = C >> 2, ppi = NT / tpp;
     const int tid = threadIdx.x;
     const int pl = tid / tpp, c = (tid - pl * tpp) * 4;
     const int C1 = C - C0, cg = C / 32;
     // the first four rows of this thread are requested BEFORE the fold: all blocks of a launch are resident at once and fold at the
-    // same time -- without this HBM idles for the fold's two dependent round trips at the start of every launch
+    // same time -- without this HBM idles for the fold's dependent round trips at the start of every launch
     const int p_begin = blockIdx.x * per, p_end = min(HW, p_begin + per);
     const float* src; int ld;
     if (c < C0) { src = src0 + (size_t)n * HW * C0 + c; ld = C0; } else { src = src1 + (size_t)n * HW * C1 + (c - C0); ld = C1; }
@@ -256,28 +272,33 @@ __global__ __launch_bounds__(256) void affine_act_fold_kernel(const float* __res
             for (int e = 0; e < 4; ++e) { a[e] += q[2 * e]; a[4 + e] += q[2 * e + 1]; }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = a[e];
+        for (int e = 0; e < 8; ++e) red[e * NT + tid] = a[e];
     }
     __syncthreads();
     if (tid < tpp) {
         double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < ppi; ++k)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += red[(k * tpp + tid) * 8 + e];
+            for (int e = 0; e < 8; ++e) a[e] += red[e * NT + k * tpp + tid];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { gs[(tid * 4 + e) * 2] = a[e]; gs[(tid * 4 + e) * 2 + 1] = a[4 + e]; }
+        for (int e = 0; e < 4; ++e) { gs[tid * 4 + e] = a[e]; gs[C + tid * 4 + e] = a[4 + e]; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double s = 0, ss = 0;
+        for (int k = 0; k < cg; ++k) { s += gs[tid * cg + k]; ss += gs[C + tid * cg + k]; }
+        const double mean = s / f.count;
+        double var = ss / f.count - mean * mean;
+        if (var < 0) var = 0;
+        mr[tid * 2] = (float)mean;
+        mr[tid * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
     }
     __syncthreads();
     f32x4 A, B;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int g = (c + e) / cg;
-        double s = 0, ss = 0;
-        for (int k = 0; k < cg; ++k) { s += gs[(g * cg + k) * 2]; ss += gs[(g * cg + k) * 2 + 1]; }
-        const double mean = s / f.count;
-        double var = ss / f.count - mean * mean;
-        if (var < 0) var = 0;
-        const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + 1e-5));
+        const float mf = mr[g * 2], rf = mr[g * 2 + 1];
         float Ae = rf * f.gamma[c + e];
         float Be = f.beta[c + e] - mf * Ae;
         if (f.film) {
@@ -314,9 +335,10 @@ int launch_affine_act_fold(const float* src0, const float* src1, int C0, int C, 
     VD_REQUIRE(f.part0 && (C0 == C || f.part1), "affine_act_fold: GroupNorm partial tables");
     const int tpp = C / 4, ppi = 256 / tpp, threads = ppi * tpp;
     int split = 1;                                  // (coarse blocks: every block folds its frame's table first -- 8192 blocks: 1.74 -> 2.58 ms per step, r05h)
-    while (nfr * split < 2048 && HW / (split * 2) >= ppi * 16) split *= 2;
+    while (nfr * split < fold_target_blocks() && HW / (split * 2) >= ppi * fold_min_rows()) split *= 2;
     const int per = (HW + split - 1) / split;
-    hipLaunchKernelGGL(affine_act_fold_kernel, dim3(split, nfr), dim3(threads), 0, s, src0, src1, C0, C, f, HW, per, act, y);
+    const size_t lds = (size_t)(8 * threads + 2 * C) * sizeof(double) + 64 * sizeof(float);
+    hipLaunchKernelGGL(affine_act_fold_kernel, dim3(split, nfr), dim3(threads), lds, s, src0, src1, C0, C, f, HW, per, act, y);
     VD_HIP(hipGetLastError());
     return 0;
 }
