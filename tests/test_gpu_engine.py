@@ -1655,3 +1655,37 @@ def test_infer_video_whole_video_is_bit_identical_with_the_suffix_skip():
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])          # 5 windows x 5 steps, bit for bit
     assert np.array_equal(outs[1][:, :4], batch[:, :4].numpy())
     assert model._window_executor.suffix_frames == 2 * 2                            # 2 latent frames of 6 per clip run the suffix
+
+
+def test_nll_job_on_the_engine_writes_what_run_bpd_evaluation_returns(tmp_path, monkeypatch):
+    """`video_nll.run()` (scripts/video_nll.py:87-140,262-352) on the real engine from a checkpoint file: the per-video pickles hold, per
+    window of the autoreg schedule, exactly what `run_bpd_evaluation` returns for that window under the same seed (the job draws its timesteps
+    and noise from torch's generator in batch-then-window order), and the whole is finite and positive like a bits-per-dim should be."""
+    import pickle
+    from argparse import Namespace
+    from video_diffusion_amd import video_nll
+    cfg = {**vda.video_model_and_diffusion_defaults(), **dict(T=4, image_size=32, num_channels=32, num_res_blocks=1,
+                                                              rp_alpha=4, rp_beta=4, rp_gamma=4, timestep_respacing="ddim5")}
+    model, diff = engine(cfg)
+    ck = tmp_path / "checkpoints" / "e" / "ema_50.pt"
+    ck.parent.mkdir(parents=True)
+    torch.save({"state_dict": synth_sd(model.param_specs()), "config": {**cfg, "max_frames": 4}, "step": 50}, ck)
+    vids = torch.rand(3, 6, 3, 32, 32, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    np.save(tmp_path / "v.npy", vids.numpy())
+    monkeypatch.chdir(tmp_path)
+    _cpu_draws(monkeypatch)
+    a = Namespace(checkpoint_path=str(ck), videos=str(tmp_path / "v.npy"), synthetic=False, inference_mode="autoreg", T=None, max_frames=None,
+                  obs_length=2, step_size=2, batch_size=2, num_videos=0, timestep_respacing="ddim5", use_ddim=False, eval_dir=None, seed=11,
+                  image_size=32, num_channels=32, num_res_blocks=1, indices=None, task_id=None, indices_path=None, clip_denoised=True, optimality=None)
+    out = video_nll.run(a, device=torch.device("cuda", 0))
+    assert str(out) == "results/e/ema_50_respaceddim5/autoreg_4_2_None_2"          # max_frames from the config BEFORE naming, T after (video_nll.py:288-296)
+    torch.manual_seed(11)
+    windows = [([0, 1], [2, 3]), ([2, 3], [4, 5])]
+    for ids in ([0, 1], [2]):
+        want = [video_nll.run_bpd_evaluation(model, diff, vids[ids], True, [o] * len(ids), [l] * len(ids)) for o, l in windows]
+        for j, i in enumerate(ids):
+            rec = pickle.load(open(tmp_path / out / "elbos" / f"elbo_{i}_respaceddim5.pkl", "rb"))
+            assert set(rec) == {"total_bpd", "prior_bpd", "vb", "xstart_mse", "mse"}
+            for k, v in rec.items():
+                assert v.shape == (2,) and np.array_equal(v, np.stack([w[k][j] for w in want])), (i, k)
+            assert np.isfinite(rec["total_bpd"]).all() and (rec["total_bpd"] > 0).all()

@@ -458,3 +458,64 @@ def test_timing_only_kernel_builds_still_compile(tmp_path):
     with ThreadPoolExecutor(max_workers=6) as pool:
         for src, flags, rc, err in pool.map(build, range(len(variants))):
             assert rc == 0, (src, flags, err)
+
+
+def test_sampling_job_run_directory_follows_the_dataset_options(tmp_path):
+    """--dataset_partition train -> 'trainset_' prefix, variable_length -> a subdirectory (video_sample.py:603-604); --override_dataset ->
+    '<name>_' prefix and model_config.json's `dataset` (:555-556); --use_gradient_method -> 'gradientmethod_' (test_util.py:111-132)."""
+    out, _ = _run_job(_job_args(tmp_path / "a", dataset_partition="train", override_dataset="carla", num_videos=1, indices=[0]))
+    assert out.name == "carla_trainset_autoreg_4_2_6_2"
+    assert json.load(open(out / "model_config.json"))["dataset"] == "carla"
+    out, _ = _run_job(_job_args(tmp_path / "b", dataset_partition="variable_length", num_videos=1, inference_mode="independent"))
+    assert out.name == "variable_length" and out.parent.name == "independent_4_2_6_2"
+    # --optimality reads <eval_dir>/optimal_schedule.pt (video_sample.py:199-200), which the reference's video_optimal_schedule.py writes: without it, its error
+    with pytest.raises(FileNotFoundError, match="optimal_schedule.pt"):
+        _run_job(_job_args(tmp_path / "c", num_videos=1, optimality="linspace-t", inference_mode="independent"))
+    assert (tmp_path / "c" / "out" / "independent_optimal-linspace-t_4_2_6_2").is_dir()
+
+
+def test_nll_job_scores_every_window_once_and_skips_finished_videos(tmp_path):
+    """video_nll.run (scripts/video_nll.py:87-140,262-352) with a stand-in sampler: every video gets one pickle {metric: array over the
+    schedule's windows} under elbos/, the frame-index lists are saved and re-checked, a second run scores nothing, --task_id selects one
+    batch-sized block, an explicit --indices is refused as in the reference."""
+    import pickle
+    import torch
+    from video_diffusion_amd import video_nll
+    calls = []
+
+    class Diff:
+        num_timesteps = 3
+
+        def calc_bpd_loop_subsampled(self, model, x0, clip_denoised, model_kwargs, latent_mask, t_seq):
+            calls.append((tuple(x0.shape), model_kwargs["frame_indices"][0].tolist(), int(model_kwargs["obs_mask"][0].sum())))
+            B = x0.shape[0]
+            return {"total_bpd": torch.full((B,), float(len(calls))), "vb": torch.ones(B, 3)}
+
+    def create(**kw):
+        model, _ = vda.create_video_model_and_diffusion(**kw)
+        return model, Diff()
+
+    def args(**over):
+        a = _job_args(tmp_path, num_videos=3, batch_size=2, clip_denoised=True, indices_path=None, **over)
+        return a
+
+    out = video_nll.run(args(), create=create, device=torch.device("cpu"))
+    assert out.name == "autoreg_4_2_6_2" and sorted(os.listdir(out / "elbos")) == ["elbo_0_respaceddim5.pkl", "elbo_1_respaceddim5.pkl", "elbo_2_respaceddim5.pkl"]
+    # autoreg(T=6, obs 2, max_frames 4, step 2): windows ([0,1],[2,3]) and ([2,3],[4,5]); two batches (2 + 1 videos) x two windows
+    assert [c[1] for c in calls] == [[0, 1, 2, 3], [2, 3, 4, 5]] * 2 and [c[0][0] for c in calls] == [2, 2, 1, 1] and all(c[2] == 2 for c in calls)
+    rec = pickle.load(open(out / "elbos" / "elbo_2_respaceddim5.pkl", "rb"))
+    assert rec["total_bpd"].shape == (2,) and rec["total_bpd"].tolist() == [3.0 * 4, 4.0 * 4]        # x window length (4 frames)
+    assert rec["vb"].tolist() == [12.0, 12.0]                                                          # summed over t, x window length
+    obs_saved, lat_saved = torch.load(out / "frame_indices.pt")
+    assert len(obs_saved) == 3 and obs_saved[0] == [[0, 1], [2, 3]] and lat_saved[2] == [[2, 3], [4, 5]]
+    n = len(calls)
+    video_nll.run(args(), create=create, device=torch.device("cpu"))
+    assert len(calls) == n                                                                             # everything on disk: no network call
+    os.remove(out / "elbos" / "elbo_1_respaceddim5.pkl")
+    video_nll.run(args(task_id=0), create=create, device=torch.device("cpu"))                          # block #0 = items 0, 1: one file missing -> the batch again
+    assert len(calls) == n + 2 and os.path.exists(out / "elbos" / "elbo_1_respaceddim5.pkl")
+    with pytest.raises(IndexError):                                                                    # block #1 = items 2, 3; item 3 does not exist: `Subset`
+        os.remove(out / "elbos" / "elbo_2_respaceddim5.pkl")                                           # fails on it in the reference as well
+        video_nll.run(args(task_id=1), create=create, device=torch.device("cpu"))
+    with pytest.raises(NotImplementedError):
+        video_nll.run(args(indices=[0]), create=create, device=torch.device("cpu"))

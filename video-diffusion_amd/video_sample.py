@@ -250,6 +250,8 @@ def load_model(args, device, rank=0, world=1, create=None):
             cfg = dict(defaults, T=mf, max_frames=mf, image_size=args.image_size, num_channels=args.num_channels,
                        num_res_blocks=args.num_res_blocks, rp_alpha=mf, rp_beta=mf, rp_gamma=mf)
         cfg.update(use_ddim=bool(getattr(args, "use_ddim", False)), timestep_respacing=args.timestep_respacing)   # video_sample.py:551-554
+        if getattr(args, "override_dataset", None) is not None:
+            cfg["dataset"] = args.override_dataset                                                                # :555-556
     else:
         cfg = None
     cfg = vdist.broadcast_object(cfg, src=0)
@@ -283,6 +285,10 @@ def add_job_arguments(ap):
     ap.add_argument("--synthetic", type=str2bool, nargs="?", const=True, default=True,
                     help="without --videos: --num_videos synthetic U[-1, 1] videos, item i seeded by i")
     ap.add_argument("--num_videos", type=int, default=2, help="size of the synthetic dataset")
+    ap.add_argument("--dataset_partition", default="test", choices=["train", "test", "variable_length"],
+                    help="names the run directory as the reference does ('trainset_' prefix, 'variable_length/' subdirectory); the videos themselves "
+                         "come from --videos / --synthetic")
+    ap.add_argument("--override_dataset", default=None, help="'<name>_' prefix of the run directory and `dataset` of model_config.json (video_sample.py:555-556)")
     ap.add_argument("--use_gradient_method", action="store_true")
     ap.add_argument("--inference_mode", default="autoreg", choices=sorted(inference_util.inference_strategies))
     ap.add_argument("--max_frames", type=int, default=None,
@@ -373,6 +379,8 @@ def run(args, create=None, device=None, infer=None):
             alias = getattr(args, "out_dir", None)
             args.eval_dir = alias if alias is not None else (None if args.checkpoint_path else "results/synthetic")
         out_dir = test_util.get_model_results_path(args) / run_id
+        if getattr(args, "dataset_partition", None) == "variable_length":                                       # video_sample.py:603-604
+            out_dir = out_dir / "variable_length"
         os.makedirs(out_dir / "samples", exist_ok=True)
         json_path = out_dir / "model_config.json"                         # video_sample.py:620-626
         if not json_path.exists():
