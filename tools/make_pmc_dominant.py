@@ -21,6 +21,9 @@ KERNELS = {
     "conv3x3_wino_z128_kernel": ("conv3x3_wino_z128_kernel", [C + "conv_wino_z128.hip", C + "vd_common.h"], 1.5),
     "conv3x3_wino_r64_kernel": ("conv3x3_wino_r64_kernel", [C + "conv_wino_r64.hip", C + "vd_common.h"], 2.25),
     "gemm_split_kernel<128,192>": ("gemm_split_kernel<128, 192", [C + "gemm_split.hip", C + "vd_common.h"], 1.0),
+    # the sub-pixel form of Upsample + conv (r06): 9 direct multiplications per output pixel = 36 per source pixel; executed per 2 x 2 source tile
+    # 4 phases x 12 of 16 positions (the structurally zero COLUMN is skipped, the zero row is not: a wave owns a row) = 12 per source pixel
+    "conv3x3_wino_r64_ups_kernel": ("conv3x3_wino_r64_ups_kernel", [C + "conv_wino_r64.hip", C + "vd_common.h"], 3.0),
 }
 # the un-profiled bench line of the same box and command (tools/profile_bench.sh): algorithmic FLOPs / bytes per launch, arithmetic mode
 bench = json.load(open(os.path.join(os.path.dirname(summary), "bench.json")))
