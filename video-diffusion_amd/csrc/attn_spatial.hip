@@ -412,14 +412,7 @@ template <int F, bool F16, int NW>
 static int launch_attn_spatial_split(const AttnSpatialArgs& a, hipStream_t s) {
     constexpr int KS = (F + 15) / 16, NPL = F16 ? 2 : 3;
     constexpr int LDS = 2 * NPL * (32 * (KS * 32 + 16) + 32 * attn_rowv(F));
-    static bool attr[64] = {};                                        // per device
-    int dev = 0;
-    VD_HIP(hipGetDevice(&dev));
-    VD_REQUIRE(dev >= 0 && dev < 64, "attn_spatial: device ordinal beyond the per-device attribute table");
-    if (!attr[dev]) {
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_spatial_split_kernel<F, F16, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr[dev] = true;
-    }
+    VD_RAISE_LDS((&attn_spatial_split_kernel<F, F16, NW>), (size_t)LDS);
     dim3 grid((a.L + NW * 32 - 1) / (NW * 32), a.heads, a.nfr);
     hipLaunchKernelGGL((attn_spatial_split_kernel<F, F16, NW>), grid, dim3(NW * 64), LDS, s, a);
     VD_HIP(hipGetLastError());

@@ -477,12 +477,7 @@ template <int NT, int JM, bool RPE, bool EXACT>
 static int launch_tm(const AttnTemporalArgs& a, hipStream_t s) {
     constexpr int TP = 16 * NT, PS = TP * (TP + 1) + (NT == 1 ? 1 : 17);
     constexpr size_t lds = (size_t)16 * PS * sizeof(float);
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_mfma_kernel<NT, JM, RPE, EXACT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    if (lds > 48 * 1024) VD_RAISE_LDS((&attn_temporal_mfma_kernel<NT, JM, RPE, EXACT>), lds);
     dim3 grid(a.HW / 16, a.heads, a.B);
     hipLaunchKernelGGL((attn_temporal_mfma_kernel<NT, JM, RPE, EXACT>), grid, dim3(512), lds, s, a);
     VD_HIP(hipGetLastError());
@@ -491,12 +486,7 @@ static int launch_tm(const AttnTemporalArgs& a, hipStream_t s) {
 
 template <int PB, int TMAX, bool RPE>
 static int launch_tt(const AttnTemporalArgs& a, size_t lds, hipStream_t s) {
-    static size_t attr = 0;
-    if (lds > attr) {
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_kernel<PB, TMAX, RPE>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
-    }
+    VD_RAISE_LDS((&attn_temporal_kernel<PB, TMAX, RPE>), lds);
     dim3 grid((a.HW + PB - 1) / PB, a.heads, a.B);
     hipLaunchKernelGGL((attn_temporal_kernel<PB, TMAX, RPE>), grid, dim3(256), lds, s, a);
     VD_HIP(hipGetLastError());

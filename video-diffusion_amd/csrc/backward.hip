@@ -300,12 +300,10 @@ int launch_attn_temporal_bwd(const AttnTemporalArgs& a, const float* dout, float
     VD_REQUIRE(lds <= 150 * 1024, "temporal attention backward: head dim too large");
     const dim3 grid(a.HW, a.heads, a.B);
     if (a.Rk) {
-        static size_t attr = 0;
-        if (lds > attr) { VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = lds; }
+        VD_RAISE_LDS((&attn_temporal_bwd_kernel<true>), lds);
         hipLaunchKernelGGL(attn_temporal_bwd_kernel<true>, grid, dim3(256), lds, s, a, dout, dqkv);
     } else {
-        static size_t attr = 0;
-        if (lds > attr) { VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = lds; }
+        VD_RAISE_LDS((&attn_temporal_bwd_kernel<false>), lds);
         hipLaunchKernelGGL(attn_temporal_bwd_kernel<false>, grid, dim3(256), lds, s, a, dout, dqkv);
     }
     VD_HIP(hipGetLastError());
@@ -456,8 +454,7 @@ int launch_attn_spatial_bwd(const AttnSpatialArgs& a, const float* dout, float* 
     float* lse = ws; float* Dv = ws + (size_t)a.nfr * a.heads * a.L;
     const size_t lds1 = ((size_t)2 * SQT * (F + 4) + (size_t)2 * SQT * (a.L + 1)) * sizeof(float);
     const size_t lds2 = ((size_t)4 * SQT * (F + 4) + (size_t)2 * SQT * (SQT + 1)) * sizeof(float);
-    static size_t attr = 0;
-    if (lds1 > attr) { VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_sp_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)); attr = lds1; }
+    VD_RAISE_LDS((&attn_sp_bwd_dq_kernel), lds1);
     const dim3 grid((a.L + SQT - 1) / SQT, a.heads, a.nfr);
     hipLaunchKernelGGL(attn_sp_bwd_dq_kernel, grid, dim3(256), lds1, s, a, dout, dqkv, lse, Dv);
     hipLaunchKernelGGL(attn_sp_bwd_dkv_kernel, grid, dim3(256), lds2, s, a, dout, dqkv, lse, Dv);
@@ -737,12 +734,10 @@ int launch_attn_temporal_weights(const AttnTemporalArgs& a, float* out, hipStrea
     VD_REQUIRE(lds <= 150 * 1024, "temporal attention weights: head dim too large");
     const dim3 grid(a.HW, a.B);
     if (a.Rk) {
-        static size_t attr = 0;
-        if (lds > attr) { VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_weights_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = lds; }
+        VD_RAISE_LDS((&attn_temporal_weights_kernel<true>), lds);
         hipLaunchKernelGGL(attn_temporal_weights_kernel<true>, grid, dim3(256), lds, s, a, out);
     } else {
-        static size_t attr = 0;
-        if (lds > attr) { VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_weights_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = lds; }
+        VD_RAISE_LDS((&attn_temporal_weights_kernel<false>), lds);
         hipLaunchKernelGGL(attn_temporal_weights_kernel<false>, grid, dim3(256), lds, s, a, out);
     }
     VD_HIP(hipGetLastError());
@@ -808,8 +803,7 @@ int launch_attn_spatial_weights(const AttnSpatialArgs& a, float* out, hipStream_
     VD_REQUIRE(a.C % a.heads == 0 && F % 4 == 0 && a.L <= 4096, "spatial attention weights: shape");
     const size_t lds = ((size_t)SQT * (F + 4) + (size_t)2 * SQT * (a.L + 1)) * sizeof(float);
     VD_REQUIRE(lds <= 150 * 1024, "spatial attention weights: sequence too long");
-    static size_t attr = 0;
-    if (lds > attr) { VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_spatial_weights_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = lds; }
+    VD_RAISE_LDS((&attn_spatial_weights_kernel), lds);
     hipLaunchKernelGGL(attn_spatial_weights_kernel, dim3((a.L + SQT - 1) / SQT, a.nfr), dim3(256), lds, s, a, out);
     VD_HIP(hipGetLastError());
     return 0;

@@ -442,13 +442,8 @@ int launch_conv_wino(const IgemmArgs& a, hipStream_t s) {
     g.TF = 64 / (TT * TT);                             // 1 or 4 frames
     g.tiles_x = Hl / (2 * TT); g.tiles_y = Hl / (2 * TT);
     const size_t lds = std::max((size_t)2 * (g.TF == 4 ? 7 : 6) * 64 * WLD * sizeof(float), (size_t)4 * 2 * 2 * 2 * 4 * 64 * 4 * sizeof(float));
-    static bool attr = false;
-    if (!attr) {
-        const void* fns[2] = {reinterpret_cast<const void*>(&conv3x3_wino_kernel<true>),
-                              reinterpret_cast<const void*>(&conv3x3_wino_kernel<false>)};
-        for (const void* f : fns) VD_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    VD_RAISE_LDS((&conv3x3_wino_kernel<true>), (size_t)160 * 1024);
+    VD_RAISE_LDS((&conv3x3_wino_kernel<false>), (size_t)160 * 1024);
     const int fgroups = (a.nfr + g.TF - 1) / g.TF;
     dim3 grid(g.tiles_x * g.tiles_y * fgroups, a.Cout / 64);
     if (g.TF == 4) hipLaunchKernelGGL((conv3x3_wino_kernel<true>), grid, dim3(256), lds, s, a, g);

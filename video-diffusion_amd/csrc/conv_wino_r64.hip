@@ -604,11 +604,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_r64_ups_kernel(IgemmArgs 
 
 template <auto KERN>
 static int r64_launch(dim3 grid, size_t lds, hipStream_t s, const IgemmArgs& k, const WinoR64Geom& g) {
-    static bool attr = false;                    // per kernel: each one that runs raises its own LDS limit once
-    if (!attr) {
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    VD_RAISE_LDS(KERN, (size_t)160 * 1024);      // per kernel and device: each one that runs raises its own LDS limit once
     hipLaunchKernelGGL(KERN, grid, dim3(256), lds, s, k, g);
     VD_HIP(hipGetLastError());
     return 0;

@@ -584,15 +584,8 @@ int launch_conv_wino_z128(const IgemmArgs& a, hipStream_t s) {
     g.ncb = a.Cout / 128;
     g.nitems = g.nbx * g.ncb;
     g.xcd_order = g.nbx % 8 == 0;
-    static bool attr[64] = {};                                        // per device: the attribute belongs to the device's copy of the function
-    int dev = 0;
-    VD_HIP(hipGetDevice(&dev));
-    VD_REQUIRE(dev >= 0 && dev < 64, "conv_wino_z128: device ordinal beyond the per-device attribute table");
-    if (!attr[dev]) {
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_z128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_z128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr[dev] = true;
-    }
+    VD_RAISE_LDS((&conv3x3_wino_z128_kernel<false>), (size_t)160 * 1024);
+    VD_RAISE_LDS((&conv3x3_wino_z128_kernel<true>), (size_t)160 * 1024);
     if (a.affA) {
         VD_REQUIRE(conv_wino_z128_act_supported(a), "conv_wino_z128 with the activation in its patch staging: shape not covered");
         hipLaunchKernelGGL(conv3x3_wino_z128_kernel<true>, dim3(g.nitems), dim3(256), z128::LDS_BYTES + 2 * a.Cin * sizeof(float), s, a, g);

@@ -187,13 +187,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 
 template <int BM, int BN>
 static int launch_t(const IgemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
     const size_t lds = 2 * (BM + BN) * LDP * sizeof(float);
-    if (!attr_set) {
-        VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    VD_RAISE_LDS((&igemm_kernel<BM, BN>), lds);
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
     hipLaunchKernelGGL((igemm_kernel<BM, BN>), grid, dim3(256), lds, s, a);
     VD_HIP(hipGetLastError());

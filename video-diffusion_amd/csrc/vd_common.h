@@ -31,6 +31,25 @@ extern thread_local std::string g_last_error;
         }                                                                              \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a DEVICE's copy of a function: raise it once per (launch site, device) -- a process
+// that drives several devices must not find the flag of device 0 set when it launches on device 1.  `st` is the site's static.
+struct LdsAttr { size_t have[64] = {}; };
+inline int raise_dynamic_lds(LdsAttr& st, const void* fn, size_t bytes) {
+    int dev = 0;
+    VD_HIP(hipGetDevice(&dev));
+    VD_REQUIRE(dev >= 0 && dev < 64, "device ordinal beyond the per-device attribute table");
+    if (bytes > st.have[dev]) {
+        VD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        st.have[dev] = bytes;
+    }
+    return 0;
+}
+#define VD_RAISE_LDS(fn, bytes)                                                                        \
+    do {                                                                                               \
+        static vd::LdsAttr lds_attr_;                                                                  \
+        if (int rc_ = vd::raise_dynamic_lds(lds_attr_, reinterpret_cast<const void*>(fn), (bytes))) return rc_; \
+    } while (0)
+
 // ---------------------------------------------------------------- kernel argument blocks
 // Implicit-GEMM convolution / linear layer on NHWC activations (see igemm.hip).
 struct IgemmArgs {
