@@ -603,6 +603,9 @@ def main():
             if traffic and c["mb"]:
                 roofline["traffic_over_algorithmic"] = round(traffic / (c["mb"] / c["launches"] * 1e6), 3)
     vdist.barrier()
+    # the last collective of the run: every rank leaves the job together (a rank that exits with its RCCL communicator alive can stall the others' teardown)
+    if tdist.is_initialized():
+        tdist.destroy_process_group()
 
     if rank != 0:
         return
