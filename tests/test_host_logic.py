@@ -519,3 +519,154 @@ def test_nll_job_scores_every_window_once_and_skips_finished_videos(tmp_path):
         video_nll.run(args(task_id=1), create=create, device=torch.device("cpu"))
     with pytest.raises(NotImplementedError):
         video_nll.run(args(indices=[0]), create=create, device=torch.device("cpu"))
+
+
+def test_full_sampler_host_loop_write_back_against_a_plain_restatement():
+    """video_sample_full.infer_video's host logic on CPU with a stand-in step (sample = x + 1 on latent slots, observed slots untouched): the
+    vertical + horizontal loop nest, the per-item gathers / scatters of the adaptive branch and the all-timestep record must equal a plain
+    item-by-item restatement of scripts/video_sample_full.py:88-323.  (The arithmetic of the step is the GPU tests' business.)"""
+    import torch
+    from video_diffusion_amd import inference_util as iu
+    from video_diffusion_amd.video_sample_full import infer_video
+
+    class Model:
+        device = torch.device("cpu")
+
+        def check_device_errors(self):
+            pass
+
+    class Diff:
+        num_timesteps = 4
+
+        def __init__(self):
+            self.calls = []
+
+        def p_sample(self, model, x, t, clip_denoised=True, model_kwargs=None, **kw):
+            self.calls.append((int(t[0]), model_kwargs["observed_frames"], model_kwargs["frame_indices"].tolist()))
+            lat = model_kwargs["latent_mask"]
+            return {"sample": x + lat * (1.0 + 0.01 * model_kwargs["frame_indices"][:, :, None, None, None].float())}
+
+    B, T, obs, mf, step = 2, 9, 3, 5, 2
+    batch = torch.rand(B, T, 3, 4, 4, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    for mode, vertical in (("autoreg", 0), ("autoreg", 2), ("adaptive-autoreg", 1), ("hierarchy-2", 4)):
+        d = Diff()
+        got, every = infer_video(mode, Model(), d, batch, mf, obs, step, vertical_steps=vertical, observed_frames="x_t_minus_1",
+                                 save_all_timesteps=True, adaptive_distance="l2")
+        # plain restatement
+        samples = torch.zeros_like(batch)
+        samples[:, :obs] = batch[:, :obs]
+        rec = torch.zeros(B, 4, T, 3, 4, 4)
+        rec[:, :, :obs] = samples[:, :obs].unsqueeze(1)
+        adaptive = "adaptive" in mode
+
+        def passes(timesteps, record_rows):
+            it = iter(iu.inference_strategies[mode](video_length=T, num_obs=obs, max_frames=mf, step_size=step, optimal_schedule_path=None,
+                                                    **(dict(distance="l2") if adaptive else {})))
+            while True:
+                if adaptive:
+                    it.set_videos(samples)
+                try:
+                    o, l = next(it)
+                except StopIteration:
+                    return
+                for i in range(B):
+                    oi, li = (o[i], l[i]) if adaptive else (o, l)
+                    x = samples[i, list(oi) + list(li)].clone()
+                    for r, ts in enumerate(timesteps):
+                        x[len(oi):] += 1.0 + 0.01 * torch.tensor(li).float()[:, None, None, None]
+                        if record_rows is not None:
+                            rec[i, record_rows[r], li] = x[len(oi):]
+                    samples[i, li] = x[len(oi):]
+
+        steps = list(range(4))[::-1]
+        if vertical:
+            passes(steps[:vertical], list(range(vertical)))
+        for k, ts in enumerate(steps[vertical:]):
+            passes([ts], None)
+            rec[:, vertical + k] = samples
+        assert np.array_equal(got, samples.numpy()), (mode, vertical)
+        assert np.array_equal(every, rec.numpy()), (mode, vertical)
+        # vertical windows are sampled with x_0, horizontal ones with the option as given; timesteps high to low
+        assert {c[1] for c in d.calls if c[0] >= 4 - vertical} <= {"x_0", "x_t_minus_1"} and d.calls[-1][0] == 0
+        if vertical:
+            assert d.calls[0][1] == "x_0"
+
+
+def test_sampling_job_covers_every_selected_item_exactly_once_across_ranks():
+    """The job's partition (video_sample.py:570-590 + one process per GPU): for any dataset size, batch size, world size and selection
+    option, the batches dealt to the ranks r, r + R, .. cover every selected dataset item exactly once, in dataset order within a batch."""
+    from argparse import Namespace
+    from video_diffusion_amd import dist as vdist
+    from video_diffusion_amd import video_sample as vs
+    rng = np.random.RandomState(0)
+    for _ in range(200):
+        n, bs, world = int(rng.randint(1, 40)), int(rng.randint(1, 9)), int(rng.randint(1, 9))
+        kind = rng.randint(4)
+        a = Namespace(batch_size=bs, indices=None, task_id=None, subset_size=None)
+        if kind == 1:
+            a.indices = sorted(rng.choice(n, size=rng.randint(1, n + 1), replace=False).tolist())
+        elif kind == 2:
+            a.task_id = int(rng.randint(0, max(1, n // bs)))
+        elif kind == 3:
+            a.subset_size = int(rng.randint(1, n + 1))
+        sel = vs.resolve_indices(a, n)
+        batches = [sel[k:k + bs] for k in range(0, len(sel), bs)]
+        seen = []
+        for r in range(world):
+            for t in vdist.task_ids(len(batches), r, world):
+                seen += batches[t]
+        assert sorted(seen) == sorted(sel) and len(set(seen)) == len(seen)
+        want = a.indices if kind == 1 else list(range(a.task_id * bs, (a.task_id + 1) * bs)) if kind == 2 else list(range(a.subset_size)) if kind == 3 else list(range(n))
+        assert sel == want
+
+
+def test_windowed_sampler_host_loop_and_all_timestep_record_against_a_plain_restatement():
+    """video_sample.infer_video's host logic on CPU with a stand-in step: window assembly, the write-back of the last n_latent slots, the
+    per-item branch of the adaptive modes and the (B, num_timesteps, T, ...) record of --save_all_timesteps (scripts/video_sample.py:84-186)."""
+    import torch
+    from video_diffusion_amd import inference_util as iu
+    from video_diffusion_amd.video_sample import infer_video
+
+    class Model:
+        device = torch.device("cpu")
+
+        def check_device_errors(self):
+            pass
+
+    class Diff:
+        num_timesteps = 3
+
+        def p_sample(self, model, x, t, clip_denoised=True, model_kwargs=None, **kw):
+            assert model_kwargs["x_t_minus_1"] is model_kwargs["x0"] and kw["return_attn_weights"] is False
+            return {"sample": x * 0.5 + model_kwargs["latent_mask"] * (float(t[0]) + 0.1 * model_kwargs["frame_indices"][:, :, None, None, None].float())}
+
+    B, T, obs, mf, step = 2, 10, 2, 5, 3
+    batch = torch.rand(B, T, 3, 4, 4, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    for mode in ("autoreg", "adaptive-autoreg", "hierarchy-2", "independent"):
+        got, every = infer_video(mode, Model(), Diff(), batch, mf, obs, step, adaptive_distance="l2", save_all_timesteps=True)
+        samples = torch.zeros_like(batch)
+        samples[:, :obs] = batch[:, :obs]
+        rec = torch.zeros(B, 3, T, 3, 4, 4)
+        rec[:, :, :obs] = samples[:, :obs].unsqueeze(1)
+        adaptive = "adaptive" in mode
+        it = iter(iu.inference_strategies[mode](video_length=T, num_obs=obs, max_frames=mf, step_size=step, optimal_schedule_path=None,
+                                                **(dict(distance="l2") if adaptive else {})))
+        while True:
+            if adaptive:
+                it.set_videos(samples)
+            try:
+                o, l = next(it)
+            except StopIteration:
+                break
+            for i in range(B):
+                oi, li = (o[i], l[i]) if adaptive else (o, l)
+                x = samples[i, list(oi) + list(li)].clone()
+                for r, ts in enumerate((2, 1, 0)):
+                    x = x * 0.5
+                    x[len(oi):] += ts + 0.1 * torch.tensor(li).float()[:, None, None, None]
+                    rec[i, r, li] = x[len(oi):]
+                samples[i, li] = x[len(oi):]
+        assert np.array_equal(got, samples.numpy()), mode
+        assert np.array_equal(every, rec.numpy()), mode
+        plain, placeholder = infer_video(mode, Model(), Diff(), batch, mf, obs, step, adaptive_distance="l2")
+        assert np.array_equal(plain, got) and placeholder.shape == (1,)
